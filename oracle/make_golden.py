@@ -1,0 +1,304 @@
+"""TEST INFRASTRUCTURE — golden-vector generator.  Runs ONLY in the build
+container: it imports the reference (/root/reference) through ``ref_shim`` and
+writes input/expected-output vectors to ``tests/golden/*.npz``.  The vectors are
+data; no reference source travels.
+
+    python oracle/make_golden.py [--only init,ops,nets,losses,steps,curve]
+
+Conventions: every fixture stores the seeds needed to regenerate weights
+(``torch.manual_seed(seed)`` then construct ``StylEx(...)``), all inputs that are
+not weights, and the reference's outputs.  Large tensors are stored as
+``stats`` = (sum, abs-sum, first 8 values).
+"""
+import argparse
+import os
+import random
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def stats(t):
+    t = t.detach().double().reshape(-1)
+    return np.concatenate([[t.sum().item(), t.abs().sum().item()], t[:8].numpy(), np.zeros(max(0, 8 - t.numel()))])
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    clean = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **clean)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+INIT_CONFIGS = [(8, 2, 16), (16, 4, 32), (32, 4, 64)]
+
+
+def gen_init(st):
+    """(1) init parity: state dict of StylEx under torch.manual_seed(seed)."""
+    for (size, cap, fmax) in INIT_CONFIGS:
+        seed = 100 + size
+        torch.manual_seed(seed)
+        m = st.StylEx(image_size=size, network_capacity=cap, fmap_max=fmax)
+        sd = m.state_dict()
+        out = {"seed": seed, "config": np.array([size, cap, fmax]), "keys": np.array(list(sd.keys()))}
+        out["shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        out["stats"] = np.stack([stats(v) for v in sd.values()])
+        for k, v in sd.items():
+            if v.numel() <= 2048:
+                out["full/" + k] = v
+        save("init_%d" % size, **out)
+
+
+def gen_ops(st):
+    """(2) op parity: Conv2DMod fwd+grads, Blur, Upsample, blocks, StyleVectorizer."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # Blur / Upsample on a non-square odd-ish tensor
+    x = torch.randn(2, 5, 6, 10, generator=g)
+    out["blur/x"] = x
+    out["blur/y"] = st.Blur()(x)
+    out["up/x"] = x
+    out["up/y"] = torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)(x)
+    # gradient of both (they are linear; the adjoint is what the backward kernels implement)
+    for nm, fn in (("blur", st.Blur()), ("up", torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))):
+        xr = x.clone().requires_grad_()
+        y = fn(xr)
+        r = torch.randn(y.shape, generator=g)
+        (y * r).sum().backward()
+        out[nm + "/r"] = r
+        out[nm + "/gx"] = xr.grad
+    # Conv2DMod cases
+    for tag, (ci, co, k, demod, hw, b, wseed) in {
+        "mod3": (16, 24, 3, True, 8, 2, 21),
+        "mod1": (16, 3, 1, False, 8, 2, 22),
+        "mod512": (512, 512, 3, True, 4, 2, 23),
+    }.items():
+        torch.manual_seed(wseed)
+        conv = st.Conv2DMod(ci, co, k, demod=demod)
+        x = torch.randn(b, ci, hw, hw, generator=g, requires_grad=True)
+        y = torch.randn(b, ci, generator=g, requires_grad=True)
+        o = conv(x, y)
+        r = torch.randn(o.shape, generator=g)
+        (o * r).sum().backward()
+        out[tag + "/cfg"] = np.array([ci, co, k, int(demod), hw, b, wseed])
+        out[tag + "/x"], out[tag + "/y"], out[tag + "/r"] = x, y, r
+        out[tag + "/out"], out[tag + "/gx"], out[tag + "/gy"] = o, x.grad, y.grad
+        if conv.weight.numel() <= 8192:
+            out[tag + "/w"], out[tag + "/gw"] = conv.weight, conv.weight.grad
+        else:
+            out[tag + "/w_stats"], out[tag + "/gw_stats"] = stats(conv.weight), stats(conv.weight.grad)
+            out[tag + "/gw_slice"] = conv.weight.grad[:4, :4]
+    # GeneratorBlock incl. transposed noise (non-zero to_noise weights so the permute matters)
+    torch.manual_seed(31)
+    blk = st.GeneratorBlock(20, 8, 12, upsample=True, upsample_rgb=True)
+    x = torch.randn(2, 8, 4, 4, generator=g)
+    prev = torch.randn(2, 3, 8, 8, generator=g)
+    istyle = torch.randn(2, 20, generator=g)
+    inoise = torch.rand(2, 16, 16, 1, generator=g)
+    xo, rgb, sc = blk(x, prev, istyle, inoise)
+    out["gblock/seed"] = 31
+    out["gblock/x"], out["gblock/prev"], out["gblock/istyle"], out["gblock/inoise"] = x, prev, istyle, inoise
+    out["gblock/xo"], out["gblock/rgb"], out["gblock/coords"] = xo, rgb, sc
+    for k2, v in blk.state_dict().items():
+        out["gblock/sd/" + k2] = v
+    # DiscriminatorBlock
+    torch.manual_seed(32)
+    dblk = st.DiscriminatorBlock(6, 10, downsample=True)
+    x = torch.randn(2, 6, 8, 8, generator=g)
+    out["dblock/seed"] = 32
+    out["dblock/x"], out["dblock/y"] = x, dblk(x)
+    for k2, v in dblk.state_dict().items():
+        out["dblock/sd/" + k2] = v
+    # StyleVectorizer (small emb)
+    torch.manual_seed(33)
+    sv = st.StyleVectorizer(24, 8, lr_mul=0.1)
+    z = torch.randn(3, 24, generator=g)
+    out["svec/seed"] = 33
+    out["svec/z"], out["svec/w"] = z, sv(z)
+    save("ops", **out)
+
+
+def gen_nets(st):
+    """(3) network parity for image_size 16 & 32, cap 4."""
+    for (size, cap, fmax) in [(16, 4, 32), (32, 4, 64)]:
+        seed = 200 + size
+        torch.manual_seed(seed)
+        m = st.StylEx(image_size=size, network_capacity=cap, fmap_max=fmax)
+        # make the noise path non-trivial: perturb to_noise params deterministically
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for blk in m.G.blocks:
+                for lin in (blk.to_noise1, blk.to_noise2):
+                    lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.3)
+                    lin.bias.copy_(torch.randn(lin.bias.shape, generator=g) * 0.1)
+        w = torch.randn(2, m.G.num_layers, 514, generator=g)
+        inoise = torch.rand(2, size, size, 1, generator=g)
+        x = torch.rand(2, 3, size, size, generator=g)
+        rgb, coords = m.G(w, inoise, get_style_coords=True)
+        save("nets_%d" % size, seed=seed, config=np.array([size, cap, fmax]), w=w, inoise=inoise, x=x,
+             rgb=rgb, coords=coords, d_out=m.D(x), enc_out=m.encoder(x), d_of_g=m.D(rgb),
+             s_out=m.S(w[:, 0]))
+
+
+def gen_losses(st):
+    """(4) loss parity incl. double backward (GP) and PL lengths."""
+    size, cap, fmax = 16, 4, 32
+    seed = 300
+    torch.manual_seed(seed)
+    m = st.StylEx(image_size=size, network_capacity=cap, fmap_max=fmax)
+    g = torch.Generator().manual_seed(seed + 1)
+    out = {"seed": seed, "config": np.array([size, cap, fmax])}
+    real = torch.randn(4, generator=g)
+    fake = torch.randn(4, generator=g)
+    out["hinge/real"], out["hinge/fake"] = real, fake
+    out["hinge/d"], out["hinge/g"] = st.hinge_loss(real, fake), st.gen_hinge_loss(fake, None)
+    # gradient penalty value + resulting D grads (double backward)
+    x = torch.rand(3, 3, size, size, generator=g).requires_grad_()
+    d_out = m.D(x)
+    gp = st.gradient_penalty(x, d_out)
+    m.D.zero_grad()
+    gp.backward()
+    out["gp/x"], out["gp/value"] = x.detach(), gp.detach()
+    names, gstats = [], []
+    for n, p in m.D.named_parameters():
+        if p.grad is None:  # GP does not depend on every bias
+            continue
+        names.append(n)
+        gstats.append(stats(p.grad))
+    out["gp/grad_names"], out["gp/grad_stats"] = np.array(names), np.stack(gstats)
+    out["gp/grad_fc_w"] = m.D.fc.weight.grad
+    out["gp/grad_b0_res_w"] = m.D.blocks[0].conv_res.weight.grad
+    # path lengths (+ grads of the PL loss wrt G params)
+    w = torch.randn(3, m.G.num_layers, 514, generator=g).requires_grad_()
+    inoise = torch.rand(3, size, size, 1, generator=g)
+    img = m.G(w, inoise)
+    torch.manual_seed(seed + 2)  # pl_noise draw inside calc_pl_lengths (:309)
+    pl = st.calc_pl_lengths(w, img)
+    m.G.zero_grad()
+    ((pl - 0.3) ** 2).mean().backward()
+    out["pl/w"], out["pl/inoise"], out["pl/noise_seed"], out["pl/lengths"] = w.detach(), inoise, seed + 2, pl.detach()
+    names, gstats = [], []
+    for n, p in m.G.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gstats.append(stats(p.grad))
+    out["pl/grad_names"], out["pl/grad_stats"] = np.array(names), np.stack(gstats)
+    out["pl/grad_w"] = w.grad
+    # KL + reconstruction (LPIPS stand-in, seed recorded)
+    a = torch.randn(4, 2, generator=g)
+    b = torch.randn(4, 2, generator=g)
+    out["kl/real"], out["kl/fake"], out["kl/value"] = a, b, st.classifier_kl_loss(a, b)
+    i1 = torch.rand(2, 3, 32, 32, generator=g)
+    i2 = torch.rand(2, 3, 32, 32, generator=g)
+    w1 = torch.randn(2, 512, generator=g)
+    w2 = torch.randn(2, 512, generator=g)
+    out["rec/i1"], out["rec/i2"], out["rec/w1"], out["rec/w2"] = i1, i2, w1, w2
+    out["rec/value"] = st.reconstruction_loss(i1, i2, w2, w1)
+    out["rec/lpips_seed"] = 4242
+    out["rec/lpips_value"] = st.lpips_loss(st.lpips_normalize(i1), st.lpips_normalize(i2)).reshape(-1)
+    save("losses", **out)
+
+
+STEP_CASES = {
+    # tag: (gae, alternating, n_steps, start_step, pl_mean0)
+    "gae1_alt": (1, True, 5, 0, None),
+    "gae2_alt": (2, True, 5, 0, None),
+    "gae2_noalt": (2, False, 3, 0, None),
+    "gae2_pl": (2, True, 2, 5024, 0.05),
+}
+
+
+def param_stats(model):
+    names, st_ = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        st_.append(stats(p))
+    return np.array(names), np.stack(st_)
+
+
+def gen_steps(st):
+    """(5) step parity: Trainer.train() x N on synthetic data."""
+    size, cap, fmax, bs = 32, 4, 64, 2
+    for tag, (gae, alt, n, start, pl0) in STEP_CASES.items():
+        cls = ref_shim.TinyClassifier(seed=99)
+        gd = torch.Generator().manual_seed(7)
+        batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+        seed_all(42)
+        tmp = tempfile.mkdtemp()
+        tr = ref_shim.make_reference_trainer(st, tmp, cls, batches, image_size=size, network_capacity=cap,
+                                             fmap_max=fmax, batch_size=bs, gradient_accumulate_every=gae,
+                                             alternating_training=alt, lr=2e-4, ttur_mult=1.5, rec_scaling=1,
+                                             kl_scaling=1)
+        tr.init_StylEx()
+        tr.steps = start
+        tr.pl_mean = pl0
+        rows = []
+        for i in range(n):
+            tr.train()
+            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                         tr.last_gp_loss if tr.last_gp_loss is not None else np.nan,
+                         tr.pl_mean if tr.pl_mean is not None else np.nan])
+            print(tag, i, rows[-1])
+        names, pst = param_stats(tr.StylEx)
+        save("steps_" + tag, config=np.array([size, cap, fmax, bs, gae, int(alt), n, start]),
+             pl_mean0=np.nan if pl0 is None else pl0, data_seed=7, seed=42, cls_seed=99, lpips_seed=4242,
+             scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst)
+
+
+def gen_curve(st, n=100):
+    """100-step scalar trajectory, config 1 shape (64 px, B=4) at GAE=2."""
+    size, cap, fmax, bs, gae = 64, 16, 512, 4, 2
+    cls = ref_shim.TinyClassifier(seed=99)
+    gd = torch.Generator().manual_seed(7)
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    seed_all(42)
+    tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), cls, batches, image_size=size,
+                                         network_capacity=cap, fmap_max=fmax, batch_size=bs,
+                                         gradient_accumulate_every=gae, lr=2e-4, ttur_mult=1.5, rec_scaling=1,
+                                         kl_scaling=1)
+    rows, t0 = [], time.time()
+    for i in range(n):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                     tr.last_gp_loss if tr.last_gp_loss is not None else np.nan])
+        if i % 10 == 0:
+            print("curve", i, rows[-1], "%.0fs" % (time.time() - t0))
+    save("curve_64", config=np.array([size, cap, fmax, bs, gae]), seed=42, data_seed=7, cls_seed=99,
+         lpips_seed=4242, scalars=np.array(rows, dtype=np.float64), wall_s=time.time() - t0,
+         threads=torch.get_num_threads())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="init,ops,nets,losses,steps")
+    a = ap.parse_args()
+    st = ref_shim.import_reference()
+    todo = a.only.split(",")
+    for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
+                     ("steps", gen_steps), ("curve", gen_curve)):
+        if name in todo:
+            fn(st)
+
+
+if __name__ == "__main__":
+    main()

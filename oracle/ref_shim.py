@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE — runs ONLY in the build container (needs /root/reference).
+
+Imports the reference's own ``stylex/stylex_train.py`` on CPU by registering
+stub modules for the third-party packages that are absent offline, so that the
+reference itself can generate golden vectors (``oracle/make_golden.py``) and
+validate the restatement in ``oracle/stylex_oracle.py``.
+
+Nothing from here travels to the GPU box as an executable dependency: the
+``-m gpu`` tests, ``smoke()`` and ``bench.py`` never import this file.
+
+Third-party semantics restated here (each one is "parity unpinned" at the
+package boundary because the real package is not installable offline):
+
+* kornia==0.6.2 ``filter2d(x, k, border_type='reflect', normalized=True)``
+  (call site stylex_train.py:153) = reflect-pad by k//2 then depthwise
+  correlation with k / sum|k|.
+* torchvision==0.11.1 ``transforms.functional.resize`` on tensors
+  (resnet_classifier.py:61) = bilinear, align_corners=False, no antialias.
+* torchvision ``transforms.Normalize`` = (x - mean) / std per channel.
+* lpips==0.1.4 ``LPIPS(net='alex')``: AlexNet features + learned 1x1 heads;
+  the pretrained weights are not available offline, so a seeded
+  random-weight network of the published architecture is used
+  (``oracle/lpips_standin.py``) — fixtures record that fact.
+"""
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF_ROOT = os.environ.get("STYLEX_REFERENCE", "/root/reference")
+REF_STYLEX = os.path.join(REF_ROOT, "stylex")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+
+def reference_available():
+    return os.path.isfile(os.path.join(REF_STYLEX, "stylex_train.py"))
+
+
+def _filter2d(x, kernel, border_type="reflect", normalized=False):
+    k = kernel.to(x).unsqueeze(1)  # [1,1,kh,kw]
+    if normalized:
+        k = k / k.abs().sum(dim=(-2, -1), keepdim=True)
+    c = x.shape[1]
+    kh, kw = k.shape[-2:]
+    k = k.expand(c, 1, kh, kw)
+    xp = F.pad(x, [kw // 2, kw // 2, kh // 2, kh // 2], mode=border_type)
+    return F.conv2d(xp, k, groups=c)
+
+
+class _Identity:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, x):
+        return x
+
+
+class _Compose:
+    def __init__(self, ts):
+        self.ts = list(ts)
+
+    def __call__(self, x):
+        for t in self.ts:
+            x = t(x)
+        return x
+
+
+class _Normalize:
+    def __init__(self, mean, std):
+        self.mean = torch.tensor(mean).view(1, -1, 1, 1)
+        self.std = torch.tensor(std).view(1, -1, 1, 1)
+
+    def __call__(self, x):
+        return (x - self.mean.to(x)) / self.std.to(x)
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("fire", Fire=lambda f: None)
+    from lpips_standin import LPIPSStandIn
+
+    mod("lpips", LPIPS=LPIPSStandIn)
+    mod("aim", Session=object)
+    mod("vector_quantize_pytorch", VectorQuantize=object)
+    mod("torch.utils.tensorboard", SummaryWriter=object)
+    kf = mod("kornia.filters", filter2d=_filter2d)
+    mod("kornia", filters=kf)
+
+    tf = mod("torchvision.transforms.functional",
+             resize=lambda x, s: F.interpolate(x, size=s, mode="bilinear", align_corners=False))
+    tr_attrs = dict(Compose=_Compose, Lambda=_Identity, Resize=_Identity, RandomResizedCrop=_Identity,
+                    CenterCrop=_Identity, ToTensor=_Identity, Normalize=_Normalize, ToPILImage=_Identity,
+                    functional=tf)
+    tt = mod("torchvision.transforms", **tr_attrs)
+    tt.transforms = tt  # `from torchvision.transforms import transforms`
+    tv = mod("torchvision", transforms=tt)
+    tv.utils = types.SimpleNamespace(save_image=lambda *a, **k: None, make_grid=lambda x, **k: x)
+    tv.datasets = types.SimpleNamespace()
+    mod("retry", api=None)
+    mod("retry.api", retry_call=lambda f, **k: f())
+
+
+_ST = None
+
+
+def import_reference():
+    """Return the reference's ``stylex_train`` module, imported once on CPU."""
+    global _ST
+    if _ST is not None:
+        return _ST
+    if not reference_available():
+        raise RuntimeError("reference not present at %s" % REF_ROOT)
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    real_avail = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True  # import-time assert, stylex_train.py:51
+    seed_state = torch.random.get_rng_state()
+    try:
+        torch.manual_seed(1234)  # module-level lpips stand-in draws weights at import (:404)
+        sys.path.insert(0, REF_STYLEX)
+        import stylex_train as st  # noqa
+    finally:
+        torch.cuda.is_available = real_avail if not callable(real_avail) else (lambda: False)
+        torch.random.set_rng_state(seed_state)
+        if REF_STYLEX in sys.path:
+            sys.path.remove(REF_STYLEX)
+    _ST = st
+    return st
+
+
+class TinyClassifier:
+    """Seeded stand-in for the frozen classifier object used by Trainer
+    (reference: ResNet/MobileNet wrappers with ``classify_images``).  Used for
+    step-parity fixtures, where the real torch.hub weights are unavailable."""
+
+    def __init__(self, seed=99, num_classes=2, image_size=32):
+        g = torch.Generator().manual_seed(seed)
+        self.w1 = torch.randn(8, 3, 3, 3, generator=g) * 0.3
+        self.b1 = torch.randn(8, generator=g) * 0.1
+        self.w2 = torch.randn(num_classes, 8, generator=g) * 0.5
+        self.b2 = torch.randn(num_classes, generator=g) * 0.1
+        self.mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        self.std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        self.image_size = image_size
+
+    def to(self, device):
+        for n in ("w1", "b1", "w2", "b2", "mean", "std"):
+            setattr(self, n, getattr(self, n).to(device))
+        return self
+
+    def classify_images(self, images):
+        x = (images - self.mean) / self.std
+        x = F.leaky_relu(F.conv2d(x, self.w1, self.b1, stride=2, padding=1), 0.2)
+        x = x.mean(dim=(2, 3))
+        return x @ self.w2.t() + self.b2
+
+
+def make_reference_trainer(st, base_dir, classifier, batches, **kw):
+    """Build the reference ``Trainer`` wired to in-memory data."""
+    st.ResNet = lambda *a, **k: classifier
+    st.MobileNet = lambda *a, **k: classifier
+    args = dict(name="gold", base_dir=base_dir, classifier_name="resnet", classifier_path="x",
+                tensorboard_dir=None, evaluate_every=10 ** 9, save_every=10 ** 9)
+    args.update(kw)
+    tr = st.Trainer(**args)
+    tr.loader = st.cycle(batches)
+    tr.dataset = list(range(1000))
+    tr.save = lambda *a, **k: None
+    tr.evaluate = lambda *a, **k: None
+    return tr

@@ -1,0 +1,568 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the StylEx hot path.
+
+A literal, slow, obviously-right restatement in plain PyTorch (CPU, fp32 or
+fp64) of the algorithm in the reference's ``stylex/stylex_train.py``.  It is
+the checker the HIP path is compared against; it is NOT the product and must
+never be imported by the package under ``explaining-in-style-reproducibility-study_amd/``.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.
+
+Pinning: ``oracle/make_golden.py`` imports the *reference itself* in the build
+container and stores its outputs under ``tests/golden/``;
+``tests/test_oracle_vs_golden.py`` checks every function here against those
+vectors (init parity, op parity, network parity, loss parity, step parity).
+Third-party boundaries that could not be pinned offline (kornia blur, LPIPS
+weights, torchvision classifier weights) are listed in ``oracle/ref_shim.py``.
+
+Every function cites the reference file:line it follows
+(paths relative to /root/reference/stylex/).
+"""
+import math
+import random as _pyrandom
+from math import log2
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# resampling ops — exact index rules
+# --------------------------------------------------------------------------
+
+
+def upsample2x_index_rule(n):
+    """Source indices / weights of bilinear x2, align_corners=False
+    (stylex_train.py:614,679 -> nn.Upsample).  For output o:
+    o=2k   -> 0.25*in[max(k-1,0)] + 0.75*in[k]
+    o=2k+1 -> 0.75*in[k]          + 0.25*in[min(k+1,n-1)]
+    Returned as integer tensors (lo, hi) and float weight of ``hi``."""
+    o = torch.arange(2 * n)
+    k = o // 2
+    odd = (o % 2) == 1
+    lo = torch.where(odd, k, (k - 1).clamp(min=0))
+    hi = torch.where(odd, (k + 1).clamp(max=n - 1), k)
+    w_hi = torch.where(odd, torch.tensor(0.25), torch.tensor(0.75))
+    return lo, hi, w_hi
+
+
+def upsample2x_bilinear_explicit(x):
+    """Separable restatement of nn.Upsample(scale_factor=2,'bilinear',False)."""
+    _, _, h, w = x.shape
+    lo, hi, wh = upsample2x_index_rule(h)
+    wh = wh.to(x.dtype).view(1, 1, -1, 1)
+    x = x.index_select(2, lo) * (1 - wh) + x.index_select(2, hi) * wh
+    lo, hi, wh = upsample2x_index_rule(w)
+    wh = wh.to(x.dtype).view(1, 1, 1, -1)
+    return x.index_select(3, lo) * (1 - wh) + x.index_select(3, hi) * wh
+
+
+def upsample2x_bilinear(x):
+    """What the reference executes (stylex_train.py:614,679)."""
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+
+
+def reflect_index(i, n):
+    """kornia 'reflect' border for pad 1: -1 -> 1, n -> n-2 (stylex_train.py:153)."""
+    if i < 0:
+        return -i
+    if i >= n:
+        return 2 * n - 2 - i
+    return i
+
+
+def blur3x3_reflect_explicit(x):
+    """[1,2,1]x[1,2,1]/16 depthwise blur with reflect border, by explicit indices."""
+    _, _, h, w = x.shape
+    taps = (1.0, 2.0, 1.0)
+    rows = [torch.tensor([reflect_index(i + d, h) for i in range(h)]) for d in (-1, 0, 1)]
+    cols = [torch.tensor([reflect_index(i + d, w) for i in range(w)]) for d in (-1, 0, 1)]
+    out = 0
+    for a, ri in zip(taps, rows):
+        xr = x.index_select(2, ri)
+        for b, ci in zip(taps, cols):
+            out = out + (a * b / 16.0) * xr.index_select(3, ci)
+    return out
+
+
+def blur3x3_reflect(x):
+    """Blur.forward (stylex_train.py:144-153) = kornia filter2d(normalized=True)."""
+    c = x.shape[1]
+    f = torch.tensor([1.0, 2.0, 1.0], dtype=x.dtype, device=x.device)
+    k = (f[None, :] * f[:, None])
+    k = (k / k.abs().sum()).expand(c, 1, 3, 3)
+    return F.conv2d(F.pad(x, [1, 1, 1, 1], mode="reflect"), k, groups=c)
+
+
+# --------------------------------------------------------------------------
+# modulated convolution — literal per-sample-weight form
+# --------------------------------------------------------------------------
+
+
+def same_padding(size, kernel, dilation=1, stride=1):
+    """Conv2DMod._get_same_padding (stylex_train.py:644-645)."""
+    return ((size - 1) * (stride - 1) + dilation * (kernel - 1)) // 2
+
+
+def modulated_conv2d(x, style, weight, demod=True, eps=1e-8):
+    """Conv2DMod.forward (stylex_train.py:647-667): per-sample weights
+    W[b,o,i,kh,kw] = weight[o,i,kh,kw]*(style[b,i]+1), optional demodulation
+    by rsqrt(sum_{i,kh,kw} W^2 + eps), applied as a grouped convolution."""
+    b, c, h, w = x.shape
+    o, _, k, _ = weight.shape
+    wmod = weight.unsqueeze(0) * (style.reshape(b, 1, c, 1, 1) + 1)
+    if demod:
+        wmod = wmod * torch.rsqrt(wmod.pow(2).sum(dim=(2, 3, 4), keepdim=True) + eps)
+    pad = same_padding(h, k)
+    y = F.conv2d(x.reshape(1, b * c, h, w), wmod.reshape(b * o, c, k, k), padding=pad, groups=b)
+    return y.reshape(b, o, h, w)
+
+
+def lrelu(x):
+    return F.leaky_relu(x, 0.2)
+
+
+# --------------------------------------------------------------------------
+# networks (parameter containers keep the reference's state-dict key names and
+# its parameter-creation order so torch.manual_seed gives identical weights)
+# --------------------------------------------------------------------------
+
+
+class _Blur(nn.Module):  # stylex_train.py:144-153 (buffer 'f' is part of the state dict)
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("f", torch.Tensor([1, 2, 1]))
+
+    def forward(self, x):
+        return blur3x3_reflect(x)
+
+
+class _Up(nn.Module):
+    def forward(self, x):
+        return upsample2x_bilinear(x)
+
+
+class _LReLU(nn.Module):
+    def forward(self, x):
+        return lrelu(x)
+
+
+class OEqualLinear(nn.Module):  # stylex_train.py:576-587
+    def __init__(self, i, o, lr_mul):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(o, i))
+        self.bias = nn.Parameter(torch.zeros(o))
+        self.lr_mul = lr_mul
+
+    def forward(self, x):
+        return F.linear(x, self.weight * self.lr_mul, self.bias * self.lr_mul)
+
+
+class OStyleVectorizer(nn.Module):  # stylex_train.py:590-601
+    def __init__(self, emb, depth, lr_mul=0.1):
+        super().__init__()
+        seq = []
+        for _ in range(depth):
+            seq += [OEqualLinear(emb, emb, lr_mul), _LReLU()]
+        self.net = nn.Sequential(*seq)
+
+    def forward(self, z):
+        return self.net(F.normalize(z, dim=1))
+
+
+class OConv2DMod(nn.Module):  # stylex_train.py:632-667
+    def __init__(self, cin, cout, kernel, demod=True):
+        super().__init__()
+        self.filters, self.demod, self.kernel, self.eps = cout, demod, kernel, 1e-8
+        self.weight = nn.Parameter(torch.randn(cout, cin, kernel, kernel))
+        nn.init.kaiming_normal_(self.weight, a=0, mode="fan_in", nonlinearity="leaky_relu")
+
+    def forward(self, x, y):
+        return modulated_conv2d(x, y, self.weight, self.demod, self.eps)
+
+
+class ORGBBlock(nn.Module):  # stylex_train.py:604-629
+    def __init__(self, latent_dim, cin, upsample):
+        super().__init__()
+        self.to_style = nn.Linear(latent_dim, cin)
+        self.conv = OConv2DMod(cin, 3, 1, demod=False)
+        self.upsample = nn.Sequential(_Up(), _Blur()) if upsample else None
+
+    def forward(self, x, prev_rgb, istyle):
+        rgb = self.conv(x, self.to_style(istyle))
+        if prev_rgb is not None:
+            rgb = rgb + prev_rgb
+        if self.upsample is not None:
+            rgb = self.upsample(rgb)
+        return rgb
+
+
+class OGeneratorBlock(nn.Module):  # stylex_train.py:670-718
+    def __init__(self, latent_dim, cin, cout, upsample=True, upsample_rgb=True):
+        super().__init__()
+        self.input_channels, self.filters = cin, cout
+        self.num_style_coords = cin + cout
+        self.upsample = _Up() if upsample else None
+        self.to_style1 = nn.Linear(latent_dim, cin)
+        self.to_noise1 = nn.Linear(1, cout)
+        self.conv1 = OConv2DMod(cin, cout, 3)
+        self.to_style2 = nn.Linear(latent_dim, cout)
+        self.to_noise2 = nn.Linear(1, cout)
+        self.conv2 = OConv2DMod(cout, cout, 3)
+        self.to_rgb = ORGBBlock(latent_dim, cout, upsample_rgb)
+
+    def forward(self, x, prev_rgb, istyle, inoise):
+        if self.upsample is not None:
+            x = self.upsample(x)
+        h, w = x.shape[2], x.shape[3]
+        crop = inoise[:, :h, :w, :]
+        # NB the (0,3,2,1) permute: noise[b,c,i,j] = crop[b,j,i]*wn[c]+bn[c]  (:696-698)
+        n1 = self.to_noise1(crop).permute(0, 3, 2, 1)
+        n2 = self.to_noise2(crop).permute(0, 3, 2, 1)
+        s1 = self.to_style1(istyle)
+        x = lrelu(self.conv1(x, s1) + n1)
+        s2 = self.to_style2(istyle)
+        x = lrelu(self.conv2(x, s2) + n2)
+        rgb = self.to_rgb(x, prev_rgb, istyle)
+        return x, rgb, torch.cat([s1, s2], dim=-1)
+
+
+def generator_filters(image_size, network_capacity, fmap_max):
+    """stylex_train.py:753-762."""
+    n = int(log2(image_size) - 1)
+    f = [min(fmap_max, network_capacity * 2 ** (i + 1)) for i in range(n)][::-1]
+    return [f[0]] + f
+
+
+def discriminator_filters(image_size, network_capacity, fmap_max):
+    """stylex_train.py:846-854."""
+    n = int(log2(image_size) - 1)
+    return [3] + [min(fmap_max, 4 * network_capacity * 2 ** i) for i in range(n + 1)]
+
+
+class OGenerator(nn.Module):  # stylex_train.py:747-825
+    def __init__(self, image_size, latent_dim, network_capacity=16, fmap_max=512):
+        super().__init__()
+        self.image_size, self.latent_dim = image_size, latent_dim
+        self.num_layers = int(log2(image_size) - 1)
+        f = generator_filters(image_size, network_capacity, fmap_max)
+        self.initial_block = nn.Parameter(torch.randn(1, f[0], 4, 4))
+        self.initial_conv = nn.Conv2d(f[0], f[0], 3, padding=1)
+        self.blocks = nn.ModuleList()
+        self.attns = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.attns.append(None)
+            self.blocks.append(OGeneratorBlock(latent_dim, f[i], f[i + 1], upsample=i != 0,
+                                               upsample_rgb=i != self.num_layers - 1))
+
+    def forward(self, styles, input_noise, get_style_coords=False):
+        x = self.initial_conv(self.initial_block.expand(styles.shape[0], -1, -1, -1))
+        rgb, coords = None, []
+        for li, block in enumerate(self.blocks):
+            x, rgb, sc = block(x, rgb, styles[:, li], input_noise)
+            coords.append(sc)
+        if get_style_coords:
+            return rgb, torch.cat(coords, dim=1)
+        return rgb
+
+
+class ODiscriminatorBlock(nn.Module):  # stylex_train.py:721-744
+    def __init__(self, cin, cout, downsample=True):
+        super().__init__()
+        self.conv_res = nn.Conv2d(cin, cout, 1, stride=2 if downsample else 1)
+        self.net = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), _LReLU(),
+                                 nn.Conv2d(cout, cout, 3, padding=1), _LReLU())
+        self.downsample = nn.Sequential(_Blur(), nn.Conv2d(cout, cout, 3, padding=1, stride=2)) if downsample else None
+
+    def forward(self, x):
+        res = self.conv_res(x)
+        x = self.net(x)
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return (x + res) * (1 / math.sqrt(2))
+
+
+class ODiscriminatorE(nn.Module):  # stylex_train.py:842-909
+    def __init__(self, image_size, network_capacity=16, encoder=False, encoder_dim=512, fmap_max=512):
+        super().__init__()
+        f = discriminator_filters(image_size, network_capacity, fmap_max)
+        n = len(f) - 1
+        self.blocks = nn.ModuleList([ODiscriminatorBlock(f[i], f[i + 1], downsample=i != n - 1) for i in range(n)])
+        self.attn_blocks = nn.ModuleList([None] * n)
+        self.quantize_blocks = nn.ModuleList([None] * n)
+        self.final_conv = nn.Conv2d(f[-1], f[-1], 3, padding=1)
+        self.fc = nn.Linear(2 * 2 * f[-1], encoder_dim if encoder else 1)
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.final_conv(x)
+        return self.fc(x.reshape(x.shape[0], -1)).squeeze()
+
+
+class OAugWrapper(nn.Module):  # stylex_train.py:558-571 (aug_prob=0 path; still draws random())
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+    def forward(self, images, prob=0.0, detach=False):
+        if _pyrandom.random() < prob:
+            raise NotImplementedError("DiffAugment is out of scope for the oracle (aug_prob=0)")
+        if detach:
+            images = images.detach()
+        return self.D(images)
+
+
+class OStylEx(nn.Module):  # stylex_train.py:912-999
+    def __init__(self, image_size, latent_dim=514, fmap_max=512, style_depth=8, network_capacity=16,
+                 lr=1e-4, ttur_mult=2, lr_mlp=0.1):
+        super().__init__()
+        self.encoder = ODiscriminatorE(image_size, network_capacity, encoder=True, fmap_max=fmap_max)
+        self.S = OStyleVectorizer(latent_dim, style_depth, lr_mlp)
+        self.G = OGenerator(image_size, latent_dim, network_capacity, fmap_max)
+        self.D = ODiscriminatorE(image_size, network_capacity, fmap_max=fmap_max)
+        self.SE = OStyleVectorizer(latent_dim, style_depth, lr_mlp)
+        self.GE = OGenerator(image_size, latent_dim, network_capacity)  # (sic) no fmap_max, :937-938
+        self.D_aug = OAugWrapper(self.D)
+        for p in list(self.SE.parameters()) + list(self.GE.parameters()):
+            p.requires_grad = False
+        gen_params = list(self.G.parameters()) + list(self.S.parameters()) + list(self.encoder.parameters())
+        self.G_opt = torch.optim.Adam(gen_params, lr=lr, betas=(0.5, 0.9))
+        self.D_opt = torch.optim.Adam(self.D.parameters(), lr=lr * ttur_mult, betas=(0.5, 0.9))
+        # _init_weights (:974-983)
+        for m in self.modules():
+            if type(m) in (nn.Conv2d, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="leaky_relu")
+        for blk in self.G.blocks:
+            for lin in (blk.to_noise1, blk.to_noise2):
+                nn.init.zeros_(lin.weight)
+            for lin in (blk.to_noise1, blk.to_noise2):
+                nn.init.zeros_(lin.bias)
+        self.reset_parameter_averaging()
+        self.beta = 0.995
+
+    def EMA(self):  # :985-992
+        for ma, cur in ((self.SE, self.S), (self.GE, self.G)):
+            for pc, pm in zip(cur.parameters(), ma.parameters()):
+                pm.data = pm.data * self.beta + (1 - self.beta) * pc.data
+
+    def reset_parameter_averaging(self):  # :994-996
+        self.SE.load_state_dict(self.S.state_dict())
+        self.GE.load_state_dict(self.G.state_dict())
+
+
+# --------------------------------------------------------------------------
+# latent helpers (stylex_train.py:319-353)
+# --------------------------------------------------------------------------
+
+
+def noise(n, latent_dim):
+    return torch.randn(n, latent_dim)
+
+
+def noise_list(n, layers, latent_dim):
+    return [(noise(n, latent_dim), layers)]
+
+
+def mixed_list(n, layers, latent_dim):
+    tt = int(torch.rand(()).numpy() * layers)
+    return noise_list(n, tt, latent_dim) + noise_list(n, layers - tt, latent_dim)
+
+
+def latent_to_w(S, descr):
+    return [(S(z), n) for z, n in descr]
+
+
+def image_noise(n, size):
+    return torch.empty(n, size, size, 1).uniform_(0.0, 1.0)
+
+
+def styles_def_to_tensor(styles_def):
+    return torch.cat([t[:, None, :].expand(-1, n, -1) for t, n in styles_def], dim=1)
+
+
+# --------------------------------------------------------------------------
+# losses (stylex_train.py:296-316, 370-438)
+# --------------------------------------------------------------------------
+
+
+def hinge_loss(real, fake):
+    return (F.relu(1 + real) + F.relu(1 - fake)).mean()
+
+
+def gen_hinge_loss(fake, real=None):
+    return fake.mean()
+
+
+def gradient_penalty(images, output, weight=10):
+    (g,) = torch.autograd.grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
+                               create_graph=True, retain_graph=True, only_inputs=True)
+    g = g.reshape(images.shape[0], -1)
+    return weight * ((g.norm(2, dim=1) - 1) ** 2).mean()
+
+
+def calc_pl_lengths(styles, images):
+    num_pixels = images.shape[2] * images.shape[3]
+    pl_noise = torch.randn(images.shape) / math.sqrt(num_pixels)
+    outputs = (images * pl_noise).sum()
+    (g,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones(outputs.shape),
+                               create_graph=True, retain_graph=True, only_inputs=True)
+    return (g ** 2).sum(dim=2).mean(dim=1).sqrt()
+
+
+def lpips_normalize(images):
+    flat = images.reshape(images.shape[0], -1)
+    mx = flat.max(dim=1)[0].view(-1, 1, 1, 1)
+    mn = flat.min(dim=1)[0].view(-1, 1, 1, 1)
+    return (images - mn) / (mx - mn) * 2 - 1
+
+
+def reconstruction_loss(lpips_fn, encoder_batch, generated, generated_w, encoder_w):
+    lp = lpips_fn(lpips_normalize(encoder_batch), lpips_normalize(generated)).mean()
+    return 0.1 * lp + 0.1 * F.l1_loss(encoder_w, generated_w) + 1 * F.l1_loss(encoder_batch, generated)
+
+
+def classifier_kl_loss(real_logits, fake_logits):
+    lr_ = F.log_softmax(real_logits, dim=1)
+    lf = F.log_softmax(fake_logits, dim=1)
+    return F.kl_div(lf, lr_, reduction="batchmean", log_target=True)
+
+
+# --------------------------------------------------------------------------
+# one optimiser step of D then G  (Trainer.train, stylex_train.py:1249-1506)
+# --------------------------------------------------------------------------
+
+
+class NanException(Exception):
+    pass
+
+
+class OracleTrainer:
+    def __init__(self, classifier, lpips_fn, loader, image_size=128, network_capacity=16, fmap_max=512,
+                 batch_size=4, mixed_prob=0.9, gradient_accumulate_every=1, lr=2e-4, lr_mlp=0.1, ttur_mult=2,
+                 no_pl_reg=False, kl_scaling=1, rec_scaling=10, alternating_training=True, gp_every=4,
+                 pl_every=32, pl_after=5000):
+        self.model = OStylEx(image_size, network_capacity=network_capacity, fmap_max=fmap_max, lr=lr,
+                             ttur_mult=ttur_mult, lr_mlp=lr_mlp)
+        self.classifier, self.lpips, self.loader = classifier, lpips_fn, loader
+        self.batch_size, self.mixed_prob, self.gae = batch_size, mixed_prob, gradient_accumulate_every
+        self.no_pl_reg, self.kl_scaling, self.rec_scaling = no_pl_reg, kl_scaling, rec_scaling
+        self.alternating = alternating_training
+        self.gp_every, self.pl_every, self.pl_after = gp_every, pl_every, pl_after
+        self.steps = 0
+        self.pl_mean = None
+        self.d_loss = self.g_loss = self.total_rec_loss = self.total_kl_loss = 0
+        self.last_gp_loss = None
+
+    def _w_from_encoder(self, batch):
+        m = self.model
+        enc = m.encoder(batch)
+        logits = self.classifier.classify_images(batch)
+        w = styles_def_to_tensor([(torch.cat((enc, logits), dim=1), m.G.num_layers)])
+        return enc, logits, w
+
+    def train(self):
+        m = self.model
+        m.train()
+        gae, bs = self.gae, self.batch_size
+        size, latent, layers = m.G.image_size, m.G.latent_dim, m.G.num_layers
+        apply_gp = self.steps % self.gp_every == 0
+        apply_pl = (not self.no_pl_reg) and self.steps > self.pl_after and self.steps % self.pl_every == 0
+        tot_d, tot_g, tot_rec, tot_kl = (torch.tensor(0.0) for _ in range(4))
+        avg_pl = self.pl_mean
+
+        # ---- discriminator phase (:1296-1360)
+        m.D_opt.zero_grad()
+        enc_in = False
+        latents_fn = None
+        for _ in range(gae):
+            real = next(self.loader)
+            real.requires_grad_()
+            if (not self.alternating) or enc_in:
+                eb = next(self.loader)
+                eb.requires_grad_()
+                _, _, w_styles = self._w_from_encoder(eb)
+                inoise = image_noise(bs, size)
+                enc_in = False
+            else:
+                latents_fn = mixed_list if _pyrandom.random() < self.mixed_prob else noise_list
+                style = latents_fn(bs, layers, latent)
+                inoise = image_noise(bs, size)
+                w_styles = styles_def_to_tensor(latent_to_w(m.S, style))
+                if self.alternating:
+                    enc_in = True
+            generated = m.G(w_styles, inoise)
+            fake_out = m.D_aug(generated.clone().detach(), detach=True)
+            real_out = m.D_aug(real)
+            divergence = hinge_loss(real_out, fake_out)
+            loss = divergence
+            if apply_gp:
+                gp = gradient_penalty(real, real_out)
+                self.last_gp_loss = gp.clone().detach().item()
+                loss = loss + gp
+            loss = loss / gae
+            if torch.isnan(loss):
+                raise NanException
+            loss.backward()
+            tot_d += divergence.detach().item() / gae
+        self.d_loss = float(tot_d)
+        m.D_opt.step()
+
+        # ---- generator phase (:1362-1467)
+        if self.alternating:
+            enc_in = False
+        m.G_opt.zero_grad()
+        for _ in range(gae):
+            batch = next(self.loader)
+            batch.requires_grad_()
+            enc_step = (not self.alternating) or enc_in
+            if enc_step:
+                enc_out, real_logits, w_styles = self._w_from_encoder(batch)
+                inoise = image_noise(bs, size)
+            else:
+                style = latents_fn(bs, layers, latent)
+                inoise = image_noise(bs, size)
+                w_styles = styles_def_to_tensor(latent_to_w(m.S, style))
+            generated = m.G(w_styles, inoise)
+            gen_logits = self.classifier.classify_images(generated)
+            fake_out = m.D_aug(generated)
+            if enc_step:
+                rec = 2 * self.rec_scaling * reconstruction_loss(self.lpips, batch, generated,
+                                                                 m.encoder(generated), enc_out) / gae
+                kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
+            loss = gen_hinge_loss(fake_out)
+            gen_loss = loss
+            if apply_pl:
+                pl = calc_pl_lengths(w_styles, generated)
+                avg_pl = np.mean(pl.detach().cpu().numpy())
+                if self.pl_mean is not None:
+                    pl_loss = ((pl - self.pl_mean) ** 2).mean()
+                    if not torch.isnan(pl_loss):
+                        gen_loss = gen_loss + pl_loss
+            gen_loss = gen_loss / gae
+            if torch.isnan(gen_loss):
+                raise NanException
+            if enc_step:
+                gen_loss.backward(retain_graph=True)
+                rec.backward(retain_graph=True)
+                kl.backward()
+                tot_g += loss.detach().item() / gae
+                tot_rec += rec.detach().item()
+                tot_kl += kl.detach().item()
+                self.g_loss, self.total_rec_loss, self.total_kl_loss = float(tot_g), float(tot_rec), float(tot_kl)
+            else:
+                gen_loss.backward()
+                tot_g += loss.detach().item() / gae
+                self.g_loss = float(tot_g)
+            enc_in = not enc_in
+        m.G_opt.step()
+
+        if apply_pl and not np.isnan(avg_pl):  # :1471-1473, EMA(0.99)
+            self.pl_mean = avg_pl if self.pl_mean is None else self.pl_mean * 0.99 + 0.01 * avg_pl
+        if self.steps % 10 == 0 and self.steps > 20000:
+            m.EMA()
+        if self.steps <= 25000 and self.steps % 1000 == 2:
+            m.reset_parameter_averaging()
+        if any(torch.isnan(t) for t in (tot_g, tot_d)):
+            raise NanException
+        self.steps += 1

@@ -1,0 +1,229 @@
+"""Pins the CPU oracle (oracle/stylex_oracle.py) against vectors produced by the
+reference itself (oracle/make_golden.py).  fp32 tolerance: 2e-5 relative to the
+tensor's max-abs unless stated (summation-order differences only); index rules
+are exact."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import stylex_oracle as so
+from lpips_standin import LPIPSStandIn
+from ref_shim import TinyClassifier
+from conftest import load_golden
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(b.detach().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, a.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, "max err %.3e (scale %.3e)" % (err, scale)
+
+
+def stats(t):
+    t = t.detach().double().reshape(-1)
+    head = t[:8].numpy()
+    return np.concatenate([[t.sum().item(), t.abs().sum().item()], head, np.zeros(max(0, 8 - t.numel()))])
+
+
+def close_stats(gold, t, tol=1e-4):
+    s = stats(t)
+    scale = max(1.0, abs(gold[1]))
+    assert abs(gold[0] - s[0]) <= tol * scale and abs(gold[1] - s[1]) <= tol * scale, (gold[:2], s[:2])
+    np.testing.assert_allclose(gold[2:], s[2:], rtol=1e-4, atol=1e-5 * max(1.0, np.abs(gold[2:]).max()))
+
+
+@pytest.mark.parametrize("size", [8, 16, 32])
+def test_init_parity(size):
+    g = load_golden("init_%d" % size)
+    s, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["seed"]))
+    m = so.OStylEx(s, network_capacity=cap, fmap_max=fmax)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    for i, (k, v) in enumerate(sd.items()):
+        assert ",".join(map(str, v.shape)) == str(g["shapes"][i]), k
+        np.testing.assert_array_equal(g["stats"][i], stats(v), err_msg=k)  # same RNG stream => bit-identical
+        if "full/" + k in g.files:
+            np.testing.assert_array_equal(g["full/" + k], v.numpy(), err_msg=k)
+
+
+def test_index_rules_exact():
+    g = load_golden("ops")
+    x = torch.from_numpy(g["up/x"])
+    # explicit index restatement == what the reference executed
+    close(g["up/y"], so.upsample2x_bilinear_explicit(x), 1e-6)
+    close(g["blur/y"], so.blur3x3_reflect_explicit(x), 1e-6)
+    close(g["up/y"], so.upsample2x_bilinear(x), 0)
+    close(g["blur/y"], so.blur3x3_reflect(x), 0)
+    lo, hi, wh = so.upsample2x_index_rule(5)
+    assert lo.tolist() == [0, 0, 0, 1, 1, 2, 2, 3, 3, 4]
+    assert hi.tolist() == [0, 1, 1, 2, 2, 3, 3, 4, 4, 4]
+    assert wh.tolist() == [0.75, 0.25] * 5
+    assert [so.reflect_index(i, 6) for i in (-1, 0, 5, 6)] == [1, 0, 5, 4]
+
+
+@pytest.mark.parametrize("nm", ["blur", "up"])
+def test_resample_adjoint(nm):
+    g = load_golden("ops")
+    x = torch.from_numpy(g[nm + "/x"]).requires_grad_()
+    fn = so.blur3x3_reflect_explicit if nm == "blur" else so.upsample2x_bilinear_explicit
+    (fn(x) * torch.from_numpy(g[nm + "/r"])).sum().backward()
+    close(g[nm + "/gx"], x.grad, 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["mod3", "mod1", "mod512"])
+def test_conv2dmod(tag):
+    g = load_golden("ops")
+    ci, co, k, demod, hw, b, wseed = (int(v) for v in g[tag + "/cfg"])
+    torch.manual_seed(wseed)
+    conv = so.OConv2DMod(ci, co, k, demod=bool(demod))
+    x = torch.from_numpy(g[tag + "/x"]).requires_grad_()
+    y = torch.from_numpy(g[tag + "/y"]).requires_grad_()
+    o = conv(x, y)
+    (o * torch.from_numpy(g[tag + "/r"])).sum().backward()
+    close(g[tag + "/out"], o)
+    close(g[tag + "/gx"], x.grad)
+    close(g[tag + "/gy"], y.grad)
+    if tag + "/w" in g.files:
+        close(g[tag + "/w"], conv.weight, 0)
+        close(g[tag + "/gw"], conv.weight.grad)
+    else:
+        close_stats(g[tag + "/gw_stats"], conv.weight.grad)
+        close(g[tag + "/gw_slice"], conv.weight.grad[:4, :4])
+
+
+def _load_sd(mod, g, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    mod.load_state_dict(sd)
+
+
+def test_blocks_and_vectorizer():
+    g = load_golden("ops")
+    blk = so.OGeneratorBlock(20, 8, 12, upsample=True, upsample_rgb=True)
+    _load_sd(blk, g, "gblock/sd/")
+    xo, rgb, sc = blk(*(torch.from_numpy(g["gblock/" + n]) for n in ("x", "prev", "istyle", "inoise")))
+    close(g["gblock/xo"], xo)
+    close(g["gblock/rgb"], rgb)
+    close(g["gblock/coords"], sc)
+    dblk = so.ODiscriminatorBlock(6, 10, True)
+    _load_sd(dblk, g, "dblock/sd/")
+    close(g["dblock/y"], dblk(torch.from_numpy(g["dblock/x"])))
+    torch.manual_seed(int(g["svec/seed"]))
+    sv = so.OStyleVectorizer(24, 8, 0.1)
+    close(g["svec/w"], sv(torch.from_numpy(g["svec/z"])))
+
+
+def build_nets_model(g, cls=so.OStylEx):
+    s, cap, fmax = (int(v) for v in g["config"])
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    m = cls(s, network_capacity=cap, fmap_max=fmax)
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for blk in m.G.blocks:
+            for lin in (blk.to_noise1, blk.to_noise2):
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=gen) * 0.3)
+                lin.bias.copy_(torch.randn(lin.bias.shape, generator=gen) * 0.1)
+    return m
+
+
+@pytest.mark.parametrize("size", [16, 32])
+def test_network_parity(size):
+    g = load_golden("nets_%d" % size)
+    m = build_nets_model(g)
+    w, inoise, x = (torch.from_numpy(g[n]) for n in ("w", "inoise", "x"))
+    rgb, coords = m.G(w, inoise, get_style_coords=True)
+    close(g["rgb"], rgb)
+    close(g["coords"], coords)
+    close(g["d_out"], m.D(x))
+    close(g["enc_out"], m.encoder(x))
+    close(g["d_of_g"], m.D(rgb), 1e-4)
+    close(g["s_out"], m.S(w[:, 0]))
+
+
+def test_loss_parity():
+    g = load_golden("losses")
+    s, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["seed"]))
+    m = so.OStylEx(s, network_capacity=cap, fmap_max=fmax)
+    real, fake = torch.from_numpy(g["hinge/real"]), torch.from_numpy(g["hinge/fake"])
+    close(g["hinge/d"], so.hinge_loss(real, fake), 1e-6)
+    close(g["hinge/g"], so.gen_hinge_loss(fake), 1e-6)
+    x = torch.from_numpy(g["gp/x"]).requires_grad_()
+    gp = so.gradient_penalty(x, m.D(x))
+    close(g["gp/value"], gp)
+    m.D.zero_grad()
+    gp.backward()
+    grads = dict(m.D.named_parameters())
+    for n, gs in zip(g["gp/grad_names"], g["gp/grad_stats"]):
+        close_stats(gs, grads[str(n)].grad, 2e-4)
+    close(g["gp/grad_fc_w"], m.D.fc.weight.grad, 1e-4)
+    close(g["gp/grad_b0_res_w"], m.D.blocks[0].conv_res.weight.grad, 1e-4)
+    w = torch.from_numpy(g["pl/w"]).requires_grad_()
+    img = m.G(w, torch.from_numpy(g["pl/inoise"]))
+    torch.manual_seed(int(g["pl/noise_seed"]))
+    pl = so.calc_pl_lengths(w, img)
+    close(g["pl/lengths"], pl)
+    m.G.zero_grad()
+    ((pl - 0.3) ** 2).mean().backward()
+    grads = dict(m.G.named_parameters())
+    for n, gs in zip(g["pl/grad_names"], g["pl/grad_stats"]):
+        close_stats(gs, grads[str(n)].grad, 5e-4)
+    close(g["pl/grad_w"], w.grad, 1e-4)
+    close(g["kl/value"], so.classifier_kl_loss(torch.from_numpy(g["kl/real"]), torch.from_numpy(g["kl/fake"])), 1e-6)
+    lp = LPIPSStandIn(seed=int(g["rec/lpips_seed"]))
+    i1, i2, w1, w2 = (torch.from_numpy(g["rec/" + n]) for n in ("i1", "i2", "w1", "w2"))
+    close(g["rec/lpips_value"], lp(so.lpips_normalize(i1), so.lpips_normalize(i2)).reshape(-1), 1e-6)
+    close(g["rec/value"], so.reconstruction_loss(lp, i1, i2, w2, w1), 1e-6)
+
+
+def run_oracle_steps(g):
+    size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
+    cls = TinyClassifier(seed=int(g["cls_seed"]))
+    gd = torch.Generator().manual_seed(int(g["data_seed"]))
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+
+    def cyc():
+        while True:
+            for b in batches:
+                yield b
+
+    lp = LPIPSStandIn(seed=int(g["lpips_seed"]))
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    tr = so.OracleTrainer(cls, lp, cyc(), image_size=size, network_capacity=cap, fmap_max=fmax, batch_size=bs,
+                          gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4, ttur_mult=1.5,
+                          rec_scaling=1, kl_scaling=1)
+    tr.steps = start
+    pl0 = float(g["pl_mean0"])
+    tr.pl_mean = None if np.isnan(pl0) else pl0
+    rows = []
+    for _ in range(n):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                     np.nan if tr.last_gp_loss is None else tr.last_gp_loss,
+                     np.nan if tr.pl_mean is None else tr.pl_mean])
+    return tr, np.array(rows)
+
+
+@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl"])
+def test_step_parity(tag):
+    """Trainer.train() x N: the oracle reproduces the reference's loss scalars.
+    Tolerance: 1e-3 relative (north_star's loss-curve bound); first step is
+    bit-identical inputs/weights so it agrees to ~1e-6."""
+    g = load_golden("steps_" + tag)
+    tr, rows = run_oracle_steps(g)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=2e-5, atol=2e-6, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
+    params = dict(tr.model.named_parameters())
+    for n, gs in zip(g["param_names"], g["param_stats"]):
+        close_stats(gs, params[str(n)], 2e-3)
