@@ -1,0 +1,729 @@
+// conv_igemm.hip — implicit-GEMM convolution kernels for gfx950 (MI355X, CDNA4).
+//
+// One LDS-tiled MFMA kernel family serves the three convolution roles of the
+// StylEx train step (reference call sites: F.conv2d in Conv2DMod.forward,
+// stylex/stylex_train.py:647-667; nn.Conv2d in DiscriminatorBlock :724-744,
+// Generator.initial_conv :771, DiscriminatorE.final_conv :881, and the
+// convolution_backward / double-backward nodes autograd derives from them):
+//
+//   fprop   y[m][n]  = sum_k  gatherF(x)[m][k] * Wf[n][k]        m=(b,ho,wo) k=(tap,c)
+//   dgrad   dx[m][c] = sum_k  gatherT(dy)[m][k] * Wb[c][k]       m=(b,hi,wi) k=(tap,n)
+//   wgrad   dW[n][tap][c] = sum_m dy[m][n] * gatherF(x)[m][tap][c]
+//
+// Activations are NHWC fp32, so every gathered row is a contiguous channel
+// vector: loads are 16-byte, 128-byte-coalesced per 8 lanes.  Tiles are staged
+// through LDS k-major ([k][row], row stride padded by one dword) so that the
+// fp32 MFMA operand read (one dword per lane, lanes 0-31 = 32 consecutive rows)
+// is bank-conflict free, and the transposing store is conflict free too.
+// Register-staged double buffering: the global loads of K-tile t+1 are issued
+// before the MFMAs of tile t and written to the other LDS stage afterwards
+// (one barrier per K-tile).
+//
+// Two arithmetic modes:
+//   F32  : v_mfma_f32_32x32x2_f32 — bitwise an fmaf chain, parity mode.
+//   BF16 : v_mfma_f32_32x32x16_bf16 — operands rounded (RNE) to bf16 when staged
+//          into LDS, fp32 accumulate.
+//
+// Modulation (Conv2DMod) never materialises per-sample weights: the per-sample
+// input-channel scale (style+1) is applied to the gathered operand while it is
+// staged, and the demodulation coefficient in the epilogue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stylex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BK = 32;  // K-tile depth (fp32 elements)
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    // round-to-nearest-even; NaN stays NaN
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// ------------------------------------------------------------------------------------------
+// Row descriptor: which gathered source rows (pixels) a thread stages.
+// ------------------------------------------------------------------------------------------
+struct RowPix {
+    int b, oh, ow;  // output-space pixel of GEMM row m (valid==false => zero row)
+    bool valid;
+};
+
+__device__ __forceinline__ RowPix decode_row(const ConvKParams& p, int m) {
+    RowPix r;
+    r.valid = m < p.M;
+    int mm = r.valid ? m : 0;
+    if (p.phase_major) {
+        // transposed stride-2 gather: rows ordered (phase_h, phase_w, b, oh/2, ow/2) so that a tile
+        // shares the parity class and the taps that cannot contribute are skipped tile-uniformly.
+        int hh = p.Ho >> 1, wh = p.Wo >> 1;
+        int per = p.B * hh * wh;
+        int ph = mm / per;
+        int rem = mm - ph * per;
+        r.b = rem / (hh * wh);
+        int q = rem - r.b * hh * wh;
+        r.oh = 2 * (q / wh) + (ph >> 1);
+        r.ow = 2 * (q % wh) + (ph & 1);
+    } else {
+        int hw = p.Ho * p.Wo;
+        r.b = mm / hw;
+        int q = mm - r.b * hw;
+        r.oh = q / p.Wo;
+        r.ow = q - r.oh * p.Wo;
+    }
+    return r;
+}
+
+// source pixel of (row, tap) -> element offset of its channel vector, or -1 when it is padding
+__device__ __forceinline__ long src_offset(const ConvKParams& p, const RowPix& r, int kh, int kw) {
+    if (!r.valid) return -1;
+    int ih, iw;
+    if (!p.transposed) {
+        ih = r.oh * p.stride + kh - p.pad;
+        iw = r.ow * p.stride + kw - p.pad;
+    } else {
+        int th = r.oh + p.pad - kh, tw = r.ow + p.pad - kw;
+        if (th < 0 || tw < 0) return -1;
+        if (p.stride == 2) {
+            if ((th | tw) & 1) return -1;
+            ih = th >> 1;
+            iw = tw >> 1;
+        } else {
+            ih = th;
+            iw = tw;
+        }
+    }
+    if (ih < 0 || iw < 0 || ih >= p.Hi || iw >= p.Wi) return -1;
+    return ((long)(r.b * p.Hi + ih) * p.Wi + iw) * p.Ck;
+}
+
+// ------------------------------------------------------------------------------------------
+// fprop / dgrad kernel.  Block = 256 threads = WM x WN waves, wave tile (TM*32) x (TN*32).
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread for A / B
+    // fp32 LDS image: [k][row] with row stride +1 dword.  bf16 image: [row][k] bf16, 80-byte rows.
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int LDH = 40;  // bf16 elements per LDS row (32 + 8 pad -> 80 B rows, 16-B aligned)
+    constexpr int A_ELEMS = BF16 ? (BM * LDH / 2) : (BK * LDA);
+    constexpr int B_ELEMS = BF16 ? (BN * LDH / 2) : (BK * LDB);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto As = [&](int st) -> float* { return smem + st * (A_ELEMS + B_ELEMS); };
+    auto Bs = [&](int st) -> float* { return smem + st * (A_ELEMS + B_ELEMS) + A_ELEMS; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: consecutive logical tiles (sharing activation rows) stay on one XCD's L2.
+    int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int m0 = (bid / n_tiles) * BM;
+    const int n0 = (bid % n_tiles) * BN;
+
+    const int kq = tid & 7;   // which float4 of the 32-deep K chunk
+    const int r0 = tid >> 3;  // 0..31
+
+    RowPix rows[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) rows[j] = decode_row(p, m0 + r0 + 32 * j);
+
+    const int T = p.KH * p.KW;
+    // K-tiles: VEC4 -> (tap, 32-channel chunk); scalar -> flattened k = tap*Ck + c
+    const int chunks = (p.Ck + BK - 1) / BK;
+    const int nk = VEC4 ? T * chunks : (T * p.Ck + BK - 1) / BK;
+
+    // tile-uniform tap skipping for the phase-major transposed stride-2 gather
+    int skip_ph = -1, skip_pw = -1;
+    if (p.phase_major) {
+        int per = p.B * (p.Ho >> 1) * (p.Wo >> 1);
+        int last = min(m0 + BM, p.M) - 1;
+        if (m0 / per == last / per) {
+            int ph = m0 / per;
+            skip_ph = ((ph >> 1) + p.pad) & 1;  // taps with (kh&1) != skip_ph never hit
+            skip_pw = ((ph & 1) + p.pad) & 1;
+        }
+    }
+
+    float4 ra[RA], rb[RB];
+
+    auto load_tile = [&](int kt) {
+        if (VEC4) {
+            int tap = kt / chunks, c0 = (kt - tap * chunks) * BK + kq * 4;
+            int kh = tap / p.KW, kw = tap - kh * p.KW;
+            bool cok = c0 < p.Ck;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                long off = cok ? src_offset(p, rows[j], kh, kw) : -1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (off >= 0) {
+                    v = *reinterpret_cast<const float4*>(p.a + off + c0);
+                    if (p.a_scale) {
+                        float4 s = *reinterpret_cast<const float4*>(p.a_scale + (long)rows[j].b * p.Ck + c0);
+                        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                    }
+                }
+                ra[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                int n = n0 + r0 + 32 * j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cok && n < p.N) v = *reinterpret_cast<const float4*>(p.w + ((long)n * T + tap) * p.Ck + c0);
+                rb[j] = v;
+            }
+        } else {
+            int kbase = kt * BK + kq * 4;
+            int KT = T * p.Ck;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = kbase + e;
+                    v[e] = 0.f;
+                    if (k < KT) {
+                        int tap = k / p.Ck, c = k - tap * p.Ck;
+                        int kh = tap / p.KW, kw = tap - kh * p.KW;
+                        long off = src_offset(p, rows[j], kh, kw);
+                        if (off >= 0) {
+                            v[e] = p.a[off + c];
+                            if (p.a_scale) v[e] *= p.a_scale[(long)rows[j].b * p.Ck + c];
+                        }
+                    }
+                }
+                ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                int n = n0 + r0 + 32 * j;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = kbase + e;
+                    v[e] = (k < KT && n < p.N) ? p.w[(long)n * KT + k] : 0.f;
+                }
+                rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+
+    auto store_tile = [&](int st) {
+        if (BF16) {
+            unsigned short* a = reinterpret_cast<unsigned short*>(As(st));
+            unsigned short* b = reinterpret_cast<unsigned short*>(Bs(st));
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                uint2 v;
+                v.x = f2bf(ra[j].x) | ((unsigned)f2bf(ra[j].y) << 16);
+                v.y = f2bf(ra[j].z) | ((unsigned)f2bf(ra[j].w) << 16);
+                *reinterpret_cast<uint2*>(a + (r0 + 32 * j) * LDH + kq * 4) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                uint2 v;
+                v.x = f2bf(rb[j].x) | ((unsigned)f2bf(rb[j].y) << 16);
+                v.y = f2bf(rb[j].z) | ((unsigned)f2bf(rb[j].w) << 16);
+                *reinterpret_cast<uint2*>(b + (r0 + 32 * j) * LDH + kq * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                float* d = As(st) + (kq * 4) * LDA + r0 + 32 * j;
+                d[0] = ra[j].x; d[LDA] = ra[j].y; d[2 * LDA] = ra[j].z; d[3 * LDA] = ra[j].w;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                float* d = Bs(st) + (kq * 4) * LDB + r0 + 32 * j;
+                d[0] = rb[j].x; d[LDB] = rb[j].y; d[2 * LDB] = rb[j].z; d[3 * LDB] = rb[j].w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto tile_skipped = [&](int kt) -> bool {
+        if (skip_ph < 0 || !VEC4) return false;
+        int tap = kt / chunks;
+        int kh = tap / p.KW, kw = tap - kh * p.KW;
+        return ((kh & 1) != skip_ph) || ((kw & 1) != skip_pw);
+    };
+
+    auto compute = [&](int st) {
+        const int li = lane & 31, lk = lane >> 5;
+        if (BF16) {
+            const unsigned short* a = reinterpret_cast<const unsigned short*>(As(st));
+            const unsigned short* b = reinterpret_cast<const unsigned short*>(Bs(st));
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    av[i] = *reinterpret_cast<const bf16x8*>(a + (wm * TM * 32 + i * 32 + li) * LDH + ks * 16 + lk * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bv[j] = *reinterpret_cast<const bf16x8*>(b + (wn * TN * 32 + j * 32 + li) * LDH + ks * 16 + lk * 8);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const float* a = As(st) + wm * TM * 32 + li;
+            const float* b = Bs(st) + wn * TN * 32 + li;
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = a[(ks * 2 + lk) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[j] = b[(ks * 2 + lk) * LDB + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop over the non-skipped K-tiles, double buffered
+    int kt = 0;
+    while (kt < nk && tile_skipped(kt)) ++kt;
+    int st = 0;
+    if (kt < nk) {
+        load_tile(kt);
+        store_tile(0);
+    }
+    __syncthreads();
+    while (kt < nk) {
+        int nxt = kt + 1;
+        while (nxt < nk && tile_skipped(nxt)) ++nxt;
+        if (nxt < nk) load_tile(nxt);
+        compute(st);
+        if (nxt < nk) store_tile(st ^ 1);
+        __syncthreads();
+        st ^= 1;
+        kt = nxt;
+    }
+
+    // ---- epilogue: D[i][j], col j = lane&31 (output channel), row i = (r&3)+8*(r>>2)+4*(lane>>5) (pixel)
+    const int lj = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + wn * TN * 32 + j * 32 + lj;
+        if (n >= p.N) continue;
+        float bias = (p.flags & STYLEX_EPI_BIAS) ? p.bias[n] : 0.f;
+        float nw = 0.f, nb = 0.f;
+        if (p.flags & STYLEX_EPI_NOISE) {
+            nw = p.noise_w[n];
+            nb = p.noise_b[n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                RowPix rp = decode_row(p, m);
+                long o = ((long)(rp.b * p.Ho + rp.oh) * p.Wo + rp.ow) * p.N + n;
+                float v = acc[i][j][r];
+                if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)rp.b * p.N + n];
+                if (p.flags & STYLEX_EPI_BIAS) v += bias;
+                if (p.flags & STYLEX_EPI_NOISE)
+                    v += p.noise[((long)rp.b * p.noise_stride + rp.ow) * p.noise_stride + rp.oh] * nw + nb;
+                if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + p.residual[o]) * p.res_scale;
+                if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
+                p.y[o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad kernel: partial[split][n][tap][c] = sum over this split's pixels of dy[m][n]*x_gather[m][tap][c]
+// Block tile 128 (n) x 128 (c) per (tap, split): 4 waves as 2x2, wave tile 64x64.
+// LDS image is k-major straight from memory ([pixel][channel]): no transpose needed for fp32.
+// ------------------------------------------------------------------------------------------
+template <int TN_, int TC_, bool VEC4, bool BF16>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
+    constexpr int WNn = 2, WNc = 2;
+    constexpr int BNn = WNn * TN_ * 32, BC = WNc * TC_ * 32;
+    constexpr int LDA = BNn + 4, LDB = BC + 4;
+    constexpr int LDHA = BK + 8, LDHB = BK + 8;  // bf16 image [row][k], rows = channel, k = pixel
+    constexpr int A_ELEMS = BF16 ? (BNn * LDHA / 2) : (BK * LDA);
+    constexpr int B_ELEMS = BF16 ? (BC * LDHB / 2) : (BK * LDB);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto As = [&](int st) -> float* { return smem + st * (A_ELEMS + B_ELEMS); };
+    auto Bs = [&](int st) -> float* { return smem + st * (A_ELEMS + B_ELEMS) + A_ELEMS; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int T = p.KH * p.KW;
+    const int n_tiles = (p.N + BNn - 1) / BNn, c_tiles = (p.Ck + BC - 1) / BC;
+
+    int bid = blockIdx.x;
+    const int tile = bid % (n_tiles * c_tiles * T);
+    const int split = bid / (n_tiles * c_tiles * T);
+    const int tap = tile % T;
+    const int n0 = ((tile / T) / c_tiles) * BNn;
+    const int c0 = ((tile / T) % c_tiles) * BC;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    const long m_begin = (long)split * p.split_len;
+    const long m_end = min((long)p.M, m_begin + p.split_len);
+    const int nk = (int)((m_end - m_begin + BK - 1) / BK);
+
+    // staging: each K-tile = 32 pixels; A row (pixel) = BNn floats of dy, B row = BC floats of x.
+    constexpr int A_V = BNn / 4, B_V = BC / 4;            // float4 per pixel row
+    constexpr int A_PER = (BK * A_V) / 256, B_PER = (BK * B_V) / 256;
+    float4 ra[A_PER], rb[B_PER];
+
+    auto load_tile = [&](int kt) {
+        long mb = m_begin + (long)kt * BK;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            int idx = tid + 256 * j;
+            int pr = idx / A_V, q = idx % A_V;
+            long m = mb + pr;
+            int n = n0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                const float* src = p.a2 + m * p.N + n;
+                int bb = (int)(m / ((long)p.Ho * p.Wo));
+                if (VEC4) {
+                    if (n < p.N) {
+                        v = *reinterpret_cast<const float4*>(src);
+                        if (p.a2_scale) {
+                            float4 s = *reinterpret_cast<const float4*>(p.a2_scale + (long)bb * p.N + n);
+                            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                        }
+                    }
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t[e] = (n + e < p.N) ? src[e] : 0.f;
+                        if (p.a2_scale && n + e < p.N) t[e] *= p.a2_scale[(long)bb * p.N + n + e];
+                    }
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            int idx = tid + 256 * j;
+            int pr = idx / B_V, q = idx % B_V;
+            long m = mb + pr;
+            int c = c0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                RowPix rp = decode_row(p, (int)m);
+                long off = src_offset(p, rp, kh, kw);
+                if (off >= 0) {
+                    if (VEC4) {
+                        if (c < p.Ck) {
+                            v = *reinterpret_cast<const float4*>(p.a + off + c);
+                            if (p.a_scale) {
+                                float4 s = *reinterpret_cast<const float4*>(p.a_scale + (long)rp.b * p.Ck + c);
+                                v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                            }
+                        }
+                    } else {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            t[e] = (c + e < p.Ck) ? p.a[off + c + e] : 0.f;
+                            if (p.a_scale && c + e < p.Ck) t[e] *= p.a_scale[(long)rp.b * p.Ck + c + e];
+                        }
+                        v = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            }
+            rb[j] = v;
+        }
+    };
+
+    auto store_tile = [&](int st) {
+        if (BF16) {
+            // transpose while storing: image [channel][pixel] bf16 so the MFMA operand read is 16 B
+            unsigned short* a = reinterpret_cast<unsigned short*>(As(st));
+            unsigned short* b = reinterpret_cast<unsigned short*>(Bs(st));
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                int idx = tid + 256 * j;
+                int pr = idx / A_V, q = idx % A_V;
+                a[(q * 4 + 0) * LDHA + pr] = f2bf(ra[j].x);
+                a[(q * 4 + 1) * LDHA + pr] = f2bf(ra[j].y);
+                a[(q * 4 + 2) * LDHA + pr] = f2bf(ra[j].z);
+                a[(q * 4 + 3) * LDHA + pr] = f2bf(ra[j].w);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                int idx = tid + 256 * j;
+                int pr = idx / B_V, q = idx % B_V;
+                b[(q * 4 + 0) * LDHB + pr] = f2bf(rb[j].x);
+                b[(q * 4 + 1) * LDHB + pr] = f2bf(rb[j].y);
+                b[(q * 4 + 2) * LDHB + pr] = f2bf(rb[j].z);
+                b[(q * 4 + 3) * LDHB + pr] = f2bf(rb[j].w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                int idx = tid + 256 * j;
+                int pr = idx / A_V, q = idx % A_V;
+                *reinterpret_cast<float4*>(As(st) + pr * LDA + q * 4) = ra[j];
+            }
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) {
+                int idx = tid + 256 * j;
+                int pr = idx / B_V, q = idx % B_V;
+                *reinterpret_cast<float4*>(Bs(st) + pr * LDB + q * 4) = rb[j];
+            }
+        }
+    };
+
+    f32x16 acc[TN_][TC_];
+#pragma unroll
+    for (int i = 0; i < TN_; ++i)
+#pragma unroll
+        for (int j = 0; j < TC_; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int st) {
+        const int li = lane & 31, lk = lane >> 5;
+        if (BF16) {
+            const unsigned short* a = reinterpret_cast<const unsigned short*>(As(st));
+            const unsigned short* b = reinterpret_cast<const unsigned short*>(Bs(st));
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 av[TN_], bv[TC_];
+#pragma unroll
+                for (int i = 0; i < TN_; ++i)
+                    av[i] = *reinterpret_cast<const bf16x8*>(a + (wn * TN_ * 32 + i * 32 + li) * LDHA + ks * 16 + lk * 8);
+#pragma unroll
+                for (int j = 0; j < TC_; ++j)
+                    bv[j] = *reinterpret_cast<const bf16x8*>(b + (wc * TC_ * 32 + j * 32 + li) * LDHB + ks * 16 + lk * 8);
+#pragma unroll
+                for (int i = 0; i < TN_; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC_; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const float* a = As(st) + wn * TN_ * 32 + li;
+            const float* b = Bs(st) + wc * TC_ * 32 + li;
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float av[TN_], bv[TC_];
+#pragma unroll
+                for (int i = 0; i < TN_; ++i) av[i] = a[(ks * 2 + lk) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TC_; ++j) bv[j] = b[(ks * 2 + lk) * LDB + j * 32];
+#pragma unroll
+                for (int i = 0; i < TN_; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC_; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0, st = 0; kt < nk; ++kt, st ^= 1) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+        compute(st);
+        if (kt + 1 < nk) store_tile(st ^ 1);
+        __syncthreads();
+    }
+
+    // partial[split][n][tap][c]
+    const int lj = lane & 31, lh = lane >> 5;
+    float* out = p.y + (long)split * p.N * T * p.Ck;
+#pragma unroll
+    for (int j = 0; j < TC_; ++j) {
+        int c = c0 + wc * TC_ * 32 + j * 32 + lj;
+        if (c >= p.Ck) continue;
+#pragma unroll
+        for (int i = 0; i < TN_; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n = n0 + wn * TN_ * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n < p.N) out[((long)n * T + tap) * p.Ck + c] = acc[i][j][r];
+            }
+    }
+}
+
+// dw_oihw[n][c][t] = sum_split partial[split][n][t][c]   (fixed order => deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int C, int T,
+                                    int splits) {
+    long total = (long)N * C * T;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the packed layout [n][t][c] so reads are coalesced
+        int c = (int)(i % C);
+        int t = (int)((i / C) % T);
+        int n = (int)(i / ((long)C * T));
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(long)k * total + i];
+        dw[((long)n * C + c) * T + t] = s;
+    }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int N,
+                                   int C, int T) {
+    long total = (long)N * C * T;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int t = (int)(i % T);
+        int c = (int)((i / T) % C);
+        int n = (int)(i / ((long)T * C));
+        float v = w[i];
+        if (wf) wf[((long)n * T + t) * C + c] = v;
+        if (wb) wb[((long)c * T + t) * N + n] = v;
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
+constexpr size_t igemm_smem() {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    return BF16 ? (size_t)2 * (BM + BN) * 40 * 2 : (size_t)2 * BK * (BM + 1 + BN + 1) * 4;
+}
+template <int TN_, int TC_, bool BF16>
+constexpr size_t wgrad_smem() {
+    constexpr int BNn = 2 * TN_ * 32, BC = 2 * TC_ * 32;
+    return BF16 ? (size_t)2 * (BNn + BC) * (BK + 8) * 2 : (size_t)2 * BK * (BNn + 4 + BC + 4) * 4;
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
+int launch_igemm(const ConvKParams& p, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    auto k = conv_igemm_kernel<WM, WN, TM, TN, VEC4, BF16>;
+    constexpr size_t sm = igemm_smem<WM, WN, TM, TN, VEC4, BF16>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), sm, s, p);
+    return (int)hipGetLastError();
+}
+
+template <bool VEC4, bool BF16>
+int dispatch_igemm(const ConvKParams& p, hipStream_t s) {
+    // tile choice by output-channel count; small-M layers take the narrow-M tile to fill more CUs
+    if (p.N > 64) return launch_igemm<2, 2, 2, 2, VEC4, BF16>(p, s);
+    if (p.N > 32) return launch_igemm<4, 1, 2, 2, VEC4, BF16>(p, s);
+    return launch_igemm<4, 1, 2, 1, VEC4, BF16>(p, s);
+}
+
+template <int TN_, int TC_, bool VEC4, bool BF16>
+int launch_wgrad(const ConvKParams& p, int blocks, hipStream_t s) {
+    auto k = conv_wgrad_kernel<TN_, TC_, VEC4, BF16>;
+    constexpr size_t sm = wgrad_smem<TN_, TC_, BF16>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), sm, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host-side entry points used by stylex_capi.hip
+// ------------------------------------------------------------------------------------------
+int stylex_launch_igemm(const ConvKParams& p, int precision, hipStream_t s) {
+    bool vec = (p.Ck % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0) &&
+               (!p.a_scale || (reinterpret_cast<uintptr_t>(p.a_scale) & 15) == 0);
+    if (precision == STYLEX_BF16) return vec ? dispatch_igemm<true, true>(p, s) : dispatch_igemm<false, true>(p, s);
+    return vec ? dispatch_igemm<true, false>(p, s) : dispatch_igemm<false, false>(p, s);
+}
+
+void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len) {
+    // tile 128x128 when both channel counts are large, else 64x64
+    bool big = p.N > 64 && p.Ck > 64;
+    *tn = big ? 2 : 1;
+    *tc = big ? 2 : 1;
+    int bt = big ? 128 : 64;
+    long tiles = (long)((p.N + bt - 1) / bt) * ((p.Ck + bt - 1) / bt) * p.KH * p.KW;
+    long want = (2048 + tiles - 1) / tiles;                 // aim at ~2048 blocks (8 per CU)
+    long max_by_len = ((long)p.M + 4 * BK - 1) / (4 * BK);  // at least 4 K-tiles per split
+    long sp = want < 1 ? 1 : want;
+    if (sp > max_by_len) sp = max_by_len;
+    if (sp < 1) sp = 1;
+    if (sp > 1024) sp = 1024;
+    long len = (((long)p.M + sp - 1) / sp + BK - 1) / BK * BK;
+    sp = ((long)p.M + len - 1) / len;
+    *splits = (int)sp;
+    *split_len = len;
+}
+
+int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s) {
+    int tn, tc, splits;
+    long split_len;
+    stylex_wgrad_plan(p, &tn, &tc, &splits, &split_len);
+    p.split_len = split_len;
+    p.y = partial;
+    int bt = tn == 2 ? 128 : 64;
+    int T = p.KH * p.KW;
+    int blocks = ((p.N + bt - 1) / bt) * ((p.Ck + bt - 1) / bt) * T * splits;
+    bool vec = (p.Ck % 4 == 0) && (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(p.a2) & 15) == 0) &&
+               (!p.a_scale || (reinterpret_cast<uintptr_t>(p.a_scale) & 15) == 0) &&
+               (!p.a2_scale || (reinterpret_cast<uintptr_t>(p.a2_scale) & 15) == 0);
+    int rc;
+    bool bf = precision == STYLEX_BF16;
+    if (tn == 2) {
+        rc = bf ? (vec ? launch_wgrad<2, 2, true, true>(p, blocks, s) : launch_wgrad<2, 2, false, true>(p, blocks, s))
+                : (vec ? launch_wgrad<2, 2, true, false>(p, blocks, s) : launch_wgrad<2, 2, false, false>(p, blocks, s));
+    } else {
+        rc = bf ? (vec ? launch_wgrad<1, 1, true, true>(p, blocks, s) : launch_wgrad<1, 1, false, true>(p, blocks, s))
+                : (vec ? launch_wgrad<1, 1, true, false>(p, blocks, s) : launch_wgrad<1, 1, false, false>(p, blocks, s));
+    }
+    if (rc) return rc;
+    long total = (long)p.N * p.Ck * T;
+    int rb = (int)((total + 255) / 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, T, splits);
+    return (int)hipGetLastError();
+}
+
+int stylex_launch_pack(const float* w, float* wf, float* wb, int N, int C, int T, hipStream_t s) {
+    long total = (long)N * C * T;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, w, wf, wb, N, C, T);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,331 @@
+// elementwise.hip — HBM-bound kernels of the StylEx step on gfx950: bilinear x2 and its adjoint,
+// 3x3 reflect blur and its adjoint, bias(+noise)+LeakyReLU and its gradient mask, row-wise
+// squared norms.  All tensors NHWC fp32; one lane handles VEC (4 or 1) consecutive channels of a
+// pixel so that a wave reads/writes whole 128-byte lines.  Grid-stride loops, 2048-block cap.
+//
+// Reference ops replaced (file stylex/stylex_train.py): nn.Upsample(scale_factor=2, bilinear,
+// align_corners=False) :614,679; Blur :144-153 (kornia filter2d, reflect); nn.Conv2d bias +
+// leaky_relu(0.2) :340-341,726-731; noise add :696-714; gradients.norm(2, dim=1) :302.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stylex_internal.h"
+
+namespace {
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef float4 T;
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ void fma(T& a, float w, T x) {
+        a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);
+    }
+};
+template <>
+struct Vec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ T ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+    static __device__ __forceinline__ void fma(T& a, float w, T x) { a = fmaf(w, x, a); }
+};
+
+// ---- bilinear x2 index rule (exact integer arithmetic) -------------------------------------
+// out[2k]   = .25*in[max(k-1,0)] + .75*in[k]
+// out[2k+1] = .75*in[k]          + .25*in[min(k+1,n-1)]
+__device__ __forceinline__ void up_rule(int o, int n, int& lo, int& hi, float& w_hi) {
+    int k = o >> 1;
+    if (o & 1) {
+        lo = k;
+        hi = min(k + 1, n - 1);
+        w_hi = 0.25f;
+    } else {
+        lo = max(k - 1, 0);
+        hi = k;
+        w_hi = 0.75f;
+    }
+}
+// weight with which output o reads input i
+__device__ __forceinline__ float up_coef(int o, int i, int n) {
+    int lo, hi;
+    float wh;
+    up_rule(o, n, lo, hi, wh);
+    return (lo == i ? 1.f - wh : 0.f) + (hi == i ? wh : 0.f);
+}
+
+template <int V>
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int cv = C / V;
+    const long total = (long)B * 2 * H * 2 * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        int ow = (int)(pix % (2 * W));
+        int oh = (int)((pix / (2 * W)) % (2 * H));
+        int b = (int)(pix / ((long)4 * H * W));
+        int hl, hh, wl, wh_;
+        float fh, fw;
+        up_rule(oh, H, hl, hh, fh);
+        up_rule(ow, W, wl, wh_, fw);
+        const float* base = x + (long)b * H * W * C + c;
+        typename Vec<V>::T acc = Vec<V>::zero();
+        // same association as the reference kernel: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
+        typename Vec<V>::T r0 = Vec<V>::zero(), r1 = Vec<V>::zero();
+        Vec<V>::fma(r0, 1.f - fw, Vec<V>::ld(base + ((long)hl * W + wl) * C));
+        Vec<V>::fma(r0, fw, Vec<V>::ld(base + ((long)hl * W + wh_) * C));
+        Vec<V>::fma(r1, 1.f - fw, Vec<V>::ld(base + ((long)hh * W + wl) * C));
+        Vec<V>::fma(r1, fw, Vec<V>::ld(base + ((long)hh * W + wh_) * C));
+        Vec<V>::fma(acc, 1.f - fh, r0);
+        Vec<V>::fma(acc, fh, r1);
+        Vec<V>::st(y + pix * C + c, acc);
+    }
+}
+
+template <int V>
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+    const int cv = C / V;
+    const long total = (long)B * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        int iw = (int)(pix % W);
+        int ih = (int)((pix / W) % H);
+        int b = (int)(pix / ((long)H * W));
+        const float* base = dy + (long)b * 4 * H * W * C + c;
+        typename Vec<V>::T acc = Vec<V>::zero();
+#pragma unroll
+        for (int a = -1; a <= 2; ++a) {
+            int oh = 2 * ih + a;
+            if (oh < 0 || oh >= 2 * H) continue;
+            float ch = up_coef(oh, ih, H);
+            if (ch == 0.f) continue;
+#pragma unroll
+            for (int e = -1; e <= 2; ++e) {
+                int ow = 2 * iw + e;
+                if (ow < 0 || ow >= 2 * W) continue;
+                float cw = up_coef(ow, iw, W);
+                if (cw == 0.f) continue;
+                Vec<V>::fma(acc, ch * cw, Vec<V>::ld(base + ((long)oh * 2 * W + ow) * C));
+            }
+        }
+        Vec<V>::st(dx + pix * C + c, acc);
+    }
+}
+
+// ---- 3x3 binomial blur, reflect border: index rule -1 -> 1, n -> n-2 -------------------------
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+template <int V>
+__global__ void blur3x3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int cv = C / V;
+    const long total = (long)B * H * W * cv;
+    const float f[3] = {1.f, 2.f, 1.f};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        int w = (int)(pix % W);
+        int h = (int)((pix / W) % H);
+        int b = (int)(pix / ((long)H * W));
+        const float* base = x + (long)b * H * W * C + c;
+        typename Vec<V>::T acc = Vec<V>::zero();
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh) {
+            int hh = reflect1(h + dh, H);
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                int ww = reflect1(w + dw, W);
+                Vec<V>::fma(acc, f[dh + 1] * f[dw + 1] * (1.f / 16.f), Vec<V>::ld(base + ((long)hh * W + ww) * C));
+            }
+        }
+        Vec<V>::st(y + pix * C + c, acc);
+    }
+}
+
+// adjoint weight: sum_d f[d] * [reflect(o+d) == i]
+__device__ __forceinline__ float blur_coef(int o, int i, int n) {
+    float s = 0.f;
+    if (reflect1(o - 1, n) == i) s += 1.f;
+    if (o == i) s += 2.f;
+    if (reflect1(o + 1, n) == i) s += 1.f;
+    return s;
+}
+
+template <int V>
+__global__ void blur3x3_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+    const int cv = C / V;
+    const long total = (long)B * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        int w = (int)(pix % W);
+        int h = (int)((pix / W) % H);
+        int b = (int)(pix / ((long)H * W));
+        const float* base = dy + (long)b * H * W * C + c;
+        typename Vec<V>::T acc = Vec<V>::zero();
+#pragma unroll
+        for (int a = -1; a <= 1; ++a) {
+            int oh = h + a;
+            if (oh < 0 || oh >= H) continue;
+            float ch = blur_coef(oh, h, H);
+#pragma unroll
+            for (int e = -1; e <= 1; ++e) {
+                int ow = w + e;
+                if (ow < 0 || ow >= W) continue;
+                float cw = blur_coef(ow, w, W);
+                Vec<V>::fma(acc, ch * cw * (1.f / 16.f), Vec<V>::ld(base + ((long)oh * W + ow) * C));
+            }
+        }
+        Vec<V>::st(dx + pix * C + c, acc);
+    }
+}
+
+// ---- bias (+ transposed noise) + LeakyReLU(0.2) ----------------------------------------------
+template <int V>
+__global__ void bias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                    const float* __restrict__ noise, long ns, const float* __restrict__ nw,
+                                    const float* __restrict__ nb, float* __restrict__ y, int B, int H, int W, int C) {
+    const int cv = C / V;
+    const long total = (long)B * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        float nz = 0.f;
+        if (noise) {
+            int w = (int)(pix % W);
+            int h = (int)((pix / W) % H);
+            int b = (int)(pix / ((long)H * W));
+            nz = noise[((long)b * ns + w) * ns + h];  // (sic) spatially transposed, stylex_train.py:696-698
+        }
+        float v[V];
+        *reinterpret_cast<typename Vec<V>::T*>(v) = Vec<V>::ld(x + pix * C + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = v[e];
+            if (bias) t += bias[c + e];
+            if (noise) t += fmaf(nz, nw[c + e], nb[c + e]);
+            v[e] = t > 0.f ? t : 0.2f * t;
+        }
+        Vec<V>::st(y + pix * C + c, *reinterpret_cast<typename Vec<V>::T*>(v));
+    }
+}
+
+template <int V>
+__global__ void bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                    long n) {
+    const long total = n / V;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float g[V], o[V];
+        *reinterpret_cast<typename Vec<V>::T*>(g) = Vec<V>::ld(dy + i * V);
+        *reinterpret_cast<typename Vec<V>::T*>(o) = Vec<V>::ld(y + i * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = o[e] > 0.f ? g[e] : 0.2f * g[e];
+        Vec<V>::st(dx + i * V, *reinterpret_cast<typename Vec<V>::T*>(g));
+    }
+}
+
+// ---- row-wise sum of squares: wave shuffle -> LDS -> one value per row (fixed order) ----------
+__global__ __launch_bounds__(1024) void rowwise_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             long cols) {
+    __shared__ float part[16];
+    const float* row = x + (long)blockIdx.x * cols;
+    float s = 0.f;
+    const bool vec = (cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    if (vec) {
+        for (long i = threadIdx.x; i < cols / 4; i += blockDim.x) {
+            float4 v = *reinterpret_cast<const float4*>(row + i * 4);
+            s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        }
+    } else {
+        for (long i = threadIdx.x; i < cols; i += blockDim.x) s = fmaf(row[i], row[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+        out[blockIdx.x] = t;
+    }
+}
+
+inline int grid_for(long work) {
+    long b = (work + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline bool vec_ok(int C, const void* a, const void* b) {
+    return (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+}
+
+}  // namespace
+
+#define LAUNCH_EW(kern, work, a, b, ...)                                                                    \
+    do {                                                                                                    \
+        if (vec_ok(C, a, b))                                                                                \
+            hipLaunchKernelGGL(kern<4>, dim3(grid_for((work) / 4)), dim3(256), 0, s, __VA_ARGS__);          \
+        else                                                                                                \
+            hipLaunchKernelGGL(kern<1>, dim3(grid_for(work)), dim3(256), 0, s, __VA_ARGS__);                \
+        return (int)hipGetLastError();                                                                      \
+    } while (0)
+
+extern "C" {
+
+int stylex_upsample2x_bilinear_fwd(const float* x, float* y, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(upsample2x_fwd_kernel, (long)B * 4 * H * W * C, x, y, x, y, B, H, W, C);
+}
+int stylex_upsample2x_bilinear_bwd(const float* dy, float* dx, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(upsample2x_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C);
+}
+int stylex_blur3x3_reflect_fwd(const float* x, float* y, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+    if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C);
+}
+int stylex_blur3x3_reflect_bwd(const float* dy, float* dx, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+    if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C);
+}
+int stylex_bias_act_fwd(const float* x, const float* bias, const float* noise, int64_t noise_stride,
+                        const float* noise_w, const float* noise_b, float* y, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    if (noise && (!noise_w || !noise_b || noise_stride < H || noise_stride < W)) return STYLEX_EINVAL;
+    LAUNCH_EW(bias_act_fwd_kernel, (long)B * H * W * C, x, y, x, bias, noise, (long)noise_stride, noise_w, noise_b, y, B,
+              H, W, C);
+}
+int stylex_bias_act_bwd(const float* dy, const float* y, float* dx, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    long n = (long)sh[0] * sh[1] * sh[2] * sh[3];
+    if (n <= 0) return STYLEX_EINVAL;
+    bool v = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+             ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+    if (v)
+        hipLaunchKernelGGL(bias_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, s, dy, y, dx, n);
+    else
+        hipLaunchKernelGGL(bias_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, s, dy, y, dx, n);
+    return (int)hipGetLastError();
+}
+int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* sh, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (sh[0] <= 0 || sh[1] <= 0) return STYLEX_EINVAL;
+    hipLaunchKernelGGL(rowwise_sumsq_kernel, dim3((unsigned)sh[0]), dim3(1024), 0, s, x, out, (long)sh[1]);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// stylex_capi.hip — extern "C" boundary of libstylex_hip.so (declared in include/stylex_hip.h).
+// Argument checking, GEMM-view parameter construction, launch, optional hipEvent timing.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "stylex_internal.h"
+
+namespace {
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+    int cls;
+    double flops;
+};
+std::mutex g_mu;
+bool g_timing = false;
+std::vector<TimedLaunch> g_pending;
+int64_t g_launches[3] = {0, 0, 0};
+double g_ms[3] = {0, 0, 0};
+double g_flops[3] = {0, 0, 0};
+
+struct ScopedTimer {
+    bool on;
+    TimedLaunch t;
+    hipStream_t s;
+    ScopedTimer(int cls, double flops, hipStream_t stream) : on(g_timing), s(stream) {
+        if (!on) return;
+        t.cls = cls;
+        t.flops = flops;
+        hipEventCreate(&t.start);
+        hipEventCreate(&t.stop);
+        hipEventRecord(t.start, s);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        hipEventRecord(t.stop, s);
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_pending.push_back(t);
+    }
+};
+
+void drain_pending() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& t : g_pending) {
+        float ms = 0.f;
+        hipEventSynchronize(t.stop);
+        hipEventElapsedTime(&ms, t.start, t.stop);
+        g_launches[t.cls] += 1;
+        g_ms[t.cls] += ms;
+        g_flops[t.cls] += t.flops;
+        hipEventDestroy(t.start);
+        hipEventDestroy(t.stop);
+    }
+    g_pending.clear();
+}
+
+bool conv_shape_ok(const int64_t* sh) {
+    for (int i = 0; i < STYLEX_CONV_NSHAPE; ++i)
+        if (sh[i] < 0 || sh[i] > 0x7fffffff) return false;
+    int64_t B = sh[0], Hi = sh[1], Wi = sh[2], C = sh[3], N = sh[4], KH = sh[5], KW = sh[6], st = sh[7], pad = sh[8],
+            Ho = sh[9], Wo = sh[10];
+    if (B < 1 || Hi < 1 || Wi < 1 || C < 1 || N < 1) return false;
+    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3))) return false;
+    if (st != 1 && st != 2) return false;
+    if (Ho != (Hi + 2 * pad - KH) / st + 1 || Wo != (Wi + 2 * pad - KW) / st + 1) return false;
+    if (B * Ho * Wo > 0x7fffffff || B * Hi * Wi > 0x7fffffff) return false;
+    return true;
+}
+
+void fill_common(ConvKParams& p, const int64_t* sh) {
+    memset(&p, 0, sizeof(p));
+    p.B = (int)sh[0];
+    p.KH = (int)sh[5];
+    p.KW = (int)sh[6];
+    p.stride = (int)sh[7];
+    p.pad = (int)sh[8];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* stylex_version(void) { return "stylex-hip 0.1 (gfx950)"; }
+
+int stylex_init(int device) {
+    hipError_t e = hipSetDevice(device);
+    return (int)e;
+}
+
+int stylex_timing_enable(int on) {
+    drain_pending();
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_timing = on != 0;
+    if (on) {
+        for (int i = 0; i < 3; ++i) {
+            g_launches[i] = 0;
+            g_ms[i] = 0;
+            g_flops[i] = 0;
+        }
+    }
+    return 0;
+}
+
+int stylex_timing_report(int cls, int64_t* launches, double* total_ms, double* total_flops) {
+    if (cls < 0 || cls > 2) return STYLEX_EINVAL;
+    drain_pending();
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (launches) *launches = g_launches[cls];
+    if (total_ms) *total_ms = g_ms[cls];
+    if (total_flops) *total_flops = g_flops[cls];
+    return 0;
+}
+
+int stylex_pack_weight(const float* w, float* wf, float* wb, const int64_t* sh, void* stream) {
+    if (!w || sh[0] < 1 || sh[1] < 1 || sh[2] < 1 || sh[3] < 1) return STYLEX_EINVAL;
+    return stylex_launch_pack(w, wf, wb, (int)sh[0], (int)sh[1], (int)(sh[2] * sh[3]), (hipStream_t)stream);
+}
+
+int stylex_conv2d_fwd(const float* x, const float* w_fwd, float* y, const int64_t* sh, int flags,
+                      const stylex_conv_epilogue* epi, int precision, void* stream) {
+    if (!x || !w_fwd || !y || !conv_shape_ok(sh)) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    ConvKParams p;
+    fill_common(p, sh);
+    p.a = x;
+    p.w = w_fwd;
+    p.y = y;
+    p.Hi = (int)sh[1];
+    p.Wi = (int)sh[2];
+    p.Ck = (int)sh[3];
+    p.N = (int)sh[4];
+    p.Ho = (int)sh[9];
+    p.Wo = (int)sh[10];
+    p.M = p.B * p.Ho * p.Wo;
+    p.flags = flags;
+    if (epi) {
+        p.a_scale = epi->in_scale;
+        p.bias = epi->bias;
+        p.out_scale = epi->out_scale;
+        p.noise = epi->noise;
+        p.noise_stride = (int)epi->noise_stride;
+        p.noise_w = epi->noise_w;
+        p.noise_b = epi->noise_b;
+        p.residual = epi->residual;
+        p.res_scale = epi->res_scale;
+    }
+    if ((flags & STYLEX_EPI_BIAS) && !p.bias) return STYLEX_EINVAL;
+    if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
+    if ((flags & STYLEX_EPI_NOISE) && (!p.noise || !p.noise_w || !p.noise_b || p.noise_stride < p.Ho || p.noise_stride < p.Wo))
+        return STYLEX_EINVAL;
+    if ((flags & STYLEX_EPI_RESIDUAL) && !p.residual) return STYLEX_EINVAL;
+    double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW;
+    ScopedTimer tm(0, flops, (hipStream_t)stream);
+    return stylex_launch_igemm(p, precision, (hipStream_t)stream);
+}
+
+int stylex_conv2d_bwd_data(const float* dy, const float* w_bwd, float* dx, const int64_t* sh, int flags,
+                           const stylex_conv_epilogue* epi, int precision, void* stream) {
+    if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    if (flags & ~(STYLEX_EPI_OSCALE)) return STYLEX_EINVAL;
+    ConvKParams p;
+    fill_common(p, sh);
+    p.a = dy;
+    p.w = w_bwd;
+    p.y = dx;
+    // source = dy [B][Ho_f][Wo_f][N_f];  dest = dx [B][Hi_f][Wi_f][C_f]
+    p.Hi = (int)sh[9];
+    p.Wi = (int)sh[10];
+    p.Ck = (int)sh[4];
+    p.N = (int)sh[3];
+    p.Ho = (int)sh[1];
+    p.Wo = (int)sh[2];
+    p.M = p.B * p.Ho * p.Wo;
+    p.transposed = 1;
+    p.phase_major = (p.stride == 2 && (p.Ho % 2 == 0) && (p.Wo % 2 == 0)) ? 1 : 0;
+    p.flags = flags;
+    if (epi) {
+        p.a_scale = epi->in_scale;    // [B][N_f] applied to dy (demodulation coefficient)
+        p.out_scale = epi->out_scale; // [B][C_f] applied to dx (modulation)
+    }
+    if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
+    // algorithmic FLOPs of a data gradient = those of the forward conv
+    double flops = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6];
+    ScopedTimer tm(1, flops, (hipStream_t)stream);
+    return stylex_launch_igemm(p, precision, (hipStream_t)stream);
+}
+
+static void wgrad_params(ConvKParams& p, const int64_t* sh) {
+    fill_common(p, sh);
+    p.Hi = (int)sh[1];
+    p.Wi = (int)sh[2];
+    p.Ck = (int)sh[3];
+    p.N = (int)sh[4];
+    p.Ho = (int)sh[9];
+    p.Wo = (int)sh[10];
+    p.M = p.B * p.Ho * p.Wo;
+}
+
+int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
+    if (!conv_shape_ok(sh)) return STYLEX_EINVAL;
+    ConvKParams p;
+    wgrad_params(p, sh);
+    int tn, tc, splits;
+    long len;
+    stylex_wgrad_plan(p, &tn, &tc, &splits, &len);
+    return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float);
+}
+
+int stylex_conv2d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes,
+                             const int64_t* sh, const float* x_scale, const float* dy_scale, int precision,
+                             void* stream) {
+    if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh)) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    if (workspace_bytes < stylex_conv2d_bwd_weight_workspace_bytes(sh)) return STYLEX_EWORKSPACE;
+    ConvKParams p;
+    wgrad_params(p, sh);
+    p.a = x;
+    p.a_scale = x_scale;
+    p.a2 = dy;
+    p.a2_scale = dy_scale;
+    double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW;
+    ScopedTimer tm(2, flops, (hipStream_t)stream);
+    return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream);
+}
+
+}  // extern "C"

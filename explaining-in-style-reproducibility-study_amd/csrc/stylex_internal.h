@@ -1,0 +1,36 @@
+// Internal (non-ABI) declarations shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stylex_hip.h"
+
+// GEMM-view of one convolution launch.  "source" = gathered activation tensor
+// [B][Hi][Wi][Ck] (x for fprop/wgrad, dy for dgrad); "dest" = [B][Ho][Wo][N].
+struct ConvKParams {
+    const float* a;         // gathered activations
+    const float* a_scale;   // [B][Ck] per-sample channel scale applied while staging (or null)
+    const float* w;         // packed weights [N][T][Ck]            (igemm)
+    const float* a2;        // second activation operand dy [M][N]   (wgrad)
+    const float* a2_scale;  // [B][N]                                (wgrad)
+    float* y;
+    const float* bias;
+    const float* out_scale;
+    const float* noise;
+    const float* noise_w;
+    const float* noise_b;
+    const float* residual;
+    float res_scale;
+    int noise_stride;
+    int B, Hi, Wi, Ck, N, KH, KW, Ho, Wo, stride, pad;
+    int transposed;   // 0: forward gather  ih = oh*s + kh - p ; 1: data-gradient gather ih = (oh + p - kh)/s
+    int phase_major;  // rows ordered by (oh&1, ow&1) first (transposed stride-2 only)
+    int M;            // B*Ho*Wo
+    int flags;
+    long split_len;   // wgrad: pixels per split (multiple of 32)
+};
+
+int stylex_launch_igemm(const ConvKParams& p, int precision, hipStream_t s);
+void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len);
+int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s);
+int stylex_launch_pack(const float* w, float* wf, float* wb, int N, int C, int T, hipStream_t s);

@@ -1,0 +1,304 @@
+"""ctypes binding of libstylex_hip.so (C-ABI declared in include/stylex_hip.h).
+
+This is the only place the Python host touches native code.  There is NO
+fallback: if the shared library is missing or a kernel returns an error the
+call raises.  PyTorch is used for device memory and the current HIP stream only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylex_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL = 1, 2, 4, 8, 16
+
+_c_f = ctypes.c_void_p  # device pointers travel as void*
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+class ConvEpilogue(ctypes.Structure):
+    _fields_ = [
+        ("in_scale", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("out_scale", ctypes.c_void_p),
+        ("noise", ctypes.c_void_p),
+        ("noise_stride", ctypes.c_int64),
+        ("noise_w", ctypes.c_void_p),
+        ("noise_b", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("res_scale", ctypes.c_float),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/stylex_hip.h one to one
+SIGNATURES = {
+    "stylex_init": (ctypes.c_int, [ctypes.c_int]),
+    "stylex_version": (ctypes.c_char_p, []),
+    "stylex_pack_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_conv2d_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.POINTER(ConvEpilogue),
+                                         ctypes.c_int, ctypes.c_void_p]),
+    "stylex_conv2d_bwd_data": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.POINTER(ConvEpilogue),
+                                              ctypes.c_int, ctypes.c_void_p]),
+    "stylex_conv2d_bwd_weight_workspace_bytes": (ctypes.c_int64, [_i64p]),
+    "stylex_conv2d_bwd_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p, _c_f, _c_f,
+                                                ctypes.c_int, ctypes.c_void_p]),
+    "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_blur3x3_reflect_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_blur3x3_reflect_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_bias_act_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_bias_act_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_rowwise_sumsq": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
+    "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+_inited_devices = set()
+
+
+class StylexHipError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libstylex_hip.so and bind every symbol the header declares.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("STYLEX_HIP_LIB", LIB_PATH)
+    if not os.path.isfile(path):
+        raise StylexHipError("libstylex_hip.so not found at %s — run `python __graft_entry__.py build` "
+                             "(there is no CPU fallback for the product path)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise StylexHipError("%s failed with code %d" % (what, rc))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ensure_device(t):
+    if not t.is_cuda:
+        raise StylexHipError("stylex HIP ops need a GPU tensor (got %s); the product path has no CPU fallback"
+                             % t.device)
+    lib = load_library()
+    idx = t.device.index
+    if idx not in _inited_devices:
+        _check(lib.stylex_init(idx), "stylex_init")
+        _inited_devices.add(idx)
+    return lib
+
+
+def _shape(*v):
+    return (ctypes.c_int64 * len(v))(*[int(i) for i in v])
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def is_cl(t):
+    return t.is_contiguous(memory_format=torch.channels_last)
+
+
+def to_cl(t):
+    """Logical NCHW, physical NHWC fp32 — the layout every kernel reads."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def conv_shape(x_shape, w_shape, stride, pad):
+    b, c, h, w = x_shape
+    n, c2, kh, kw = w_shape
+    assert c == c2, (x_shape, w_shape)
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (w + 2 * pad - kw) // stride + 1
+    return (b, h, w, c, n, kh, kw, stride, pad, ho, wo)
+
+
+def empty_cl(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
+
+
+def pack_weight(w, want_fwd=True, want_bwd=False):
+    lib = _ensure_device(w)
+    w = w.contiguous()
+    n, c, kh, kw = w.shape
+    wf = torch.empty(n * kh * kw * c, dtype=torch.float32, device=w.device) if want_fwd else None
+    wb = torch.empty(n * kh * kw * c, dtype=torch.float32, device=w.device) if want_bwd else None
+    _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), _stream()), "stylex_pack_weight")
+    return wf, wb
+
+
+def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
+               noise_w=None, noise_b=None, residual=None, res_scale=1.0):
+    """x: channels_last [B,C,H,W]; w: OIHW parameter.  Returns channels_last [B,N,Ho,Wo]."""
+    lib = _ensure_device(x)
+    assert is_cl(x) and x.dtype == torch.float32
+    sh = conv_shape(x.shape, w.shape, stride, pad)
+    wf, _ = pack_weight(w, True, False)
+    y = empty_cl((sh[0], sh[4], sh[9], sh[10]), x)
+    flags = 0
+    epi = ConvEpilogue()
+    keep = []
+    if in_scale is not None:
+        in_scale = in_scale.contiguous()
+        keep.append(in_scale)
+        epi.in_scale = in_scale.data_ptr()
+    if bias is not None:
+        flags |= EPI_BIAS
+        epi.bias = bias.data_ptr()
+    if lrelu:
+        flags |= EPI_LRELU
+    if out_scale is not None:
+        out_scale = out_scale.contiguous()
+        keep.append(out_scale)
+        flags |= EPI_OSCALE
+        epi.out_scale = out_scale.data_ptr()
+    if noise is not None:
+        noise = noise.contiguous()
+        keep.append(noise)
+        flags |= EPI_NOISE
+        epi.noise = noise.data_ptr()
+        epi.noise_stride = noise.shape[1]
+        epi.noise_w = noise_w.data_ptr()
+        epi.noise_b = noise_b.data_ptr()
+    if residual is not None:
+        assert is_cl(residual) and residual.shape == y.shape
+        flags |= EPI_RESIDUAL
+        epi.residual = residual.data_ptr()
+        epi.res_scale = res_scale
+    _check(lib.stylex_conv2d_fwd(_ptr(x), _ptr(wf), _ptr(y), _shape(*sh), flags, ctypes.byref(epi), precision,
+                                 _stream()), "stylex_conv2d_fwd")
+    return y
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_scale=None):
+    lib = _ensure_device(dy)
+    assert is_cl(dy) and dy.dtype == torch.float32
+    sh = conv_shape(x_shape, w.shape, stride, pad)
+    assert tuple(dy.shape) == (sh[0], sh[4], sh[9], sh[10]), (dy.shape, sh)
+    _, wb = pack_weight(w, False, True)
+    dx = empty_cl(tuple(x_shape), dy)
+    epi = ConvEpilogue()
+    flags = 0
+    if in_scale is not None:
+        in_scale = in_scale.contiguous()
+        epi.in_scale = in_scale.data_ptr()
+    if out_scale is not None:
+        out_scale = out_scale.contiguous()
+        flags |= EPI_OSCALE
+        epi.out_scale = out_scale.data_ptr()
+    _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), _shape(*sh), flags, ctypes.byref(epi), precision,
+                                      _stream()), "stylex_conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None):
+    lib = _ensure_device(x)
+    assert is_cl(x) and is_cl(dy)
+    sh = conv_shape(x.shape, w_shape, stride, pad)
+    shp = _shape(*sh)
+    nbytes = lib.stylex_conv2d_bwd_weight_workspace_bytes(shp)
+    if nbytes < 0:
+        raise StylexHipError("bad wgrad shape %r" % (sh,))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    if x_scale is not None:
+        x_scale = x_scale.contiguous()
+    if dy_scale is not None:
+        dy_scale = dy_scale.contiguous()
+    _check(lib.stylex_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, _ptr(x_scale),
+                                        _ptr(dy_scale), precision, _stream()), "stylex_conv2d_bwd_weight")
+    return dw
+
+
+def _ew(fn_name, x, out_shape, in_shape_for_kernel):
+    lib = _ensure_device(x)
+    assert is_cl(x) and x.dtype == torch.float32
+    y = empty_cl(out_shape, x)
+    b, c, h, w = in_shape_for_kernel
+    _check(getattr(lib, fn_name)(_ptr(x), _ptr(y), _shape(b, h, w, c), _stream()), fn_name)
+    return y
+
+
+def upsample2x_fwd(x):
+    b, c, h, w = x.shape
+    return _ew("stylex_upsample2x_bilinear_fwd", x, (b, c, 2 * h, 2 * w), (b, c, h, w))
+
+
+def upsample2x_bwd(dy):
+    b, c, h2, w2 = dy.shape
+    return _ew("stylex_upsample2x_bilinear_bwd", dy, (b, c, h2 // 2, w2 // 2), (b, c, h2 // 2, w2 // 2))
+
+
+def blur3x3_fwd(x):
+    return _ew("stylex_blur3x3_reflect_fwd", x, tuple(x.shape), tuple(x.shape))
+
+
+def blur3x3_bwd(dy):
+    return _ew("stylex_blur3x3_reflect_bwd", dy, tuple(dy.shape), tuple(dy.shape))
+
+
+def bias_act_fwd(x, bias=None, noise=None, noise_w=None, noise_b=None):
+    lib = _ensure_device(x)
+    assert is_cl(x)
+    b, c, h, w = x.shape
+    y = empty_cl(tuple(x.shape), x)
+    ns = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        ns = noise.shape[1]
+    _check(lib.stylex_bias_act_fwd(_ptr(x), _ptr(bias), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(y),
+                                   _shape(b, h, w, c), _stream()), "stylex_bias_act_fwd")
+    return y
+
+
+def bias_act_bwd(dy, y):
+    lib = _ensure_device(dy)
+    assert is_cl(dy) and is_cl(y)
+    b, c, h, w = dy.shape
+    dx = empty_cl(tuple(dy.shape), dy)
+    _check(lib.stylex_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), _shape(b, h, w, c), _stream()), "stylex_bias_act_bwd")
+    return dx
+
+
+def rowwise_sumsq(x2d):
+    lib = _ensure_device(x2d)
+    x2d = x2d.contiguous()
+    out = torch.empty(x2d.shape[0], dtype=torch.float32, device=x2d.device)
+    _check(lib.stylex_rowwise_sumsq(_ptr(x2d), _ptr(out), _shape(x2d.shape[0], x2d.shape[1]), _stream()),
+           "stylex_rowwise_sumsq")
+    return out
+
+
+def timing_enable(on):
+    load_library().stylex_timing_enable(int(on))
+
+
+def timing_report():
+    lib = load_library()
+    out = {}
+    for cls, name in enumerate(("fwd", "bwd_data", "bwd_weight")):
+        n = ctypes.c_int64()
+        ms = ctypes.c_double()
+        fl = ctypes.c_double()
+        lib.stylex_timing_report(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+        out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value)
+    return out

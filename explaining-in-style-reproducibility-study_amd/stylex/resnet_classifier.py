@@ -1,0 +1,51 @@
+"""Frozen ResNet-18 classifier wrapper (reference API: stylex/resnet_classifier.py:29-71).
+Forward stays on stock PyTorch-ROCm; gradients still flow to the input images."""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from tv_models import ResNet18
+
+_MEAN, _STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _device(cuda_rank):
+    return torch.device("cuda:%d" % cuda_rank) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def load_resnet_classifier(model_name, cuda_rank, output_size=2, seed=1234):
+    """ResNet-18 with a 2-logit head.  ``trained_classifiers/<model_name>`` is loaded when it
+    exists (reference :16-26); otherwise seeded random weights are used (synthetic benchmarks —
+    the torch.hub / checkpoint files are unavailable offline)."""
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = ResNet18()
+    model.fc = nn.Linear(512, output_size)
+    torch.random.set_rng_state(state)
+    path = os.path.join("trained_classifiers", str(model_name))
+    if model_name is not None and os.path.isfile(path):
+        model.load_state_dict(torch.load(path, map_location="cpu"))
+    return model.to(_device(cuda_rank))
+
+
+class ResNet:
+    def __init__(self, model_name, cuda_rank, output_size=2, image_size=32, normalize=True):
+        self.model = load_resnet_classifier(model_name, cuda_rank, output_size)
+        self.resnet_dim = 224
+        self.image_size = image_size
+        self.normalize = normalize
+        dev = next(self.model.parameters()).device
+        self._mean = torch.tensor(_MEAN, device=dev).view(1, 3, 1, 1)
+        self._std = torch.tensor(_STD, device=dev).view(1, 3, 1, 1)
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.model.eval()
+
+    def classify_images(self, images):
+        # torchvision 0.11 resize on tensors == bilinear, align_corners=False, no antialias (:61)
+        x = F.interpolate(images, size=[self.resnet_dim, self.resnet_dim], mode="bilinear", align_corners=False)
+        if self.normalize:
+            x = (x - self._mean) / self._std
+        return self.model(x)

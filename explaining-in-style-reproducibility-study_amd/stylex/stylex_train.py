@@ -1,0 +1,778 @@
+"""StylEx model container, losses and Trainer — drop-in for the reference's
+``stylex/stylex_train.py`` (default architecture, cli.py:17), running the
+adversarial step on the HIP kernels behind ``ops.py``.
+
+Kept verbatim from the reference's API: ``Trainer`` kwargs,
+methods and attributes; ``StylEx`` children/optimisers; the free functions the
+AttFind notebook imports.  New, MI355X-first behaviour:
+  * no import-time CUDA assert, no LPIPS pinned to cuda:0 (reference :51,:404);
+  * D-phase generator/encoder forwards run under no_grad (their graph is never
+    used, :1330-1331) and D weight-gradients are skipped in the G phase (they
+    are zeroed by the next D_opt.zero_grad, :1297) — results identical;
+  * the three encoder-step backward calls (:1436-1438) are one backward of the sum;
+  * loss scalars stay on the device; one host sync per phase instead of 5-8
+    ``.item()`` per micro-step;
+  * data-parallel training = one process per GPU with RCCL all-reduce of flat
+    gradient buckets (``parallel.py``), including the encoder the reference forgot
+    to wrap (:1188-1193).
+"""
+import json
+import math
+import multiprocessing
+import os
+from math import floor, log2
+from pathlib import Path
+from random import random
+from shutil import rmtree
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.optim import Adam
+from torch.utils import data
+from torch.utils.data.distributed import DistributedSampler  # noqa: F401  (re-exported for the notebook)
+
+import ops
+import parallel
+from lpips_alex import LPIPS
+from mobilenet_classifier import MobileNet
+from networks import (Blur, Conv2DMod, DiscriminatorBlock, DiscriminatorE, EqualLinear, Flatten,  # noqa: F401
+                      Generator, GeneratorBlock, HipConv2d, RGBBlock, StyleVectorizer, Upsample2x, exists, leaky_relu)
+from resnet_classifier import ResNet
+from version import __version__
+
+NUM_CORES = multiprocessing.cpu_count()
+EXTS = ["jpg", "jpeg", "png"]
+
+
+class NanException(Exception):
+    pass
+
+
+# ------------------------------------------------------------------------------------------
+# small helpers with the reference's names
+# ------------------------------------------------------------------------------------------
+
+
+def default(value, d):
+    return value if exists(value) else d
+
+
+def cycle(iterable):
+    while True:
+        for i in iterable:
+            yield i
+
+
+def cast_list(el):
+    return el if isinstance(el, list) else [el]
+
+
+def is_empty(t):
+    if isinstance(t, torch.Tensor):
+        return t.nelement() == 0
+    return not exists(t)
+
+
+def set_requires_grad(model, flag):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def _dev(device):
+    """Accept the reference's integer rank, a torch.device or None."""
+    if isinstance(device, torch.device):
+        return device
+    if device is None or not torch.cuda.is_available():
+        return torch.device("cpu")
+    return torch.device("cuda:%d" % int(device))
+
+
+def noise(n, latent_dim, device):  # reference :319-320 — CPU RNG, then copy (keeps the draw order)
+    return torch.randn(n, latent_dim).to(_dev(device))
+
+
+def noise_list(n, layers, latent_dim, device):
+    return [(noise(n, latent_dim, device), layers)]
+
+
+def mixed_list(n, layers, latent_dim, device):
+    tt = int(torch.rand(()).numpy() * layers)
+    return noise_list(n, tt, latent_dim, device) + noise_list(n, layers - tt, latent_dim, device)
+
+
+def latent_to_w(style_vectorizer, latent_descr):
+    return [(style_vectorizer(z), num_layers) for z, num_layers in latent_descr]
+
+
+def image_noise(n, im_size, device):  # reference :336-337
+    return torch.empty(n, im_size, im_size, 1).uniform_(0., 1.).to(_dev(device))
+
+
+def evaluate_in_chunks(max_batch_size, model, *args):
+    chunks = list(zip(*[a.split(max_batch_size, dim=0) for a in args]))
+    outs = [model(*c) for c in chunks]
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+
+def styles_def_to_tensor(styles_def):
+    return torch.cat([t[:, None, :].expand(-1, n, -1) for t, n in styles_def], dim=1)
+
+
+def slerp(val, low, high):
+    low_n = low / torch.norm(low, dim=1, keepdim=True)
+    high_n = high / torch.norm(high, dim=1, keepdim=True)
+    omega = torch.acos((low_n * high_n).sum(1))
+    so = torch.sin(omega)
+    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+
+
+def make_weights_for_balanced_classes(dataset, nclasses):  # imported by the AttFind notebook
+    count = [0] * nclasses
+    for _, label in dataset:
+        count[int(label)] += 1
+    total = float(sum(count))
+    per_class = [total / c if c else 0.0 for c in count]
+    return [per_class[int(label)] for _, label in dataset]
+
+
+# ------------------------------------------------------------------------------------------
+# losses (reference :296-316, :370-438)
+# ------------------------------------------------------------------------------------------
+
+
+def _flat_rows(t):
+    """[B, ...] -> [B, n] without a layout copy for channels_last tensors (a sum of squares
+    does not care about the element order)."""
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)
+    return t.reshape(t.shape[0], -1)
+
+
+def gradient_penalty(images, output, weight=10):
+    """10 * mean((||dD/dx||_2 - 1)^2) on reals (reference :296-303); the per-sample norm is the
+    wavefront-shuffle reduction kernel."""
+    (gradients,) = torch.autograd.grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
+                                       create_graph=True, retain_graph=True, only_inputs=True)
+    norms = ops.rowwise_sumsq(_flat_rows(gradients)).sqrt()
+    return weight * ((norms - 1) ** 2).mean()
+
+
+def calc_pl_lengths(styles, images):
+    """Path lengths (reference :306-316); pl_noise is drawn on the CPU generator for draw-order parity."""
+    num_pixels = images.shape[2] * images.shape[3]
+    pl_noise = (torch.randn(images.shape) / math.sqrt(num_pixels)).to(images.device)
+    outputs = (images * pl_noise).sum()
+    (pl_grads,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones_like(outputs),
+                                      create_graph=True, retain_graph=True, only_inputs=True)
+    return (pl_grads ** 2).sum(dim=2).mean(dim=1).sqrt()
+
+
+def gen_hinge_loss(fake, real):
+    return fake.mean()
+
+
+def hinge_loss(real, fake):
+    return (F.relu(1 + real) + F.relu(1 - fake)).mean()
+
+
+def lpips_normalize(images):
+    flat = images.reshape(images.shape[0], -1)
+    hi = flat.max(dim=1)[0].view(-1, 1, 1, 1)
+    lo = flat.min(dim=1)[0].view(-1, 1, 1, 1)
+    return (images - lo) / (hi - lo) * 2 - 1
+
+
+_LPIPS = {}
+
+
+def get_lpips(device):
+    """Lazily built per device (the reference builds it on cuda:0 at import, :404)."""
+    key = str(device)
+    if key not in _LPIPS:
+        _LPIPS[key] = LPIPS(net="alex").to(device)
+    return _LPIPS[key]
+
+
+def reconstruction_loss(encoder_batch, generated_images, generated_images_w, encoder_w, lpips_fn=None):
+    lpips_fn = lpips_fn or get_lpips(encoder_batch.device)
+    perceptual = lpips_fn(lpips_normalize(encoder_batch), lpips_normalize(generated_images)).mean()
+    return 0.1 * perceptual + 0.1 * F.l1_loss(encoder_w, generated_images_w) + 1 * F.l1_loss(encoder_batch,
+                                                                                             generated_images)
+
+
+def classifier_kl_loss(real_classifier_logits, fake_classifier_logits):
+    real_lp = F.log_softmax(real_classifier_logits, dim=1)
+    fake_lp = F.log_softmax(fake_classifier_logits, dim=1)
+    return F.kl_div(fake_lp, real_lp, reduction="batchmean", log_target=True)
+
+
+# ------------------------------------------------------------------------------------------
+# dataset (reference :520-556) — PIL only, torchvision is optional
+# ------------------------------------------------------------------------------------------
+
+
+class Dataset(data.Dataset):
+    def __init__(self, folder, image_size, transparent=False, aug_prob=0.):
+        super().__init__()
+        self.folder, self.image_size, self.transparent, self.aug_prob = folder, image_size, transparent, aug_prob
+        self.paths = [p for ext in EXTS for p in Path(f"{folder}").glob(f"**/*.{ext}")]
+        assert len(self.paths) > 0, f"No images were found in {folder} for training"
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, index):
+        from PIL import Image
+
+        img = Image.open(self.paths[index]).convert("RGBA" if self.transparent else "RGB")
+        s = self.image_size
+        w, h = img.size
+        scale = s / min(w, h)  # Resize(image_size): shorter side -> image_size
+        img = img.resize((max(s, round(w * scale)), max(s, round(h * scale))), Image.BILINEAR)
+        w, h = img.size
+        left, top = (w - s) // 2, (h - s) // 2
+        img = img.crop((left, top, left + s, top + s))  # CenterCrop (aug_prob=0 path)
+        arr = np.asarray(img, dtype=np.float32) / 255.0
+        return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
+
+
+class MNIST_1vA(data.Dataset):
+    """Named-dataset hook of the reference (:495-517); needs torchvision's MNIST, absent offline."""
+
+    def __init__(self, folder="./", digit=8):
+        raise RuntimeError("MNIST_1vA needs torchvision.datasets.MNIST (download) — unavailable offline")
+
+
+class AugWrapper(nn.Module):  # reference :558-571
+    def __init__(self, D, image_size):
+        super().__init__()
+        self.D = D
+
+    def forward(self, images, prob=0., types=[], detach=False):
+        if random() < prob:  # one Python random() per call even at prob 0 (RNG parity)
+            from diff_augment import DiffAugment
+
+            if not (0.5 > random()):
+                images = torch.flip(images, dims=(3,))
+            images = DiffAugment(images, types=types)
+        if detach:
+            images = images.detach()
+        return self.D(images)
+
+
+# ------------------------------------------------------------------------------------------
+# model container (reference :912-999)
+# ------------------------------------------------------------------------------------------
+
+
+class StylEx(nn.Module):
+    def __init__(self, image_size, latent_dim=514, fmap_max=512, style_depth=8, network_capacity=16, transparent=False,
+                 fp16=False, cl_reg=False, steps=1, lr=1e-4, ttur_mult=2, fq_layers=[], fq_dict_size=256,
+                 attn_layers=[], no_const=False, lr_mlp=0.1, rank=0, classifier_labels=2, encoder_class=None,
+                 kl_rec_during_disc=False):
+        super().__init__()
+        assert not fp16 and not cl_reg and encoder_class is None, "apex fp16 / cl_reg / debug encoders: out of scope"
+        self.lr, self.steps, self.ema_beta, self.fp16 = lr, steps, 0.995, False
+        # construction ORDER is part of the contract: it fixes the RNG stream of the initial weights
+        self.encoder = DiscriminatorE(image_size, network_capacity, encoder=True, fq_layers=fq_layers,
+                                      fq_dict_size=fq_dict_size, attn_layers=attn_layers, transparent=transparent,
+                                      fmap_max=fmap_max)
+        self.S = StyleVectorizer(latent_dim, style_depth, lr_mul=lr_mlp)
+        self.G = Generator(image_size, latent_dim, network_capacity, transparent=transparent, attn_layers=attn_layers,
+                           no_const=no_const, fmap_max=fmap_max)
+        self.D = DiscriminatorE(image_size, network_capacity, fq_layers=fq_layers, fq_dict_size=fq_dict_size,
+                                attn_layers=attn_layers, transparent=transparent, fmap_max=fmap_max)
+        self.SE = StyleVectorizer(latent_dim, style_depth, lr_mul=lr_mlp)
+        self.GE = Generator(image_size, latent_dim, network_capacity, transparent=transparent, attn_layers=attn_layers,
+                            no_const=no_const)  # (sic) the reference does not forward fmap_max here (:937-938)
+        self.D_cl = None
+        self.D_aug = AugWrapper(self.D, image_size)
+        set_requires_grad(self.SE, False)
+        set_requires_grad(self.GE, False)
+        generator_params = list(self.G.parameters()) + list(self.S.parameters()) + list(self.encoder.parameters())
+        self.G_opt = Adam(generator_params, lr=self.lr, betas=(0.5, 0.9))
+        self.D_opt = Adam(self.D.parameters(), lr=self.lr * ttur_mult, betas=(0.5, 0.9))
+        self._init_weights()
+        self.reset_parameter_averaging()
+        self.to(_dev(rank))
+
+    def _init_weights(self):
+        for m in self.modules():  # the reference tests exact nn.Conv2d / nn.Linear types (:975-977)
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="leaky_relu")
+        for block in self.G.blocks:
+            for lin in (block.to_noise1, block.to_noise2):
+                nn.init.zeros_(lin.weight)
+                nn.init.zeros_(lin.bias)
+
+    def EMA(self):
+        for ma, cur in ((self.SE, self.S), (self.GE, self.G)):
+            for p_cur, p_ma in zip(cur.parameters(), ma.parameters()):
+                p_ma.data = p_ma.data * self.ema_beta + (1 - self.ema_beta) * p_cur.data
+
+    def reset_parameter_averaging(self):
+        self.SE.load_state_dict(self.S.state_dict())
+        self.GE.load_state_dict(self.G.state_dict())
+
+    def forward(self, x):
+        return x
+
+
+# ------------------------------------------------------------------------------------------
+# Trainer (reference :1002-1774)
+# ------------------------------------------------------------------------------------------
+
+
+class Trainer:
+    def __init__(self, name="default", results_dir="results", models_dir="models", base_dir="./", image_size=128,
+                 network_capacity=16, fmap_max=512, transparent=False, batch_size=4, mixed_prob=0.9,
+                 gradient_accumulate_every=1, lr=2e-4, lr_mlp=0.1, ttur_mult=2, rel_disc_loss=False, num_workers=None,
+                 save_every=1000, evaluate_every=1000, num_image_tiles=8, trunc_psi=0.6, fp16=False, cl_reg=False,
+                 no_pl_reg=False, fq_layers=[], fq_dict_size=256, attn_layers=[], no_const=False, aug_prob=0.,
+                 aug_types=["translation", "cutout"], top_k_training=False, generator_top_k_gamma=0.99,
+                 generator_top_k_frac=0.5, dual_contrast_loss=False, dataset_aug_prob=0., calculate_fid_every=None,
+                 calculate_fid_num_images=12800, clear_fid_cache=False, is_ddp=False, rank=0, world_size=1, log=False,
+                 kl_scaling=1, rec_scaling=10, classifier_path="mnist.pth", num_classes=2, encoder_class=None,
+                 alternating_training=True, sample_from_encoder=False, dataset_name=None, tensorboard_dir=None,
+                 classifier_name=None,
+                 # --- extensions (defaults reproduce the reference) ---
+                 classifier=None, lpips_fn=None, gp_every=4, pl_every=32, pl_after=5000, device=None,
+                 *args, **kwargs):
+        kwargs.pop("kl_rec_during_disc", None)  # cli.py forwards it; only the new architecture reads it
+        self.model_params = [args, kwargs]
+        self.StylEx = None
+        self.kl_scaling, self.rec_scaling = kl_scaling, rec_scaling
+        self.alternating_training = alternating_training
+        self.name = name
+        base_dir = Path(base_dir)
+        self.base_dir = base_dir
+        self.results_dir = base_dir / results_dir
+        self.models_dir = base_dir / models_dir
+        self.fid_dir = base_dir / "fid" / name
+        self.config_path = self.models_dir / name / ".config.json"
+        assert log2(image_size).is_integer(), "image size must be a power of 2 (64, 128, 256, 512, 1024)"
+        assert not fp16, "apex fp16 is out of scope; use ops.set_precision('bf16')"
+        assert not (dual_contrast_loss or top_k_training or rel_disc_loss or cl_reg), "variant losses are out of scope"
+        self.image_size, self.network_capacity, self.fmap_max = image_size, network_capacity, fmap_max
+        self.transparent = transparent
+        self.fq_layers, self.fq_dict_size = cast_list(fq_layers), fq_dict_size
+        self.attn_layers, self.no_const = cast_list(attn_layers), no_const
+        self.aug_prob, self.aug_types = aug_prob, aug_types
+        self.lr, self.lr_mlp, self.ttur_mult = lr, lr_mlp, ttur_mult
+        self.batch_size, self.num_workers, self.mixed_prob = batch_size, num_workers, mixed_prob
+        self.num_image_tiles, self.evaluate_every, self.save_every = num_image_tiles, evaluate_every, save_every
+        self.steps = 0
+        self.av = None
+        self.trunc_psi = trunc_psi
+        self.no_pl_reg = no_pl_reg
+        self.pl_mean = None
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.fp16 = False
+        self.d_loss = self.g_loss = self.total_rec_loss = self.total_kl_loss = 0
+        self.q_loss = self.last_gp_loss = self.last_cr_loss = self.last_fid = None
+        self.init_folders()
+        self.loader = None
+        self.dataset = None
+        self.dataset_aug_prob = dataset_aug_prob
+        self.calculate_fid_every, self.calculate_fid_num_images = calculate_fid_every, calculate_fid_num_images
+        self.clear_fid_cache = clear_fid_cache
+        self.is_ddp, self.is_main, self.rank, self.world_size = is_ddp, rank == 0, rank, world_size
+        self.sample_from_encoder = sample_from_encoder
+        self.logger = None
+        self.gp_every, self.pl_every, self.pl_after = gp_every, pl_every, pl_after
+        self.device = _dev(device if device is not None else rank)
+        self.lpips_fn = lpips_fn
+        self.num_classes = num_classes
+        if classifier is not None:
+            self.classifier = classifier
+        elif str(classifier_name).lower() == "resnet":
+            self.classifier = ResNet(classifier_path, cuda_rank=rank, output_size=num_classes, image_size=image_size)
+        else:
+            self.classifier = MobileNet(classifier_path, cuda_rank=rank, output_size=num_classes, image_size=image_size)
+        self.tb_writer = None
+        if exists(tensorboard_dir):
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+
+                self.tb_writer = SummaryWriter(os.path.join(tensorboard_dir, name))
+            except Exception:  # tensorboard is optional (absent offline)
+                self.tb_writer = None
+
+    # ---- bookkeeping -------------------------------------------------------------------
+
+    @property
+    def image_extension(self):
+        return "jpg" if not self.transparent else "png"
+
+    @property
+    def checkpoint_num(self):
+        return floor(self.steps // self.save_every)
+
+    @property
+    def hparams(self):
+        return {"image_size": self.image_size, "network_capacity": self.network_capacity}
+
+    def init_StylEx(self):
+        args, kwargs = self.model_params
+        self.StylEx = StylEx(lr=self.lr, lr_mlp=self.lr_mlp, ttur_mult=self.ttur_mult, image_size=self.image_size,
+                             network_capacity=self.network_capacity, fmap_max=self.fmap_max,
+                             transparent=self.transparent, fq_layers=self.fq_layers, fq_dict_size=self.fq_dict_size,
+                             attn_layers=self.attn_layers, no_const=self.no_const, rank=self.device,
+                             classifier_labels=self.num_classes, *args, **kwargs)
+        if self.is_ddp:
+            m = self.StylEx
+            parallel.broadcast_parameters(m)
+            self._d_sync = parallel.GradSync(list(m.D.parameters()))
+            self._g_sync = parallel.GradSync(list(m.G.parameters()) + list(m.S.parameters())
+                                             + list(m.encoder.parameters()))
+
+    def write_config(self):
+        self.config_path.write_text(json.dumps(self.config()))
+
+    def load_config(self):
+        config = self.config() if not self.config_path.exists() else json.loads(self.config_path.read_text())
+        self.image_size = config["image_size"]
+        self.network_capacity = config["network_capacity"]
+        self.transparent = config["transparent"]
+        self.fq_layers = config["fq_layers"]
+        self.fq_dict_size = config["fq_dict_size"]
+        self.fmap_max = config.pop("fmap_max", 512)
+        self.attn_layers = config.pop("attn_layers", [])
+        self.no_const = config.pop("no_const", False)
+        self.lr_mlp = config.pop("lr_mlp", 0.1)
+        self.StylEx = None
+        self.init_StylEx()
+
+    def config(self):
+        return {"image_size": self.image_size, "network_capacity": self.network_capacity, "lr_mlp": self.lr_mlp,
+                "transparent": self.transparent, "fq_layers": self.fq_layers, "fq_dict_size": self.fq_dict_size,
+                "attn_layers": self.attn_layers, "no_const": self.no_const,
+                # the reference reads 'fmap_max' back (:1209) but never writes it (:1215-1218); writing it
+                # keeps non-default widths loadable and stays readable by the reference
+                "fmap_max": self.fmap_max}
+
+    def set_data_src(self, folder="./", dataset_name=None):
+        if dataset_name == "MNIST":
+            self.dataset = MNIST_1vA(digit=8)
+        self.dataset = Dataset(folder, self.image_size, transparent=self.transparent, aug_prob=self.dataset_aug_prob)
+        num_workers = default(self.num_workers, NUM_CORES if not self.is_ddp else 0)
+        sampler = DistributedSampler(self.dataset, rank=self.rank, num_replicas=self.world_size,
+                                     shuffle=True) if self.is_ddp else None
+        loader = data.DataLoader(self.dataset, num_workers=num_workers,
+                                 batch_size=math.ceil(self.batch_size / self.world_size), sampler=sampler,
+                                 shuffle=not self.is_ddp, drop_last=True, pin_memory=torch.cuda.is_available())
+        self.loader = cycle(loader)
+        num_samples = len(self.dataset)
+        if not exists(self.aug_prob) and num_samples < 1e5:
+            self.aug_prob = min(0.5, (1e5 - num_samples) * 3e-6)
+            print(f"autosetting augmentation probability to {round(self.aug_prob * 100)}%")
+
+    # ---- the hot path -------------------------------------------------------------------
+
+    def _next_batch(self):
+        return next(self.loader).to(self.device, non_blocking=True)
+
+    def _styles_from_encoder(self, batch):
+        m = self.StylEx
+        enc = m.encoder(batch)
+        logits = self.classifier.classify_images(batch)
+        w = styles_def_to_tensor([(torch.cat((enc, logits), dim=1), m.G.num_layers)])
+        return enc, logits, w
+
+    def _styles_from_noise(self, latents_fn, batch_size):
+        m = self.StylEx
+        style = latents_fn(batch_size, m.G.num_layers, m.G.latent_dim, device=self.device)
+        inoise = image_noise(batch_size, m.G.image_size, device=self.device)
+        return styles_def_to_tensor(latent_to_w(m.S, style)), inoise
+
+    def train(self):
+        """One optimiser step of D, then one of G (reference :1249-1506)."""
+        assert exists(self.loader), "You must first initialize the data source with `.set_data_src(<folder of images>)`"
+        if not exists(self.StylEx):
+            self.init_StylEx()
+        m = self.StylEx
+        m.train()
+        dev = self.device
+        gae = self.gradient_accumulate_every
+        batch_size = math.ceil(self.batch_size / self.world_size)
+        image_size = m.G.image_size
+        aug = {"prob": self.aug_prob, "types": self.aug_types}
+        apply_gp = self.steps % self.gp_every == 0
+        apply_pl = (not self.no_pl_reg) and self.steps > self.pl_after and self.steps % self.pl_every == 0
+        tot_d, tot_g, tot_rec, tot_kl = (torch.zeros((), device=dev) for _ in range(4))
+        gp_val = None
+        avg_pl_length = self.pl_mean
+        latents_fn = None
+
+        # ---------------- discriminator phase ----------------
+        m.D_opt.zero_grad()
+        encoder_input = False
+        for micro in range(gae):
+            real = self._next_batch()
+            if apply_gp:
+                real.requires_grad_()
+            with torch.no_grad():  # the generator/encoder graph is never used in this phase (:1330-1331)
+                if (not self.alternating_training) or encoder_input:
+                    _, _, w_styles = self._styles_from_encoder(self._next_batch())
+                    inoise = image_noise(batch_size, image_size, device=dev)
+                    encoder_input = False
+                else:
+                    latents_fn = mixed_list if random() < self.mixed_prob else noise_list
+                    w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
+                    if self.alternating_training:
+                        encoder_input = True
+                generated = m.G(w_styles, inoise)
+            fake_out = m.D_aug(generated, detach=True, **aug)
+            real_out = m.D_aug(real, **aug)
+            divergence = hinge_loss(real_out, fake_out)
+            disc_loss = divergence
+            if apply_gp:
+                gp = gradient_penalty(real, real_out)
+                gp_val = gp.detach()
+                disc_loss = disc_loss + gp
+            (disc_loss / gae).backward()
+            tot_d += divergence.detach() / gae
+        if self.is_ddp:
+            self._d_sync.all_reduce()
+        self.d_loss = float(tot_d)  # the one host sync of this phase
+        if gp_val is not None:
+            self.last_gp_loss = float(gp_val)
+        if math.isnan(self.d_loss):
+            raise NanException  # reference: raise_if_nan hook on the loss (:1352) — before the step
+        m.D_opt.step()
+
+        # ---------------- generator phase ----------------
+        if self.alternating_training:
+            encoder_input = False
+        m.G_opt.zero_grad()
+        set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
+        try:
+            for micro in range(gae):
+                batch = self._next_batch()
+                enc_step = (not self.alternating_training) or encoder_input
+                if enc_step:
+                    enc_out, real_logits, w_styles = self._styles_from_encoder(batch)
+                    inoise = image_noise(batch_size, image_size, device=dev)
+                else:
+                    w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
+                generated = m.G(w_styles, inoise)
+                fake_out = m.D_aug(generated, **aug)
+                loss = gen_hinge_loss(fake_out, None)
+                total = loss
+                if enc_step:
+                    gen_logits = self.classifier.classify_images(generated)
+                    rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, m.encoder(generated), enc_out,
+                                                                     self.lpips_fn) / gae
+                    kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
+                if apply_pl:
+                    pl_lengths = calc_pl_lengths(w_styles, generated)
+                    avg_pl_length = np.mean(pl_lengths.detach().cpu().numpy())
+                    if not is_empty(self.pl_mean):
+                        pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
+                        if not torch.isnan(pl_loss):
+                            total = total + pl_loss
+                total = total / gae
+                if enc_step:
+                    (total + rec + kl).backward()  # == the three backward calls of :1436-1438
+                    tot_rec += rec.detach()
+                    tot_kl += kl.detach()
+                else:
+                    total.backward()
+                tot_g += loss.detach() / gae
+                encoder_input = not encoder_input
+        finally:
+            set_requires_grad(m.D, True)
+        if self.is_ddp:
+            self._g_sync.all_reduce()
+        self.g_loss, rec_f, kl_f = (float(v) for v in torch.stack((tot_g, tot_rec, tot_kl)).tolist())
+        if (not self.alternating_training) or gae > 1:
+            self.total_rec_loss, self.total_kl_loss = rec_f, kl_f
+        if math.isnan(self.g_loss):
+            raise NanException
+        if exists(self.tb_writer):
+            for k, v in (("G", self.g_loss), ("D", self.d_loss), ("rec", self.total_rec_loss),
+                         ("kl", self.total_kl_loss)):
+                self.tb_writer.add_scalar("loss/" + k, v, self.steps)
+        m.G_opt.step()
+
+        if apply_pl and not np.isnan(avg_pl_length):  # EMA(0.99), reference :1128, :1471-1473
+            self.pl_mean = avg_pl_length if self.pl_mean is None else self.pl_mean * 0.99 + 0.01 * avg_pl_length
+        if self.is_main and self.steps % 10 == 0 and self.steps > 20000:
+            m.EMA()
+        if self.is_main and self.steps <= 25000 and self.steps % 1000 == 2:
+            m.reset_parameter_averaging()
+        if self.is_main:
+            if self.steps % self.save_every == 0:
+                self.save(self.checkpoint_num)
+            if self.steps % self.evaluate_every == 0 or (self.steps % 100 == 0 and self.steps < 2500):
+                self.evaluate(encoder_input=self.sample_from_encoder, num=floor(self.steps / self.evaluate_every))
+            if exists(self.calculate_fid_every) and self.steps % self.calculate_fid_every == 0 and self.steps != 0:
+                self.last_fid = self.calculate_fid(math.ceil(self.calculate_fid_num_images / self.batch_size))
+        self.steps += 1
+        self.av = None
+
+    # ---- evaluation / generation (reference :1508-1698) ---------------------------------------
+
+    @torch.no_grad()
+    def evaluate(self, encoder_input=False, num=0, trunc=1.0):
+        m = self.StylEx
+        m.eval()
+        rows = self.num_image_tiles
+        latent_dim, image_size, num_layers = m.G.latent_dim, m.G.image_size, m.G.num_layers
+        latents = noise_list(rows ** 2, num_layers, latent_dim, device=self.device)
+        n = image_noise(rows ** 2, image_size, device=self.device)
+        tag = ""
+        image_batch = self._next_batch()
+        w = None
+        if encoder_input:
+            tag = "from_encoder"
+            logits = self.classifier.classify_images(image_batch)
+            w = [(torch.cat((m.encoder(image_batch), logits), dim=1), num_layers)]
+            rows = len(image_batch)
+        out_dir = self.results_dir / self.name
+        imgs = self.generate_truncated(m.S, m.G, latents, n, w=w, trunc_psi=self.trunc_psi)
+        save_image_grid(torch.cat((image_batch, imgs)), str(out_dir / f"{num}-{tag}.png"), nrow=rows)
+        imgs = self.generate_truncated(m.SE, m.GE, latents, n, w=w, trunc_psi=self.trunc_psi)
+        save_image_grid(torch.cat((image_batch, imgs)), str(out_dir / f"{num}-{tag}-ema.png"), nrow=rows)
+        nn_ = noise(rows, latent_dim, device=self.device)
+        tiled = nn_.repeat_interleave(rows, dim=0)
+        repeated = nn_.repeat(rows, 1)
+        tt = int(num_layers / 2)
+        mixed = [(tiled, tt), (repeated, num_layers - tt)]
+        imgs = self.generate_truncated(m.SE, m.GE, mixed, n, trunc_psi=self.trunc_psi)
+        save_image_grid(torch.cat((image_batch, imgs)), str(out_dir / f"{num}-{tag}-mr.png"), nrow=rows)
+
+    @torch.no_grad()
+    def calculate_fid(self, num_batches):
+        raise RuntimeError("FID needs pytorch_fid + Inception weights (network) — out of scope offline")
+
+    @torch.no_grad()
+    def truncate_style(self, tensor, trunc_psi=0.75):
+        m = self.StylEx
+        if not exists(self.av):
+            z = noise(2000, m.G.latent_dim, device=self.device)
+            samples = evaluate_in_chunks(self.batch_size, m.S, z).cpu().numpy()
+            self.av = np.expand_dims(np.mean(samples, axis=0), axis=0)
+        av = torch.from_numpy(self.av).to(self.device)
+        return trunc_psi * (tensor - av) + av
+
+    @torch.no_grad()
+    def truncate_style_defs(self, w, trunc_psi=0.75):
+        return [(self.truncate_style(t, trunc_psi=trunc_psi), n) for t, n in w]
+
+    @torch.no_grad()
+    def generate_truncated(self, S, G, style, noi, w=None, trunc_psi=0.75, num_image_tiles=8):
+        if w is None:
+            w = [(S(z), n) for z, n in style]
+        w_styles = styles_def_to_tensor(self.truncate_style_defs(w, trunc_psi=trunc_psi))
+        return evaluate_in_chunks(self.batch_size, G, w_styles, noi).clamp_(0., 1.)
+
+    @torch.no_grad()
+    def generate_interpolation(self, num=0, num_image_tiles=8, trunc=1.0, num_steps=100, save_frames=False):
+        m = self.StylEx
+        m.eval()
+        rows = num_image_tiles
+        latent_dim, image_size, num_layers = m.G.latent_dim, m.G.image_size, m.G.num_layers
+        low = noise(rows ** 2, latent_dim, device=self.device)
+        high = noise(rows ** 2, latent_dim, device=self.device)
+        n = image_noise(rows ** 2, image_size, device=self.device)
+        frames = []
+        for ratio in torch.linspace(0., 8., num_steps):
+            latents = [(slerp(ratio, low, high), num_layers)]
+            imgs = self.generate_truncated(m.SE, m.GE, latents, n, trunc_psi=self.trunc_psi)
+            frames.append(grid_to_pil(imgs, nrow=rows))
+        frames[0].save(str(self.results_dir / self.name / f"{num}.gif"), save_all=True, append_images=frames[1:],
+                       duration=80, loop=0, optimize=True)
+        if save_frames:
+            folder = self.results_dir / self.name / f"{num}"
+            folder.mkdir(parents=True, exist_ok=True)
+            for i, fr in enumerate(frames):
+                fr.save(str(folder / f"{i}.{self.image_extension}"))
+
+    def print_log(self):
+        data_ = [("G", self.g_loss), ("D", self.d_loss), ("GP", self.last_gp_loss), ("PL", self.pl_mean),
+                 ("CR", self.last_cr_loss), ("Q", self.q_loss), ("FID", self.last_fid), ("Rec", self.total_rec_loss),
+                 ("KL", self.total_kl_loss)]
+        print(" | ".join(f"{k}: {v:.2f}" for k, v in data_ if exists(v)))
+
+    def track(self, value, name):
+        pass  # aim logger is not available offline (reference :1717-1720)
+
+    def model_name(self, num):
+        return str(self.models_dir / self.name / f"model_{num}.pt")
+
+    def init_folders(self):
+        (self.results_dir / self.name).mkdir(parents=True, exist_ok=True)
+        (self.models_dir / self.name).mkdir(parents=True, exist_ok=True)
+
+    def clear(self):
+        rmtree(str(self.models_dir / self.name), True)
+        rmtree(str(self.results_dir / self.name), True)
+        rmtree(str(self.fid_dir), True)
+        rmtree(str(self.config_path), True)
+        self.init_folders()
+
+    def save(self, num):
+        if not exists(self.StylEx):
+            self.init_StylEx()
+        torch.save({"StylEx": self.StylEx.state_dict(), "version": __version__}, self.model_name(num))
+        self.write_config()
+
+    def load(self, num=-1):
+        self.load_config()
+        name = num
+        if num == -1:
+            saved = sorted(int(p.stem.split("_")[1]) for p in Path(self.models_dir / self.name).glob("model_*.pt"))
+            if not saved:
+                return
+            name = saved[-1]
+            print(f"continuing from previous epoch - {name}")
+        self.steps = name * self.save_every
+        load_data = torch.load(self.model_name(name), map_location=self.device)
+        if "version" in load_data:
+            print(f"loading from version {load_data['version']}")
+        self.StylEx.load_state_dict(load_data["StylEx"])
+        if self.is_ddp:
+            parallel.broadcast_parameters(self.StylEx)
+
+
+def grid_to_pil(images, nrow=8, padding=2):
+    """torchvision.utils.make_grid + ToPILImage equivalent (torchvision is absent offline)."""
+    from PIL import Image
+
+    images = images.detach().float().cpu().clamp(0, 1)
+    n, c, h, w = images.shape
+    ncol = min(nrow, n)
+    nrows = int(math.ceil(n / ncol))
+    grid = torch.zeros(c, nrows * (h + padding) + padding, ncol * (w + padding) + padding)
+    for i in range(n):
+        r, q = divmod(i, ncol)
+        y0, x0 = padding + r * (h + padding), padding + q * (w + padding)
+        grid[:, y0:y0 + h, x0:x0 + w] = images[i]
+    arr = (grid.permute(1, 2, 0).numpy() * 255 + 0.5).astype(np.uint8)
+    return Image.fromarray(arr if c != 1 else arr[:, :, 0])
+
+
+def save_image_grid(images, path, nrow=8):
+    grid_to_pil(images, nrow=nrow).save(path)
+
+
+class ModelLoader:  # reference :1777-1800
+    def __init__(self, *, base_dir, name="default", load_from=-1, **trainer_kwargs):
+        trainer_kwargs.setdefault("classifier_name", "resnet")
+        self.model = Trainer(name=name, base_dir=base_dir, **trainer_kwargs)
+        self.model.load(load_from)
+
+    def noise_to_styles(self, noise_, trunc_psi=None):
+        w = self.model.StylEx.SE(noise_.to(self.model.device))
+        if exists(trunc_psi):
+            w = self.model.truncate_style(w)
+        return w
+
+    def styles_to_images(self, w):
+        m = self.model.StylEx
+        w_tensors = styles_def_to_tensor([(w, m.GE.num_layers)])
+        images = m.GE(w_tensors, image_noise(w.shape[0], self.model.image_size, device=self.model.device))
+        return images.clamp_(0., 1.)

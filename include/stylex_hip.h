@@ -1,0 +1,141 @@
+/*
+ * stylex_hip.h — C-ABI of libstylex_hip.so: hand-written gfx950 (MI355X / CDNA4)
+ * kernels for the StylEx adversarial train step.
+ *
+ * The reference (NoahVl/Explaining-In-Style-Reproducibility-Study) has no native
+ * layer of its own: every GPU kernel it runs comes from PyTorch/cuDNN through the
+ * Python ops cited below.  This header is the boundary a maintainer would bind
+ * (ctypes stub in INTEGRATION.md) to replace those ops on MI355X.
+ *
+ * Conventions:
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *    borrowed for the duration of the enqueue only;
+ *  - activations are fp32 or bf16 (`act_dtype`) NHWC ("channels_last"):
+ *    x[b][h][w][c]; weights arrive in the reference's OIHW parameter layout and
+ *    are repacked by stylex_pack_weight();
+ *  - every entry point only ENQUEUES work on `stream` (a hipStream_t passed as
+ *    void*), never allocates/frees device memory, never synchronises;
+ *  - return value: 0 on success, a hipError_t code (>0) from the runtime, or a
+ *    negative STYLEX_E* code for bad arguments.  Never throws.
+ *  - `shape` arrays are int64 host arrays; layout documented per function.
+ *  - `precision`: arithmetic of the MFMA contraction —
+ *      STYLEX_F32  v_mfma_f32_32x32x2_f32   (exact fp32, parity mode)
+ *      STYLEX_BF16 v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 when staged
+ *                                            into LDS, fp32 accumulate).
+ */
+#ifndef STYLEX_HIP_H
+#define STYLEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STYLEX_F32 0
+#define STYLEX_BF16 1
+
+#define STYLEX_EINVAL (-1)   /* bad shape / unsupported configuration */
+#define STYLEX_EWORKSPACE (-2) /* workspace too small */
+
+/* conv shape vector, shared by the three conv entry points:
+ *   [0]=B [1]=Hi [2]=Wi [3]=C (input channels) [4]=N (output channels)
+ *   [5]=KH [6]=KW [7]=stride [8]=pad [9]=Ho [10]=Wo                      */
+#define STYLEX_CONV_NSHAPE 11
+
+/* epilogue flags for stylex_conv2d_fwd */
+#define STYLEX_EPI_BIAS 1      /* + bias[n]                                          */
+#define STYLEX_EPI_LRELU 2     /* leaky_relu(., 0.2)                                 */
+#define STYLEX_EPI_OSCALE 4    /* * out_scale[b][n]  (demodulation coefficient)      */
+#define STYLEX_EPI_NOISE 8     /* + noise[b][w][h] * noise_w[n] + noise_b[n] (sic: transposed) */
+#define STYLEX_EPI_RESIDUAL 16 /* (acc + residual[m][n]) * res_scale                 */
+
+/* One-time per-process/per-device initialisation (kernel attributes). */
+int stylex_init(int device);
+const char* stylex_version(void);
+
+/* Repack an OIHW parameter W[N][C][KH][KW] (fp32) into the two K-contiguous
+ * layouts the implicit-GEMM kernels read:
+ *   w_fwd[n][t][c]  (t = kh*KW+kw)   — forward / "fprop" operand
+ *   w_bwd[c][t][n]                   — data-gradient operand
+ * Either output may be NULL.  shape = {N, C, KH, KW}.
+ * Replaces: the implicit weight handling inside F.conv2d
+ * (reference stylex/stylex_train.py:660 and nn.Conv2d at :724-736, :771, :881). */
+int stylex_pack_weight(const float* w_oihw, float* w_fwd, float* w_bwd, const int64_t* shape, void* stream);
+
+/* y[b,ho,wo,n] = epi( sum_{kh,kw,c} in_scale[b][c] * x[b,ho*s+kh-p,wo*s+kw-p,c] * w_fwd[n][kh*KW+kw][c] )
+ * Replaces F.conv2d in Conv2DMod.forward (stylex_train.py:647-667, with the
+ * modulation applied as in_scale = style+1 and demodulation as out_scale) and
+ * nn.Conv2d in DiscriminatorBlock / Generator.initial_conv / final_conv
+ * (:724-744, :771, :881) including the fused bias + LeakyReLU(0.2) (:340-341),
+ * the noise add (:696-705) and the residual merge (:743).
+ * Optional pointers may be NULL when the corresponding flag is clear. */
+typedef struct {
+    const float* in_scale;  /* [B][C]  or NULL */
+    const float* bias;      /* [N] */
+    const float* out_scale; /* [B][N] */
+    const float* noise;     /* [B][S][S] image noise plane; value used at (h,w) is noise[b][w][h] */
+    int64_t noise_stride;   /* S */
+    const float* noise_w;   /* [N] */
+    const float* noise_b;   /* [N] */
+    const float* residual;  /* [B][Ho][Wo][N] */
+    float res_scale;
+} stylex_conv_epilogue;
+
+int stylex_conv2d_fwd(const float* x, const float* w_fwd, float* y, const int64_t* shape, int flags,
+                      const stylex_conv_epilogue* epi, int precision, void* stream);
+
+/* dx[b,hi,wi,c] = sum_{kh,kw,n} dy[b,(hi+p-kh)/s,(wi+p-kw)/s,n] * w_bwd[c][t][n]   (exact division only)
+ * Replaces the input-gradient half of aten::convolution_backward issued by
+ * autograd for the call sites above (and, through create_graph=True, the
+ * double-backward chain of gradient_penalty, stylex_train.py:296-303). */
+/* Modulated form: epi->in_scale [B][N] scales dy while it is staged (demodulation
+ * coefficient) and, with STYLEX_EPI_OSCALE, epi->out_scale [B][C] scales dx
+ * (style+1).  flags may only contain STYLEX_EPI_OSCALE; epi may be NULL. */
+int stylex_conv2d_bwd_data(const float* dy, const float* w_bwd, float* dx, const int64_t* shape, int flags,
+                           const stylex_conv_epilogue* epi, int precision, void* stream);
+
+/* dw[n][c][kh][kw] (OIHW, fp32) = sum_{b,ho,wo} dy[b,ho,wo,n] * x[b,ho*s+kh-p,wo*s+kw-p,c]
+ * Deterministic two-stage split-K reduction through `workspace`.
+ * Replaces the weight-gradient half of aten::convolution_backward. */
+int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* shape);
+/* x_scale [B][C] / dy_scale [B][N] (either may be NULL) are the per-sample
+ * modulation / demodulation factors of the modulated conv, applied while staging. */
+int stylex_conv2d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes,
+                             const int64_t* shape, const float* x_scale, const float* dy_scale, int precision,
+                             void* stream);
+
+/* Bilinear x2, align_corners=False (nn.Upsample, stylex_train.py:614,679) and its adjoint.
+ * shape = {B, H, W, C} of the LOW-resolution tensor.  Index rule (exact):
+ *   out[2k] = .25*in[max(k-1,0)] + .75*in[k];  out[2k+1] = .75*in[k] + .25*in[min(k+1,n-1)] */
+int stylex_upsample2x_bilinear_fwd(const float* x, float* y, const int64_t* shape, void* stream);
+int stylex_upsample2x_bilinear_bwd(const float* dy, float* dx, const int64_t* shape, void* stream);
+
+/* 3x3 binomial blur /16 with reflect border (Blur.forward, stylex_train.py:144-153 ->
+ * kornia.filters.filter2d(normalized=True, border_type='reflect')) and its adjoint.
+ * shape = {B, H, W, C}.  Index rule (exact): -1 -> 1, H -> H-2. */
+int stylex_blur3x3_reflect_fwd(const float* x, float* y, const int64_t* shape, void* stream);
+int stylex_blur3x3_reflect_bwd(const float* dy, float* dx, const int64_t* shape, void* stream);
+
+/* y = leaky_relu(x + bias[c] (+ noise[b][w][h]*noise_w[c] + noise_b[c]), 0.2)
+ * (nn.Conv2d bias + leaky_relu, stylex_train.py:340-341,726-731; noise add :696-714).
+ * shape = {B, H, W, C}.  bias/noise pointers may be NULL.  bwd: dx = dy * (y>0 ? 1 : 0.2). */
+int stylex_bias_act_fwd(const float* x, const float* bias, const float* noise, int64_t noise_stride,
+                        const float* noise_w, const float* noise_b, float* y, const int64_t* shape, void* stream);
+int stylex_bias_act_bwd(const float* dy, const float* y, float* dx, const int64_t* shape, void* stream);
+
+/* out[r] = sum_j x[r][j]^2   (per-sample squared L2 norm; gradient_penalty :302,
+ * calc_pl_lengths :316).  shape = {rows, cols}.  One wavefront-shuffle + LDS
+ * reduction per row block; deterministic. */
+int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void* stream);
+
+/* Per-kernel timing hook: when enabled every conv launch is bracketed
+ * by hipEvents on its stream; stylex_timing_report returns, per kernel class
+ * (0=fwd,1=bwd_data,2=bwd_weight): launches, total ms, total algorithmic FLOPs. */
+int stylex_timing_enable(int on);
+int stylex_timing_report(int kernel_class, int64_t* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STYLEX_HIP_H */

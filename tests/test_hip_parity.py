@@ -1,0 +1,294 @@
+"""-m gpu: parity of the HIP path (through the C-ABI, libstylex_hip.so) against the CPU
+oracle and the golden vectors captured from the reference.
+
+Tolerances (stated per north_star): fp32 mode 2e-5 relative to the tensor's max-abs (only the
+summation order differs: v_mfma_f32_32x32x2_f32 is an fmaf chain); bf16 mode 3e-2 (operands
+rounded to bf16, fp32 accumulate); resampling index arithmetic is exact, values to 1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import hip_backend as hb  # noqa: E402
+import ops  # noqa: E402
+import stylex_oracle as so  # noqa: E402
+import stylex_train as st  # noqa: E402
+from conftest import load_golden  # noqa: E402
+from lpips_standin import LPIPSStandIn  # noqa: E402
+from test_oracle_vs_golden import build_nets_model, close_stats  # noqa: E402
+from test_host_logic_cpu import make_trainer, run_steps  # noqa: E402
+
+DEV = "cuda:0"
+TOL32, TOLBF = 2e-5, 3e-2
+
+
+@pytest.fixture(autouse=True)
+def hip_impl():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    prev = ops.use_impl(ops.HipOps)
+    ops.set_precision("fp32")
+    hb.load_library()  # fails loudly if the extension is missing
+    yield
+    ops.set_precision("fp32")
+    ops.use_impl(prev)
+
+
+def close(a, b, tol=TOL32, what=""):
+    a = torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1e-3, a.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e (scale %.3e, tol %.1e)" % (what, err, scale, tol)
+
+
+def cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # B, C, N, H, W, k, stride, pad
+    (2, 16, 24, 8, 8, 3, 1, 1),
+    (2, 3, 64, 16, 16, 3, 1, 1),      # first D conv (scalar-gather path, K = 27)
+    (3, 6, 10, 9, 7, 3, 1, 1),        # odd sizes, C % 4 != 0
+    (2, 64, 64, 16, 16, 3, 2, 1),     # blur-downsample conv
+    (2, 8, 12, 8, 8, 1, 2, 0),        # conv_res 1x1 stride 2
+    (2, 32, 3, 8, 8, 1, 1, 0),        # toRGB shape
+    (1, 128, 160, 12, 12, 3, 1, 1),   # >1 N tile, >1 K chunk
+    (2, 40, 72, 10, 10, 3, 1, 1),     # ragged channel chunks
+    (5, 20, 36, 6, 6, 3, 2, 1),
+    (2, 512, 512, 4, 4, 3, 1, 1),
+    (1, 64, 64, 64, 64, 3, 1, 1),     # many M tiles
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_triad_vs_oracle(case, prec):
+    """Conv fwd, data-gradient and weight-gradient against F.conv2d + autograd on the CPU."""
+    B, C, N, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(N, C, k, k, generator=g) / (C * k * k) ** 0.5
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y_ref = F.conv2d(xr, wr, None, s, p)
+    r = torch.randn(y_ref.shape, generator=g)
+    (y_ref * r).sum().backward()
+    ops.set_precision(prec)
+    tol = TOL32 if prec == "fp32" else TOLBF
+    xd, wd = cl(x).requires_grad_(), w.to(DEV).requires_grad_()
+    y = ops.conv2d(xd, wd, None, s, p)
+    (y * cl(r)).sum().backward()
+    close(y_ref, y, tol, "fwd")
+    close(xr.grad, xd.grad, tol, "dgrad")
+    close(wr.grad, wd.grad, tol, "wgrad")
+
+
+def test_conv_bias_lrelu_and_second_order():
+    """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 8, 8, generator=g)
+    w1 = torch.randn(10, 6, 3, 3, generator=g) * 0.2
+    b1 = torch.randn(10, generator=g) * 0.1
+    w2 = torch.randn(4, 10, 3, 3, generator=g) * 0.2
+    b2 = torch.randn(4, generator=g) * 0.1
+
+    def net(xx, p, conv):
+        h = conv(xx, p[0], p[1], 1, 1, True)
+        return conv(h, p[2], p[3], 2, 1, False)
+
+    def ref_conv(xx, w, b, s, p, act):
+        y = F.conv2d(xx, w, b, s, p)
+        return F.leaky_relu(y, 0.2) if act else y
+
+    outs = []
+    for dev, conv in (("cpu", ref_conv), (DEV, ops.conv2d)):
+        ps = [t.clone().to(dev).requires_grad_() for t in (w1, b1, w2, b2)]
+        xx = (x.clone().to(dev) if dev == "cpu" else cl(x)).requires_grad_()
+        y = net(xx, ps, conv)
+        (gx,) = torch.autograd.grad(y.sum(), xx, create_graph=True)
+        pen = ((gx.reshape(2, -1).norm(2, dim=1) - 1) ** 2).mean()
+        pen.backward()
+        outs.append((y, gx, pen, [q.grad for q in ps]))
+    (y0, g0, p0, gr0), (y1, g1, p1, gr1) = outs
+    close(y0, y1, what="y")
+    close(g0, g1, what="gx")
+    close(p0, p1, 1e-4, "penalty")
+    for a, b, nm in zip(gr0, gr1, ("w1", "b1", "w2", "b2")):
+        if a is None:
+            assert b is None or float(b.abs().max()) == 0.0
+            continue
+        close(a, b, 2e-4, "second-order grad " + nm)
+
+
+def test_resampling_exact_index_rules():
+    g = load_golden("ops")
+    x = torch.from_numpy(g["up/x"])
+    xd = cl(x).requires_grad_()
+    for nm, fn in (("up", ops.upsample2x), ("blur", ops.blur3x3)):
+        xd.grad = None
+        y = fn(xd)
+        close(g[nm + "/y"], y, 1e-6, nm + " fwd vs reference")
+        (y * cl(torch.from_numpy(g[nm + "/r"]))).sum().backward()
+        close(g[nm + "/gx"], xd.grad, 1e-6, nm + " adjoint vs reference")
+    # index rule: a one-hot input lights up exactly the outputs the rule names, with exact weights
+    for n in (2, 3, 8):
+        for i in range(n):
+            e = torch.zeros(1, 4, n, n)
+            e[0, :, i, i] = 1.0
+            yu = ops.upsample2x(cl(e)).cpu()
+            assert torch.equal(yu, so.upsample2x_bilinear_explicit(e)), (n, i)
+            yb = ops.blur3x3(cl(e)).cpu()
+            assert torch.equal(yb, so.blur3x3_reflect_explicit(e)), (n, i)
+    # odd channel count exercises the scalar path
+    x3 = torch.randn(2, 3, 6, 10)
+    close(so.upsample2x_bilinear(x3), ops.upsample2x(cl(x3)), 1e-6, "up C=3")
+    close(so.blur3x3_reflect(x3), ops.blur3x3(cl(x3)), 1e-6, "blur C=3")
+
+
+def test_bias_act_and_noise_act_and_sumsq():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 12, 8, 8, generator=g)
+    b = torch.randn(12, generator=g)
+    xd, bd = cl(x).requires_grad_(), b.to(DEV).requires_grad_()
+    xr, br = x.clone().requires_grad_(), b.clone().requires_grad_()
+    y = ops.conv2d  # noqa
+    from ops import _BiasAct
+
+    yd = _BiasAct.apply(xd, bd)
+    yr = F.leaky_relu(xr + br.view(1, -1, 1, 1), 0.2)
+    r = torch.randn(yr.shape, generator=g)
+    (yd * cl(r)).sum().backward()
+    (yr * r).sum().backward()
+    close(yr, yd, 1e-6)
+    close(xr.grad, xd.grad, 1e-6)
+    close(br.grad, bd.grad, 1e-5)
+    inoise = torch.rand(2, 16, 16, 1, generator=g)
+    nw, nb = torch.randn(12, generator=g), torch.randn(12, generator=g)
+    from cpu_ops import CpuOracleOps
+
+    close(CpuOracleOps.noise_act(x, inoise, nw, nb), ops.noise_act(cl(x), inoise.to(DEV), nw.to(DEV), nb.to(DEV)), 1e-6)
+    v = torch.randn(5, 3 * 64 * 64 + 3, generator=g)
+    close(v.pow(2).sum(1), ops.rowwise_sumsq(v.to(DEV)), 1e-5)
+
+
+@pytest.mark.parametrize("tag", ["mod3", "mod1", "mod512"])
+def test_conv2dmod_vs_reference_golden(tag):
+    g = load_golden("ops")
+    ci, co, k, demod, hw, b, wseed = (int(v) for v in g[tag + "/cfg"])
+    torch.manual_seed(wseed)
+    conv = st.Conv2DMod(ci, co, k, demod=bool(demod)).to(DEV)
+    x = cl(torch.from_numpy(g[tag + "/x"])).requires_grad_()
+    y = torch.from_numpy(g[tag + "/y"]).to(DEV).requires_grad_()
+    o = conv(x, y)
+    (o * cl(torch.from_numpy(g[tag + "/r"]))).sum().backward()
+    close(g[tag + "/out"], o, what="out")
+    close(g[tag + "/gx"], x.grad, what="gx")
+    close(g[tag + "/gy"], y.grad, 1e-4, "gstyle")
+    if tag + "/gw" in g.files:
+        close(g[tag + "/gw"], conv.weight.grad, what="gw")
+    else:
+        close(g[tag + "/gw_slice"], conv.weight.grad[:4, :4], what="gw slice")
+        close_stats(g[tag + "/gw_stats"], conv.weight.grad.cpu())
+
+
+@pytest.mark.parametrize("size", [16, 32])
+def test_network_parity_vs_reference_golden(size):
+    g = load_golden("nets_%d" % size)
+    prev = ops.use_impl(ops.HipOps)
+    m = build_nets_model(g, cls=st.StylEx).to(DEV)
+    ops.use_impl(prev)
+    w, inoise, x = (torch.from_numpy(g[n]).to(DEV) for n in ("w", "inoise", "x"))
+    rgb, coords = m.G(w, inoise, get_style_coords=True)
+    close(g["rgb"], rgb, what="G rgb")
+    close(g["coords"], coords, what="style coords")
+    close(g["d_out"], m.D(x), what="D")
+    close(g["enc_out"], m.encoder(x), what="encoder")
+    close(g["d_of_g"], m.D(rgb), 1e-4, "D(G)")
+
+
+def test_gp_and_pl_double_backward_vs_reference_golden():
+    g = load_golden("losses")
+    s, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["seed"]))
+    m = st.StylEx(s, network_capacity=cap, fmap_max=fmax, rank=0)
+    x = cl(torch.from_numpy(g["gp/x"])).requires_grad_()
+    gp = st.gradient_penalty(x, m.D(x))
+    close(g["gp/value"], gp, 1e-4, "gp value")
+    m.D.zero_grad()
+    gp.backward()
+    grads = dict(m.D.named_parameters())
+    for n, gs in zip(g["gp/grad_names"], g["gp/grad_stats"]):
+        close_stats(gs, grads[str(n)].grad.cpu(), 5e-4)
+    close(g["gp/grad_fc_w"], m.D.fc.weight.grad, 2e-4, "gp grad fc")
+    close(g["gp/grad_b0_res_w"], m.D.blocks[0].conv_res.weight.grad, 2e-4, "gp grad conv_res")
+    w = torch.from_numpy(g["pl/w"]).to(DEV).requires_grad_()
+    img = m.G(w, torch.from_numpy(g["pl/inoise"]).to(DEV))
+    torch.manual_seed(int(g["pl/noise_seed"]))
+    pl = st.calc_pl_lengths(w, img)
+    close(g["pl/lengths"], pl, 1e-4, "pl lengths")
+    m.G.zero_grad()
+    ((pl - 0.3) ** 2).mean().backward()
+    grads = dict(m.G.named_parameters())
+    for n, gs in zip(g["pl/grad_names"], g["pl/grad_stats"]):
+        close_stats(gs, grads[str(n)].grad.cpu(), 2e-3, head_atol=1e-5)
+    close(g["pl/grad_w"], w.grad, 5e-4, "pl grad w")
+
+
+@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl"])
+def test_trainer_step_parity_gpu(tag, tmp_path):
+    """Trainer.train() on the HIP path reproduces the reference's loss scalars (1e-3, north_star)."""
+    g = load_golden("steps_" + tag)
+    tr, n = make_trainer(g, tmp_path, device=torch.device(DEV))
+    rows = run_steps(tr, n)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=2e-4, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=2e-3, atol=2e-3, equal_nan=True)
+
+
+# ---- full-size, size-independent properties at BASELINE.json's 256 px / B=32 shapes ------------
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(32, 64, 64, 256, 3, 1, 1), (32, 128, 128, 128, 3, 2, 1), (32, 3, 64, 256, 3, 1, 1),
+                                  (32, 512, 512, 16, 3, 1, 1)])
+def test_full_size_adjoint_identities(case, prec):
+    """<conv(x,w), r> == <x, dgrad(r,w)> == <w, wgrad(x,r)> — holds for any size, checks the three
+    kernels against each other on the real benchmark shapes where the CPU oracle is too slow."""
+    B, C, N, S, k, s, p = case
+    ops.set_precision(prec)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, C, S, S, device=DEV, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (torch.randn(N, C, k, k, device=DEV, generator=g) / (C * k * k) ** 0.5).requires_grad_()
+    y = ops.conv2d(x, w, None, s, p)
+    r = torch.randn(y.shape, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    lhs = (y.double() * r.double()).sum()
+    gx, gw = torch.autograd.grad(y, (x, w), r)
+    a = (x.detach().double() * gx.double()).sum()
+    b = (w.detach().double() * gw.double()).sum()
+    tol = 1e-4 if prec == "fp32" else 2e-2
+    scale = float(y.detach().double().abs().mul(r.double().abs()).sum()) ** 0.5 + abs(float(lhs))
+    assert abs(float(lhs - a)) <= tol * scale and abs(float(lhs - b)) <= tol * scale, (float(lhs), float(a), float(b))
+    # spot-check one output pixel block against a direct fp64 evaluation
+    xs = x.detach()[:1, :, :10, :10].double().cpu()
+    ys = F.conv2d(xs, w.detach().double().cpu(), None, s, p)
+    hh = ys.shape[2] - 2  # rows not touched by the crop boundary
+    close(ys[:, :, :hh, :hh], y.detach()[:1, :, :hh, :hh], TOL32 * 5 if prec == "fp32" else TOLBF, "spot")
+
+
+def test_full_size_resampling_roundtrip():
+    """Linearity + constants: blur and bilinear x2 preserve constants exactly-ish and commute with scaling."""
+    x = torch.rand(32, 64, 128, 128, device=DEV).contiguous(memory_format=torch.channels_last)
+    ones = torch.ones_like(x)
+    assert float((ops.blur3x3(ones) - 1).abs().max()) <= 1e-6
+    assert float((ops.upsample2x(ones) - 1).abs().max()) <= 1e-6
+    close(ops.upsample2x(x * 3.0), ops.upsample2x(x) * 3.0, 1e-6)
+    # adjoint identity at full size
+    r = torch.rand(32, 64, 256, 256, device=DEV).contiguous(memory_format=torch.channels_last)
+    xr = x.clone().requires_grad_()
+    (ops.upsample2x(xr) * r).sum().backward()
+    lhs = float((ops.upsample2x(x).double() * r.double()).sum())
+    rhs = float((x.double() * xr.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs)

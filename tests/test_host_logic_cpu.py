@@ -1,0 +1,155 @@
+"""Host logic of the product package on CPU: module wiring, init order, state-dict layout,
+losses, Trainer control flow — against the vectors captured from the reference.  The HIP
+kernels cannot run here, so the product's op surface is replaced by the oracle's CPU test
+double (oracle/cpu_ops.py) for the duration of this file; the numerical parity of the kernels
+themselves is the job of the ``-m gpu`` tests."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import ops
+import stylex_train as st
+from cpu_ops import CpuOracleOps
+from lpips_standin import LPIPSStandIn
+from ref_shim import TinyClassifier
+from conftest import load_golden
+from test_oracle_vs_golden import close, close_stats, stats, build_nets_model
+
+
+@pytest.fixture(autouse=True)
+def cpu_double():
+    prev = ops.use_impl(CpuOracleOps)
+    yield
+    ops.use_impl(prev)
+
+
+@pytest.mark.parametrize("size", [8, 16, 32])
+def test_init_parity_product(size):
+    g = load_golden("init_%d" % size)
+    s, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["seed"]))
+    m = st.StylEx(s, network_capacity=cap, fmap_max=fmax)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    for i, (k, v) in enumerate(sd.items()):
+        assert ",".join(map(str, v.shape)) == str(g["shapes"][i]), k
+        np.testing.assert_array_equal(g["stats"][i], stats(v), err_msg=k)
+
+
+@pytest.mark.parametrize("size", [16, 32])
+def test_network_parity_product(size):
+    g = load_golden("nets_%d" % size)
+    m = build_nets_model(g, cls=st.StylEx)
+    w, inoise, x = (torch.from_numpy(g[n]) for n in ("w", "inoise", "x"))
+    rgb, coords = m.G(w, inoise, get_style_coords=True)
+    close(g["rgb"], rgb)
+    close(g["coords"], coords)
+    close(g["d_out"], m.D(x))
+    close(g["enc_out"], m.encoder(x))
+    close(g["s_out"], m.S(w[:, 0]))
+
+
+def test_losses_product():
+    g = load_golden("losses")
+    s, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["seed"]))
+    m = st.StylEx(s, network_capacity=cap, fmap_max=fmax)
+    real, fake = torch.from_numpy(g["hinge/real"]), torch.from_numpy(g["hinge/fake"])
+    close(g["hinge/d"], st.hinge_loss(real, fake), 1e-6)
+    close(g["hinge/g"], st.gen_hinge_loss(fake, None), 1e-6)
+    x = torch.from_numpy(g["gp/x"]).requires_grad_()
+    gp = st.gradient_penalty(x, m.D(x))
+    close(g["gp/value"], gp)
+    m.D.zero_grad()
+    gp.backward()
+    close(g["gp/grad_fc_w"], m.D.fc.weight.grad, 1e-4)
+    w = torch.from_numpy(g["pl/w"]).requires_grad_()
+    img = m.G(w, torch.from_numpy(g["pl/inoise"]))
+    torch.manual_seed(int(g["pl/noise_seed"]))
+    close(g["pl/lengths"], st.calc_pl_lengths(w, img))
+    close(g["kl/value"], st.classifier_kl_loss(torch.from_numpy(g["kl/real"]), torch.from_numpy(g["kl/fake"])), 1e-6)
+    lp = LPIPSStandIn(seed=int(g["rec/lpips_seed"]))
+    i1, i2, w1, w2 = (torch.from_numpy(g["rec/" + n]) for n in ("i1", "i2", "w1", "w2"))
+    close(g["rec/value"], st.reconstruction_loss(i1, i2, w2, w1, lp), 1e-6)
+    # the product's own LPIPS implements the same published graph as the stand-in
+    mine = st.LPIPS(seed=int(g["rec/lpips_seed"]))
+    close(g["rec/lpips_value"], mine(st.lpips_normalize(i1), st.lpips_normalize(i2)).reshape(-1), 1e-6)
+
+
+def make_trainer(g, tmp_path, device=None):
+    size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
+    cls = TinyClassifier(seed=int(g["cls_seed"]))
+    gd = torch.Generator().manual_seed(int(g["data_seed"]))
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    lp = LPIPSStandIn(seed=int(g["lpips_seed"]))
+    if device is not None:
+        cls.to(device)
+        lp = lp.to(device)
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    tr = st.Trainer(name="t", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax,
+                    batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4,
+                    ttur_mult=1.5, rec_scaling=1, kl_scaling=1, classifier=cls, lpips_fn=lp, classifier_name="resnet",
+                    evaluate_every=10 ** 9, save_every=10 ** 9, device=device)
+    tr.loader = st.cycle(batches)
+    tr.dataset = list(range(1000))
+    tr.save = lambda *a, **k: None
+    tr.evaluate = lambda *a, **k: None
+    tr.init_StylEx()
+    tr.steps = start
+    pl0 = float(g["pl_mean0"])
+    tr.pl_mean = None if np.isnan(pl0) else pl0
+    return tr, n
+
+
+def run_steps(tr, n):
+    rows = []
+    for _ in range(n):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                     np.nan if tr.last_gp_loss is None else tr.last_gp_loss,
+                     np.nan if tr.pl_mean is None else tr.pl_mean])
+    return np.array(rows, dtype=np.float64)
+
+
+@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl"])
+def test_trainer_step_parity_cpu(tag, tmp_path):
+    g = load_golden("steps_" + tag)
+    tr, n = make_trainer(g, tmp_path)
+    rows = run_steps(tr, n)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
+    params = dict(tr.StylEx.named_parameters())
+    for name, gs in zip(g["param_names"], g["param_stats"]):
+        # after N Adam steps an element may legitimately differ by a fraction of lr (2e-4)
+        close_stats(gs, params[str(name)], 2e-3, head_atol=1e-4)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    g = load_golden("steps_gae1_alt")
+    tr, _ = make_trainer(g, tmp_path)
+    del tr.save
+    tr.save_every = 1
+    st.Trainer.save(tr, 0)
+    ck = torch.load(tr.model_name(0))
+    assert set(ck.keys()) == {"StylEx", "version"} and ck["version"] == "1.8.7"
+    gi = load_golden("init_32")
+    assert list(ck["StylEx"].keys()) == [str(k) for k in gi["keys"]]
+    tr2, _ = make_trainer(g, tmp_path)
+    tr2.load(0)
+    for (k, a), (_, b) in zip(tr.StylEx.state_dict().items(), tr2.StylEx.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback in the product path: HIP ops refuse CPU tensors."""
+    ops.use_impl(ops.HipOps)
+    import hip_backend
+
+    with pytest.raises(hip_backend.StylexHipError):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3), None, 1, 1)

@@ -31,11 +31,13 @@ def stats(t):
     return np.concatenate([[t.sum().item(), t.abs().sum().item()], head, np.zeros(max(0, 8 - t.numel()))])
 
 
-def close_stats(gold, t, tol=1e-4):
+def close_stats(gold, t, tol=1e-4, head_atol=None):
     s = stats(t)
     scale = max(1.0, abs(gold[1]))
     assert abs(gold[0] - s[0]) <= tol * scale and abs(gold[1] - s[1]) <= tol * scale, (gold[:2], s[:2])
-    np.testing.assert_allclose(gold[2:], s[2:], rtol=1e-4, atol=1e-5 * max(1.0, np.abs(gold[2:]).max()))
+    if head_atol is None:
+        head_atol = 1e-5 * max(1.0, np.abs(gold[2:]).max())
+    np.testing.assert_allclose(gold[2:], s[2:], rtol=1e-4, atol=head_atol)
 
 
 @pytest.mark.parametrize("size", [8, 16, 32])
