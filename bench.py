@@ -1,0 +1,211 @@
+"""bench.py — StylEx G+D+enc train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W              # one GPU
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one ``Trainer.train()`` call = one D optimiser step + one G optimiser step over
+``gradient_accumulate_every`` micro-batches per phase (reference stylex/stylex_train.py:1249-1506).
+Workload (Bench B = the metric's "G+D+enc step"): FFHQ-shaped synthetic 256x256
+batches, 32 images per GPU per micro-batch, GAE=2 with alternating training => one noise and one
+encoder micro-step per phase; steps start at 0 so one call in four carries the gradient penalty.
+Inputs are device-resident before the timed region.  images/s counts B*GAE images per call.
+
+Prints ONE JSON line (rank 0) with the contract keys plus
+  roofline     — dominant conv kernel class, algorithmic FLOPs / hipEvent time, vs the dense MFMA peak
+  cpu_baseline — the CPU oracle ("port") timed on the host cores on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd")
+for p in (os.path.join(PKG, "stylex"), PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+G_FWD, D_FWD, E_FWD = 17.767, 35.511, 35.513  # conv GFLOP per image @256 px
+
+
+def algorithmic_gflop_per_image(gae):
+    """Bench A (GAE=1) 4G+8.75D = 381.8; Bench B (GAE=2) (8G+17.5D+7E)/2 = 506.1."""
+    if gae == 1:
+        return 4 * G_FWD + 8.75 * D_FWD
+    noise = (G_FWD + 6 * D_FWD) + (3 * G_FWD + 2 * D_FWD) + 0.75 * D_FWD
+    enc = (E_FWD + G_FWD + 6 * D_FWD) + (6 * E_FWD + 3 * G_FWD + 2 * D_FWD) + 0.75 * D_FWD
+    return (noise * (gae - gae // 2) + enc * (gae // 2)) / gae
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def build_trainer(args, device, rank, world):
+    import stylex_train as st
+
+    gen = torch.Generator().manual_seed(7 + rank)
+    ring = [torch.rand(args.batch, 3, args.image_size, args.image_size, generator=gen).to(device) for _ in range(8)]
+    seed_all(42)
+    tr = st.Trainer(name="bench", base_dir=args.workdir, image_size=args.image_size, network_capacity=16,
+                    fmap_max=512, batch_size=args.batch * world, gradient_accumulate_every=args.gae, lr=2e-4,
+                    ttur_mult=1.5, mixed_prob=0.9, rec_scaling=1, kl_scaling=1, aug_prob=0.,
+                    alternating_training=True, classifier_name=args.classifier, classifier_path=None,
+                    evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None, is_ddp=world > 1, rank=rank,
+                    world_size=world, device=device)
+    tr.loader = st.cycle(ring)
+    tr.dataset = list(range(10 ** 6))
+    tr.save = lambda *a, **k: None
+    tr.evaluate = lambda *a, **k: None
+    tr.init_StylEx()
+    seed_all(42 + rank)  # rank-distinct latents/noise, rank-identical weights (broadcast in init_StylEx)
+    return tr
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/stylex_oracle.py, a port of the reference's CPU path) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import stylex_oracle as so
+    from lpips_standin import LPIPSStandIn
+    from ref_shim import TinyClassifier
+
+    # the oracle's grouped convolutions stop scaling (and collapse under oversubscription) beyond a
+    # handful of threads: 256 threads on the GPU box measured 60x SLOWER than 8.  Use <= 16.
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    torch.set_num_threads(cores)
+    bs = args.cpu_batch
+    gen = torch.Generator().manual_seed(7)
+    ring = [torch.rand(bs, 3, args.image_size, args.image_size, generator=gen) for _ in range(4)]
+
+    def cyc():
+        while True:
+            for b in ring:
+                yield b
+
+    seed_all(42)
+    tr = so.OracleTrainer(TinyClassifier(seed=99), LPIPSStandIn(seed=4242), cyc(), image_size=args.image_size,
+                          network_capacity=16, fmap_max=512, batch_size=bs, gradient_accumulate_every=args.gae,
+                          lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1)
+    tr.steps = 1  # a non-GP step
+    t0 = time.time()
+    tr.train()
+    dt = time.time() - t0
+    return {"value": bs * args.gae / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 non-GP Trainer.train() of the CPU oracle at %dpx, batch %d, GAE %d (%.1f s); stand-in "
+                      "classifier/LPIPS" % (args.image_size, bs, args.gae, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--precision", default=os.environ.get("STYLEX_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per micro-batch")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--gae", type=int, default=2, help="gradient_accumulate_every (2 = noise + encoder micro-step)")
+    ap.add_argument("--classifier", default="resnet")
+    ap.add_argument("--workdir", default="/tmp/stylex_bench")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--roofline-steps", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda:%d" % local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import hip_backend as hb
+    import ops
+
+    hb.load_library()  # no fallback: fail loudly if the extension is missing
+    ops.set_precision(args.precision)
+    tr = build_trainer(args, device, rank, world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train()
+    tr.steps = 0  # the timed region starts on a GP step: 1 call in 4 carries the penalty
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    images = world * args.batch * args.gae * args.steps
+    value = images / dt
+
+    # ---- roofline of the dominant conv kernel class, hipEvent-timed on the launch stream
+    roof = None
+    if rank == 0 and args.roofline_steps > 0:
+        hb.timing_enable(1)
+        tr.steps = 0
+        for _ in range(args.roofline_steps):
+            tr.train()
+        torch.cuda.synchronize()
+        rep = hb.timing_report()
+        hb.timing_enable(0)
+        name, r = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {"bound": "mfma", "kernel": "conv_%s (implicit-GEMM MFMA)" % name, "achieved": round(ach, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(1, r["launches"]), 4),
+                "classes": {k: {"tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "ms": round(v["ms"], 2),
+                                "launches": v["launches"]} for k, v in rep.items()}}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        gf = algorithmic_gflop_per_image(args.gae)
+        line = {
+            "metric": "StylEx G+D+enc train-step images/sec @256px", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic (torch.rand 256x256 batches resident in HBM, random-init weights, seeded "
+                    "random-weight ResNet-18 classifier and LPIPS-AlexNet)",
+            "config": {"workload": "FFHQ 256x256 StylEx, batch 32/GPU, GAE=%d (noise+encoder micro-steps), GP every "
+                                   "4th step, ResNet-18 classifier" % args.gae,
+                       "image_size": args.image_size, "batch_per_gpu": args.batch,
+                       "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
+                       "parallelism": "dp%d" % world},
+            "algorithmic_conv_gflop_per_image": round(gf, 1),
+            "step_conv_tflops": round(gf * value / 1e3, 2),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
