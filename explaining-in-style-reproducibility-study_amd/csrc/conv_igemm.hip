@@ -39,13 +39,14 @@ namespace {
 
 constexpr int BK = 32;  // K-tile depth (fp32 elements)
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    // round-to-nearest-even; NaN stays NaN
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);  // v_cvt_pk_bf16_f32, round-to-nearest-even
+    return *reinterpret_cast<unsigned*>(&r);
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(pack_bf16(f, 0.f) & 0xffffu); }
 
 // ------------------------------------------------------------------------------------------
 // Row descriptor: which gathered source rows (pixels) a thread stages.
@@ -182,7 +183,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             for (int j = 0; j < RB; ++j) {
                 int n = n0 + r0 + 32 * j;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cok && n < p.N) v = *reinterpret_cast<const float4*>(p.w + ((long)n * T + tap) * p.Ck + c0);
+                if (cok && n < p.N) {
+                    long wo = ((long)n * T + tap) * p.Ck + c0;
+                    if (BF16) {  // weights are pre-packed bf16: 4 elements = 8 bytes, kept packed in rb[j].xy
+                        uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.w) + wo);
+                        v.x = __uint_as_float(h.x);
+                        v.y = __uint_as_float(h.y);
+                    } else {
+                        v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.w) + wo);
+                    }
+                }
                 rb[j] = v;
             }
         } else {
@@ -214,9 +224,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int k = kbase + e;
-                    v[e] = (k < KT && n < p.N) ? p.w[(long)n * KT + k] : 0.f;
+                    v[e] = 0.f;
+                    if (k < KT && n < p.N) {
+                        if (BF16)
+                            v[e] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p.w)[(long)n * KT + k] << 16);
+                        else
+                            v[e] = reinterpret_cast<const float*>(p.w)[(long)n * KT + k];
+                    }
                 }
-                rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+                if (BF16)  // same packed form as the vector path
+                    rb[j] = make_float4(__uint_as_float(pack_bf16(v[0], v[1])), __uint_as_float(pack_bf16(v[2], v[3])), 0.f, 0.f);
+                else
+                    rb[j] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     };
@@ -228,15 +247,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
                 uint2 v;
-                v.x = f2bf(ra[j].x) | ((unsigned)f2bf(ra[j].y) << 16);
-                v.y = f2bf(ra[j].z) | ((unsigned)f2bf(ra[j].w) << 16);
+                v.x = pack_bf16(ra[j].x, ra[j].y);
+                v.y = pack_bf16(ra[j].z, ra[j].w);
                 *reinterpret_cast<uint2*>(a + (r0 + 32 * j) * LDH + kq * 4) = v;
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 uint2 v;
-                v.x = f2bf(rb[j].x) | ((unsigned)f2bf(rb[j].y) << 16);
-                v.y = f2bf(rb[j].z) | ((unsigned)f2bf(rb[j].w) << 16);
+                v.x = __float_as_uint(rb[j].x);
+                v.y = __float_as_uint(rb[j].y);
                 *reinterpret_cast<uint2*>(b + (r0 + 32 * j) * LDH + kq * 4) = v;
             }
         } else {
@@ -595,14 +614,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
     }
 }
 
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int N,
+template <typename OUT>
+__device__ __forceinline__ OUT cvt_out(float v);
+template <>
+__device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ unsigned short cvt_out<unsigned short>(float v) { return f2bf(v); }
+
+template <typename OUT>
+__global__ void pack_weight_kernel(const float* __restrict__ w, OUT* __restrict__ wf, OUT* __restrict__ wb, int N,
                                    int C, int T) {
     long total = (long)N * C * T;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int t = (int)(i % T);
         int c = (int)((i / T) % C);
         int n = (int)(i / ((long)T * C));
-        float v = w[i];
+        OUT v = cvt_out<OUT>(w[i]);
         if (wf) wf[((long)n * T + t) * C + c] = v;
         if (wb) wb[((long)c * T + t) * N + n] = v;
     }
@@ -666,6 +693,10 @@ int stylex_launch_igemm(const ConvKParams& p, int precision, hipStream_t s) {
     bool vec = (p.Ck % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
                ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0) &&
                (!p.a_scale || (reinterpret_cast<uintptr_t>(p.a_scale) & 15) == 0);
+    if (precision == STYLEX_BF16 && !p.transposed) {
+        int rc = stylex_launch_halo(p, s);
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+    }
     if (precision == STYLEX_BF16) return vec ? dispatch_igemm<true, true>(p, s) : dispatch_igemm<false, true>(p, s);
     return vec ? dispatch_igemm<true, false>(p, s) : dispatch_igemm<false, false>(p, s);
 }
@@ -719,11 +750,15 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
     return (int)hipGetLastError();
 }
 
-int stylex_launch_pack(const float* w, float* wf, float* wb, int N, int C, int T, hipStream_t s) {
+int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, int dtype, hipStream_t s) {
     long total = (long)N * C * T;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, w, wf, wb, N, C, T);
+    if (dtype == STYLEX_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, w, (unsigned short*)wf,
+                           (unsigned short*)wb, N, C, T);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)wf, (float*)wb, N, C, T);
     return (int)hipGetLastError();
 }

@@ -31,13 +31,13 @@ struct ScopedTimer {
         if (!on) return;
         t.cls = cls;
         t.flops = flops;
-        hipEventCreate(&t.start);
-        hipEventCreate(&t.stop);
-        hipEventRecord(t.start, s);
+        (void)hipEventCreate(&t.start);
+        (void)hipEventCreate(&t.stop);
+        (void)hipEventRecord(t.start, s);
     }
     ~ScopedTimer() {
         if (!on) return;
-        hipEventRecord(t.stop, s);
+        (void)hipEventRecord(t.stop, s);
         std::lock_guard<std::mutex> lk(g_mu);
         g_pending.push_back(t);
     }
@@ -47,13 +47,13 @@ void drain_pending() {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& t : g_pending) {
         float ms = 0.f;
-        hipEventSynchronize(t.stop);
-        hipEventElapsedTime(&ms, t.start, t.stop);
+        (void)hipEventSynchronize(t.stop);
+        (void)hipEventElapsedTime(&ms, t.start, t.stop);
         g_launches[t.cls] += 1;
         g_ms[t.cls] += ms;
         g_flops[t.cls] += t.flops;
-        hipEventDestroy(t.start);
-        hipEventDestroy(t.stop);
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
     }
     g_pending.clear();
 }
@@ -115,12 +115,13 @@ int stylex_timing_report(int cls, int64_t* launches, double* total_ms, double* t
     return 0;
 }
 
-int stylex_pack_weight(const float* w, float* wf, float* wb, const int64_t* sh, void* stream) {
+int stylex_pack_weight(const float* w, void* wf, void* wb, const int64_t* sh, int precision, void* stream) {
     if (!w || sh[0] < 1 || sh[1] < 1 || sh[2] < 1 || sh[3] < 1) return STYLEX_EINVAL;
-    return stylex_launch_pack(w, wf, wb, (int)sh[0], (int)sh[1], (int)(sh[2] * sh[3]), (hipStream_t)stream);
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    return stylex_launch_pack(w, wf, wb, (int)sh[0], (int)sh[1], (int)(sh[2] * sh[3]), precision, (hipStream_t)stream);
 }
 
-int stylex_conv2d_fwd(const float* x, const float* w_fwd, float* y, const int64_t* sh, int flags,
+int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* sh, int flags,
                       const stylex_conv_epilogue* epi, int precision, void* stream) {
     if (!x || !w_fwd || !y || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
@@ -158,7 +159,7 @@ int stylex_conv2d_fwd(const float* x, const float* w_fwd, float* y, const int64_
     return stylex_launch_igemm(p, precision, (hipStream_t)stream);
 }
 
-int stylex_conv2d_bwd_data(const float* dy, const float* w_bwd, float* dx, const int64_t* sh, int flags,
+int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const int64_t* sh, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* stream) {
     if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
@@ -176,6 +177,27 @@ int stylex_conv2d_bwd_data(const float* dy, const float* w_bwd, float* dx, const
     p.Ho = (int)sh[1];
     p.Wo = (int)sh[2];
     p.M = p.B * p.Ho * p.Wo;
+    if (precision == STYLEX_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1) {
+        // dx = conv3x3(dy, flipped taps): forward-gather form, eligible for the LDS-halo kernel
+        ConvKParams q = p;
+        q.flip_taps = 1;
+        q.flags = flags;
+        if (epi) {
+            q.a_scale = epi->in_scale;
+            q.out_scale = epi->out_scale;
+        }
+        if (!((flags & STYLEX_EPI_OSCALE) && !q.out_scale)) {
+            double fl = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6];
+            ScopedTimer tmh(1, fl, (hipStream_t)stream);
+            int rc = stylex_launch_halo(q, (hipStream_t)stream);
+            if (rc != STYLEX_NOT_APPLICABLE) return rc;
+            if (tmh.on) {  // not applicable: nothing was launched; fall through to the generic kernel
+                (void)hipEventDestroy(tmh.t.start);
+                (void)hipEventDestroy(tmh.t.stop);
+                tmh.on = false;
+            }
+        }
+    }
     p.transposed = 1;
     p.phase_major = (p.stride == 2 && (p.Ho % 2 == 0) && (p.Wo % 2 == 0)) ? 1 : 0;
     p.flags = flags;

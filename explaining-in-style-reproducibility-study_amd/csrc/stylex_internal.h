@@ -10,7 +10,7 @@
 struct ConvKParams {
     const float* a;         // gathered activations
     const float* a_scale;   // [B][Ck] per-sample channel scale applied while staging (or null)
-    const float* w;         // packed weights [N][T][Ck]            (igemm)
+    const void* w;          // packed weights [N][T][Ck], fp32 (F32 mode) or bf16 (BF16 mode)
     const float* a2;        // second activation operand dy [M][N]   (wgrad)
     const float* a2_scale;  // [B][N]                                (wgrad)
     float* y;
@@ -25,6 +25,7 @@ struct ConvKParams {
     int B, Hi, Wi, Ck, N, KH, KW, Ho, Wo, stride, pad;
     int transposed;   // 0: forward gather  ih = oh*s + kh - p ; 1: data-gradient gather ih = (oh + p - kh)/s
     int phase_major;  // rows ordered by (oh&1, ow&1) first (transposed stride-2 only)
+    int flip_taps;    // halo kernel: read weight tap 8-t for compute tap t (data gradient of a 3x3/s1/p1 conv)
     int M;            // B*Ho*Wo
     int flags;
     long split_len;   // wgrad: pixels per split (multiple of 32)
@@ -33,4 +34,8 @@ struct ConvKParams {
 int stylex_launch_igemm(const ConvKParams& p, int precision, hipStream_t s);
 void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len);
 int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s);
-int stylex_launch_pack(const float* w, float* wf, float* wb, int N, int C, int T, hipStream_t s);
+int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, int dtype, hipStream_t s);
+
+#define STYLEX_NOT_APPLICABLE (-100)
+// 3x3/s1/p1 bf16 kernel with the input halo resident in LDS (conv_halo.hip)
+int stylex_launch_halo(const ConvKParams& p, hipStream_t s);

@@ -37,7 +37,7 @@ class ConvEpilogue(ctypes.Structure):
 SIGNATURES = {
     "stylex_init": (ctypes.c_int, [ctypes.c_int]),
     "stylex_version": (ctypes.c_char_p, []),
-    "stylex_pack_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_pack_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_conv2d_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.POINTER(ConvEpilogue),
                                          ctypes.c_int, ctypes.c_void_p]),
     "stylex_conv2d_bwd_data": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.POINTER(ConvEpilogue),
@@ -136,13 +136,18 @@ def empty_cl(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
 
 
-def pack_weight(w, want_fwd=True, want_bwd=False):
+def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
+    """OIHW fp32 parameter -> K-contiguous operand layouts, fp32 or bf16 according to `precision`."""
     lib = _ensure_device(w)
     w = w.contiguous()
+    if w.dtype != torch.float32:
+        w = w.float()
     n, c, kh, kw = w.shape
-    wf = torch.empty(n * kh * kw * c, dtype=torch.float32, device=w.device) if want_fwd else None
-    wb = torch.empty(n * kh * kw * c, dtype=torch.float32, device=w.device) if want_bwd else None
-    _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), _stream()), "stylex_pack_weight")
+    dt = torch.bfloat16 if precision == BF16 else torch.float32
+    wf = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_fwd else None
+    wb = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_bwd else None
+    _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
+           "stylex_pack_weight")
     return wf, wb
 
 
@@ -152,7 +157,7 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
     lib = _ensure_device(x)
     assert is_cl(x) and x.dtype == torch.float32
     sh = conv_shape(x.shape, w.shape, stride, pad)
-    wf, _ = pack_weight(w, True, False)
+    wf, _ = pack_weight(w, True, False, precision)
     y = empty_cl((sh[0], sh[4], sh[9], sh[10]), x)
     flags = 0
     epi = ConvEpilogue()
@@ -194,7 +199,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     assert is_cl(dy) and dy.dtype == torch.float32
     sh = conv_shape(x_shape, w.shape, stride, pad)
     assert tuple(dy.shape) == (sh[0], sh[4], sh[9], sh[10]), (dy.shape, sh)
-    _, wb = pack_weight(w, False, True)
+    _, wb = pack_weight(w, False, True, precision)
     dx = empty_cl(tuple(x_shape), dy)
     epi = ConvEpilogue()
     flags = 0

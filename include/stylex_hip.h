@@ -58,10 +58,12 @@ const char* stylex_version(void);
  * layouts the implicit-GEMM kernels read:
  *   w_fwd[n][t][c]  (t = kh*KW+kw)   — forward / "fprop" operand
  *   w_bwd[c][t][n]                   — data-gradient operand
- * Either output may be NULL.  shape = {N, C, KH, KW}.
+ * Either output may be NULL.  shape = {N, C, KH, KW}.  The packed element type follows `precision`:
+ * fp32 for STYLEX_F32, bf16 (RNE) for STYLEX_BF16 — the conv entry points expect the matching one.
  * Replaces: the implicit weight handling inside F.conv2d
  * (reference stylex/stylex_train.py:660 and nn.Conv2d at :724-736, :771, :881). */
-int stylex_pack_weight(const float* w_oihw, float* w_fwd, float* w_bwd, const int64_t* shape, void* stream);
+int stylex_pack_weight(const float* w_oihw, void* w_fwd, void* w_bwd, const int64_t* shape, int precision,
+                       void* stream);
 
 /* y[b,ho,wo,n] = epi( sum_{kh,kw,c} in_scale[b][c] * x[b,ho*s+kh-p,wo*s+kw-p,c] * w_fwd[n][kh*KW+kw][c] )
  * Replaces F.conv2d in Conv2DMod.forward (stylex_train.py:647-667, with the
@@ -82,7 +84,7 @@ typedef struct {
     float res_scale;
 } stylex_conv_epilogue;
 
-int stylex_conv2d_fwd(const float* x, const float* w_fwd, float* y, const int64_t* shape, int flags,
+int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* shape, int flags,
                       const stylex_conv_epilogue* epi, int precision, void* stream);
 
 /* dx[b,hi,wi,c] = sum_{kh,kw,n} dy[b,(hi+p-kh)/s,(wi+p-kw)/s,n] * w_bwd[c][t][n]   (exact division only)
@@ -92,7 +94,7 @@ int stylex_conv2d_fwd(const float* x, const float* w_fwd, float* y, const int64_
 /* Modulated form: epi->in_scale [B][N] scales dy while it is staged (demodulation
  * coefficient) and, with STYLEX_EPI_OSCALE, epi->out_scale [B][C] scales dx
  * (style+1).  flags may only contain STYLEX_EPI_OSCALE; epi may be NULL. */
-int stylex_conv2d_bwd_data(const float* dy, const float* w_bwd, float* dx, const int64_t* shape, int flags,
+int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const int64_t* shape, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* stream);
 
 /* dw[n][c][kh][kw] (OIHW, fp32) = sum_{b,ho,wo} dy[b,ho,wo,n] * x[b,ho*s+kh-p,wo*s+kw-p,c]

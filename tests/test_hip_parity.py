@@ -61,6 +61,10 @@ CONV_CASES = [
     (5, 20, 36, 6, 6, 3, 2, 1),
     (2, 512, 512, 4, 4, 3, 1, 1),
     (1, 64, 64, 64, 64, 3, 1, 1),     # many M tiles
+    (2, 64, 64, 32, 32, 3, 1, 1),     # bf16: LDS-halo kernel, 8x32 tiles
+    (2, 32, 32, 16, 16, 3, 1, 1),     # bf16: LDS-halo kernel, 16x16 tiles, N=32 variant
+    (1, 40, 96, 40, 48, 3, 1, 1),     # halo kernel with partial tiles and a ragged channel chunk
+    (3, 128, 24, 24, 40, 3, 1, 1),    # halo kernel: N < tile, H not a multiple of the tile
 ]
 
 
@@ -84,6 +88,41 @@ def test_conv_triad_vs_oracle(case, prec):
     close(y_ref, y, tol, "fwd")
     close(xr.grad, xd.grad, tol, "dgrad")
     close(wr.grad, wd.grad, tol, "wgrad")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 8, 8), (2, 64, 64, 32, 32), (2, 32, 32, 16, 32)])
+def test_fused_conv_epilogue_and_scales(shape, prec):
+    """The fused forms of the C-ABI (modulation in_scale, demod out_scale, bias, transposed noise,
+    residual merge, lrelu) and the scaled data/weight gradients against plain torch."""
+    B, C, N, H, W = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(N, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    s_in = torch.rand(B, C, generator=g) + 0.5
+    s_out = torch.rand(B, N, generator=g) + 0.5
+    bias, nw, nb = (torch.randn(N, generator=g) for _ in range(3))
+    S = max(H, W)
+    inoise = torch.rand(B, S, S, generator=g)
+    res = torch.randn(B, N, H, W, generator=g)
+    P = hb.BF16 if prec == "bf16" else hb.F32
+    tol = TOL32 if prec == "fp32" else TOLBF
+    ref = F.conv2d(x * s_in[:, :, None, None], w, None, 1, 1) * s_out[:, :, None, None] + bias.view(1, -1, 1, 1)
+    ref = ref + inoise[:, :W, :H].transpose(1, 2)[:, None] * nw.view(1, -1, 1, 1) + nb.view(1, -1, 1, 1)
+    ref = F.leaky_relu((ref + res) * 0.5, 0.2)
+    d = lambda t: t.to(DEV)
+    y = hb.conv2d_fwd(cl(x), d(w), 1, 1, P, bias=d(bias), lrelu=True, in_scale=d(s_in), out_scale=d(s_out),
+                      noise=d(inoise), noise_w=d(nw), noise_b=d(nb), residual=cl(res), res_scale=0.5)
+    close(ref, y, tol, "fused fwd")
+    dy = torch.randn(B, N, H, W, generator=g)
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    z = F.conv2d(xr * s_in[:, :, None, None], wr, None, 1, 1) * s_out[:, :, None, None]
+    (z * dy).sum().backward()
+    dx = hb.conv2d_bwd_data(cl(dy), d(w), tuple(x.shape), 1, 1, P, in_scale=d(s_out), out_scale=d(s_in))
+    close(xr.grad, dx, tol, "scaled dgrad")
+    dw = hb.conv2d_bwd_weight(cl(x), cl(dy), tuple(w.shape), 1, 1, P, x_scale=d(s_in), dy_scale=d(s_out))
+    close(wr.grad, dw, tol, "scaled wgrad")
 
 
 def test_conv_bias_lrelu_and_second_order():
