@@ -721,6 +721,16 @@ void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long
 }
 
 int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s) {
+    if (precision == STYLEX_BF16 && stylex_wgrad_halo_applicable(p)) {
+        int hs = 0;
+        int rc = stylex_launch_wgrad_halo(p, partial, s, &hs);
+        if (rc) return rc;
+        long total = (long)p.N * p.Ck * 9;
+        int rb = (int)((total + 255) / 256);
+        if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, 9, hs);
+        return (int)hipGetLastError();
+    }
     int tn, tc, splits;
     long split_len;
     stylex_wgrad_plan(p, &tn, &tc, &splits, &split_len);

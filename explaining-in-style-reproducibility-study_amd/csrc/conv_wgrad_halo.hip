@@ -1,0 +1,206 @@
+// conv_wgrad_halo.hip — weight gradient of a 3x3 / stride-1 / pad-1 convolution on gfx950 (bf16 MFMA,
+// fp32 accumulate), with the activation tile + halo and the dy tile resident in LDS.
+//
+//   dW[n][tap][c] = sum_{b,y,x} dy[b,y,x,n] * xin[b,y+kh-1,x+kw-1,c]
+//
+// GEMM view: D[i=n][j=c] += A[n][k=pixel] * B[k=pixel][c].  Both operands are stored pixel-major in
+// memory (NHWC), i.e. k is the SLOW axis, while an MFMA lane needs 8 consecutive k of one row.  The
+// transpose is done by the LDS transpose-read ds_read_b64_tr_b16: within a 16-lane group, lane i
+// supplies the address of 4 contiguous bf16; lane l receives element (l&3) of rows 4j+(l>>2), j=0..3
+// (measured with tools/probes/tr_probe.hip).  Giving lane i the address [pixel (i>>2)][channel 4*(i&3)]
+// returns to lane l the 4 consecutive pixels of channel l — and a 3x3 tap shift is just a different
+// starting ROW, so all 9 taps read the same resident halo with no realignment.
+//
+// A block owns a 64(n) x 64(c) x 9-tap accumulator (144 fp32 registers per lane, 4 waves as 2x2 of
+// 32x32) and walks a contiguous range of 8x32-pixel tiles (split-K over tiles); per tile it stages
+// dy [256 px][64 n] and the x halo [340 px][64 c] as bf16 (fp32 -> bf16 on the way, per-sample
+// modulation/demodulation scales folded in), in 32-channel panels of unpadded 64-byte pixel rows:
+// a 32-lane tr-read then covers 4 rows x 64 B = all 64 banks exactly once (conflict free), and the
+// 8-byte staging stores are conflict free as well.  Partials go to workspace[split][n][tap][c] and
+// are reduced in fixed order by wgrad_reduce_kernel (deterministic).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stylex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<unsigned*>(&r);
+}
+
+typedef __attribute__((address_space(3))) s16x4* lds_s4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* smem_base, int byte_off, int row_pitch_bytes) {
+    // two transpose reads: pixels k..k+3 and k+4..k+7 of this lane's channel
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(smem_base + byte_off));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(smem_base + byte_off + 4 * row_pitch_bytes));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+constexpr int TW = 32, TH = 8, HWD = TW + 2, NP = (TH + 2) * HWD;  // 8x32 pixel tile, 10x34 halo
+constexpr int PIX_ROW = 64;                                          // bytes per pixel row of a 32-channel panel
+// panel strides carry a 64-byte skew so that the two panels a 16-lane staging store touches fall on
+// different bank halves
+constexpr int DY_PANEL = 256 * PIX_ROW + 64;                         // 16 KiB (+skew)
+constexpr int X_PANEL = NP * PIX_ROW + 64;                           // 21.25 KiB (+skew)
+constexpr int X_OFF = 2 * DY_PANEL;
+constexpr int SMEM_BYTES = 2 * DY_PANEL + 2 * X_PANEL;               // 75.5 KiB -> 2 blocks / CU
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int H = p.Ho, W = p.Wo, C = p.Ck, N = p.N;
+    const int n_tiles = (N + 63) / 64, c_tiles = (C + 63) / 64;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total_tiles = p.B * tiles_img;
+
+    int bid = blockIdx.x;
+    const int ot = bid % (n_tiles * c_tiles);   // output tile (fastest: blocks sharing pixel tiles run together)
+    const int split = bid / (n_tiles * c_tiles);
+    const int n0 = (ot / c_tiles) * 64, c0 = (ot % c_tiles) * 64;
+    const int t_begin = split * (int)p.split_len;
+    const int t_end = min(total_tiles, t_begin + (int)p.split_len);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // tr-read lane addressing (see header): group g = lane>>4 -> channel block (g&1)*16, k half (g>>1)*8
+    const int i16 = lane & 15, g = lane >> 4;
+    const int lane_off = ((g >> 1) * 8 + (i16 >> 2)) * PIX_ROW + ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int b = tile / tiles_img;
+        const int tt = tile - b * tiles_img;
+        const int y0 = (tt / tiles_x) * TH, x0 = (tt % tiles_x) * TW;
+
+        // ---- stage dy tile: 256 px x 64 n (16 float4 per pixel), 16 float4 per thread
+        {
+            const int q = tid & 15;  // float4 index within the 64 channels
+            const int nn = n0 + q * 4;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.a2_scale && nn < N) sc = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                int px = (tid >> 4) + 16 * it;
+                int y = y0 + px / TW, x = x0 + (px % TW);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nn < N && y < H && x < W) v = *reinterpret_cast<const float4*>(p.a2 + ((long)(b * H + y) * W + x) * N + nn);
+                uint2 h;
+                h.x = pack_bf16(v.x * sc.x, v.y * sc.y);
+                h.y = pack_bf16(v.z * sc.z, v.w * sc.w);
+                *reinterpret_cast<uint2*>(smem + (q >> 3) * DY_PANEL + px * PIX_ROW + (q & 7) * 8) = h;
+            }
+        }
+        // ---- stage x halo: 340 px x 64 c
+        {
+            const int q = tid & 15;
+            const int cc = c0 + q * 4;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.a_scale && cc < C) sc = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+#pragma unroll 4
+            for (int it = 0; it < (NP + 15) / 16; ++it) {
+                int hp = (tid >> 4) + 16 * it;
+                if (hp < NP) {
+                    int hh = hp / HWD, ww = hp - hh * HWD;
+                    int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cc < C && y >= 0 && y < H && x >= 0 && x < W)
+                        v = *reinterpret_cast<const float4*>(p.a + ((long)(b * H + y) * W + x) * C + cc);
+                    uint2 h;
+                    h.x = pack_bf16(v.x * sc.x, v.y * sc.y);
+                    h.y = pack_bf16(v.z * sc.z, v.w * sc.w);
+                    *reinterpret_cast<uint2*>(smem + X_OFF + (q >> 3) * X_PANEL + hp * PIX_ROW + (q & 7) * 8) = h;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 16 k-steps of 16 pixels (half a tile row each); 9 taps share the A operand
+        const char* a_base = smem + wn * DY_PANEL + lane_off;
+        const char* b_base = smem + X_OFF + wc * X_PANEL + lane_off;
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int r = ks >> 1, pw0 = (ks & 1) * 16;
+            bf16x8 av = tr_read8(a_base, (r * TW + pw0) * PIX_ROW, PIX_ROW);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t - kh * 3;
+                bf16x8 bv = tr_read8(b_base, ((r + kh) * HWD + pw0 + kw) * PIX_ROW, PIX_ROW);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- partial[split][n][tap][c]; D[i=n][j=c]: col j = lane&31, row i = (r&3)+8*(r>>2)+4*(lane>>5)
+    const int lj = lane & 31, lh = lane >> 5;
+    float* out = p.y + (long)split * N * 9 * C;
+    const int c = c0 + wc * 32 + lj;
+    if (c < C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n < N) out[((long)n * 9 + t) * C + c] = acc[t][r];
+            }
+    }
+}
+
+}  // namespace
+
+bool stylex_wgrad_halo_applicable(const ConvKParams& p) {
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
+    if (p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    if (p.Ck % 4 != 0 || p.N % 4 != 0 || p.Wo < 32 || p.Ho < 8) return false;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.a2) & 15)) return false;
+    if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return false;
+    if (p.a2_scale && (reinterpret_cast<uintptr_t>(p.a2_scale) & 15)) return false;
+    return true;
+}
+
+void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split) {
+    long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    long otiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64);
+    long want = (512 + otiles - 1) / otiles;  // ~2 resident blocks per CU
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    long tps = (tiles + want - 1) / want;
+    *tiles_per_split = (int)tps;
+    *splits = (int)((tiles + tps - 1) / tps);
+}
+
+int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out) {
+    int splits, tps;
+    stylex_wgrad_halo_plan(p, &splits, &tps);
+    p.split_len = tps;
+    p.y = partial;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_halo_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    int blocks = ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * splits;
+    hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3(blocks), dim3(256), SMEM_BYTES, s, p);
+    *splits_out = splits;
+    return (int)hipGetLastError();
+}

@@ -230,6 +230,11 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
     int tn, tc, splits;
     long len;
     stylex_wgrad_plan(p, &tn, &tc, &splits, &len);
+    if (p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Wo >= 32 && p.Ho >= 8) {  // halo plan may use more splits
+        int hs, tps;
+        stylex_wgrad_halo_plan(p, &hs, &tps);
+        if (hs > splits) splits = hs;
+    }
     return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float);
 }
 

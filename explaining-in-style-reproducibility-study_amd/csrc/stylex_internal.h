@@ -39,3 +39,8 @@ int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, 
 #define STYLEX_NOT_APPLICABLE (-100)
 // 3x3/s1/p1 bf16 kernel with the input halo resident in LDS (conv_halo.hip)
 int stylex_launch_halo(const ConvKParams& p, hipStream_t s);
+
+// 3x3/s1/p1 bf16 weight gradient with resident halo + LDS transpose reads (conv_wgrad_halo.hip)
+bool stylex_wgrad_halo_applicable(const ConvKParams& p);
+void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);
+int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out);
