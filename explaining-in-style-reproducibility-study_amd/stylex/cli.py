@@ -1,0 +1,191 @@
+"""Command-line entry point — drop-in for the reference's ``stylex/cli.py``
+(``train_from_folder`` :84-250, ``run_training`` :43-81, ``main`` :253-254).
+
+Same flag names and defaults (``python cli.py --data <folder> --image_size 64 ...``).  ``fire`` and
+``retry`` are not installable offline, so the 1:1 flag mapping and the NaN retry loop are done here.
+Multi-GPU: one process per GPU over RCCL.  Either launch with
+``python -m torch.distributed.run --nproc-per-node N cli.py --multi_gpus ...`` (RANK/WORLD_SIZE in the
+environment) or let ``--multi_gpus`` spawn one process per visible device like the reference did.
+"""
+import ast
+import os
+import random
+import sys
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stylex_train import NanException, Trainer
+
+# flag -> default, in the reference's order (cli.py:84-171)
+DEFAULTS = dict(
+    data="../data/Kaggle_FFHQ_Resized_256px/flickrfaceshq-dataset-nvidia-resized-256px/resized",
+    results_dir="./results", models_dir="./models", name="Faces-Resnet-64", new=False, load_from=-1, image_size=64,
+    network_capacity=16, fmap_max=512, transparent=False, batch_size=4, gradient_accumulate_every=8,
+    num_train_steps=150000, learning_rate=2e-4, lr_mlp=0.1, ttur_mult=1.5, rel_disc_loss=False, num_workers=3,
+    save_every=500, evaluate_every=50, generate=False, num_generate=1, generate_interpolation=False,
+    interpolation_num_steps=100, save_frames=False, num_image_tiles=8, trunc_psi=0.75, mixed_prob=0.9, fp16=False,
+    no_pl_reg=False, cl_reg=False, fq_layers=[], fq_dict_size=256, attn_layers=[], no_const=False, aug_prob=0.,
+    aug_types=["translation", "cutout"], top_k_training=False, generator_top_k_gamma=0.99, generator_top_k_frac=0.5,
+    dual_contrast_loss=False, dataset_aug_prob=0., multi_gpus=False, calculate_fid_every=None,
+    calculate_fid_num_images=12800, clear_fid_cache=False, seed=42, log=False, kl_scaling=1, rec_scaling=1,
+    classifier_name="resnet", classifier_path="mobilenet-64px-gender.pth", num_classes=2, encoder_class=None,
+    kl_rec_during_disc=False, sample_from_encoder=True, alternating_training=True, dataset_name=None,
+    tensorboard_dir="tb_logs_stylex",
+    # MI355X additions
+    precision="fp32",
+)
+
+# train_from_folder kwarg -> Trainer kwarg, where the names differ
+_RENAMED = {"learning_rate": "lr"}
+_NOT_FOR_TRAINER = {"data", "new", "load_from", "num_train_steps", "generate", "num_generate", "generate_interpolation",
+                    "interpolation_num_steps", "save_frames", "multi_gpus", "seed", "precision"}
+
+
+def cast_list(el):
+    return el if isinstance(el, list) else [el]
+
+
+def timestamped_filename(prefix="generated-"):
+    return prefix + datetime.now().strftime("%m-%d-%Y_%H-%M-%S")
+
+
+def set_seed(seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def retry_call(fn, tries=3, exceptions=NanException):
+    for attempt in range(tries):
+        try:
+            return fn()
+        except exceptions:
+            if attempt == tries - 1:
+                raise
+
+
+def run_training(rank, world_size, model_args, data, load_from, new, num_train_steps, name, seed, dataset_name=None,
+                 precision="fp32", spawned=True):
+    is_main = rank == 0
+    is_ddp = world_size > 1
+    if is_ddp:
+        set_seed(seed)
+        if spawned:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "12355")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        if torch.cuda.is_available():
+            torch.cuda.set_device(rank % torch.cuda.device_count())
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
+        print(f"{rank + 1}/{world_size} process initialized.")
+    import ops
+
+    ops.set_precision(precision)
+    model_args = dict(model_args, is_ddp=is_ddp, rank=rank, world_size=world_size)
+    model = Trainer(**model_args)
+    if not new:
+        model.load(load_from)
+    else:
+        model.clear()
+    model.set_data_src(data, dataset_name=dataset_name)
+    try:
+        from tqdm import tqdm
+
+        bar = tqdm(initial=model.steps, total=num_train_steps, mininterval=10., desc=f"{name}<{data}>")
+    except Exception:
+        bar = None
+    while model.steps < num_train_steps:
+        retry_call(model.train, tries=3, exceptions=NanException)
+        if bar is not None:
+            bar.n = model.steps
+            bar.refresh()
+        if is_main and model.steps % 50 == 0:
+            model.print_log()
+    model.save(model.checkpoint_num)
+    if is_ddp:
+        dist.destroy_process_group()
+
+
+def train_from_folder(**overrides):
+    unknown = set(overrides) - set(DEFAULTS)
+    if unknown:
+        raise TypeError("unknown arguments: %s" % ", ".join(sorted(unknown)))
+    a = dict(DEFAULTS, **overrides)
+    model_args = {}
+    for k, v in a.items():
+        if k in _NOT_FOR_TRAINER:
+            continue
+        model_args[_RENAMED.get(k, k)] = v
+    model_args["aug_types"] = cast_list(a["aug_types"])
+
+    if a["generate"]:
+        model = Trainer(**model_args)
+        model.load(a["load_from"])
+        samples_name = timestamped_filename()
+        for num in range(a["num_generate"]):
+            model.evaluate(encoder_input=a["sample_from_encoder"], num=f"{samples_name}-{num}")
+        print(f"sample images generated at {a['results_dir']}/{a['name']}/{samples_name}")
+        return
+    if a["generate_interpolation"]:
+        model = Trainer(**model_args)
+        model.load(a["load_from"])
+        samples_name = timestamped_filename()
+        model.generate_interpolation(samples_name, a["num_image_tiles"], num_steps=a["interpolation_num_steps"],
+                                     save_frames=a["save_frames"])
+        print(f"interpolation generated at {a['results_dir']}/{a['name']}/{samples_name}")
+        return
+
+    common = (model_args, a["data"], a["load_from"], a["new"], a["num_train_steps"], a["name"], a["seed"],
+              a["dataset_name"], a["precision"])
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world > 1:  # launched by torch.distributed.run: one process per GPU already exists
+        run_training(int(os.environ["RANK"]), env_world, *common, spawned=False)
+        return
+    world_size = torch.cuda.device_count()
+    if world_size <= 1 or not a["multi_gpus"]:
+        run_training(0, 1, *common)
+        return
+    mp.spawn(run_training, args=(world_size,) + common, nprocs=world_size, join=True)
+
+
+def _parse_value(text):
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def parse_flags(argv):
+    """`--flag value`, `--flag=value`, bare `--flag` (True) and `--noflag` (False), like python-fire."""
+    out, i = {}, 0
+    while i < len(argv):
+        tok = argv[i]
+        if not tok.startswith("--"):
+            raise SystemExit("unexpected argument %r" % tok)
+        key = tok[2:].replace("-", "_")
+        if "=" in key:
+            key, val = key.split("=", 1)
+            out[key] = _parse_value(val)
+            i += 1
+        elif i + 1 < len(argv) and not argv[i + 1].startswith("--"):
+            out[key] = _parse_value(argv[i + 1])
+            i += 2
+        elif key.startswith("no") and key[2:] in DEFAULTS and key not in DEFAULTS:
+            out[key[2:]] = False
+            i += 1
+        else:
+            out[key] = True
+            i += 1
+    return out
+
+
+def main():
+    train_from_folder(**parse_flags(sys.argv[1:]))
+
+
+if __name__ == "__main__":
+    main()

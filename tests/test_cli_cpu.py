@@ -1,0 +1,55 @@
+"""Config 1 plumbing (BASELINE.json configs[0]): the drop-in cli.py entry point end to end on CPU —
+image folder -> Dataset/DataLoader -> Trainer.train() -> evaluate PNG grids -> checkpoint + config.
+Ops run on the CPU test double (no GPU here)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cli
+import ops
+from cpu_ops import CpuOracleOps
+
+
+@pytest.fixture(autouse=True)
+def cpu_double():
+    prev = ops.use_impl(CpuOracleOps)
+    yield
+    ops.use_impl(prev)
+
+
+def test_flag_parsing_matches_fire_conventions():
+    f = cli.parse_flags(["--data", "x/y", "--image_size", "128", "--new", "--aug_types", "[cutout]", "--lr_mlp=0.05",
+                         "--nosample_from_encoder", "--name", "run1", "--fmap_max", "64"])
+    assert f == {"data": "x/y", "image_size": 128, "new": True, "aug_types": "[cutout]", "lr_mlp": 0.05,
+                 "sample_from_encoder": False, "name": "run1", "fmap_max": 64}
+    with pytest.raises(TypeError):
+        cli.train_from_folder(not_a_flag=1)
+    # the reference's defaults (cli.py:84-171)
+    d = cli.DEFAULTS
+    assert (d["image_size"], d["batch_size"], d["gradient_accumulate_every"], d["ttur_mult"], d["trunc_psi"],
+            d["rec_scaling"], d["classifier_name"], d["seed"]) == (64, 4, 8, 1.5, 0.75, 1, "resnet", 42)
+
+
+def test_train_from_folder_cpu(tmp_path):
+    from PIL import Image
+
+    data = tmp_path / "imgs"
+    data.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(6):
+        Image.fromarray(rng.randint(0, 255, (40, 48, 3), dtype=np.uint8)).save(data / f"{i}.png")
+    cli.train_from_folder(data=str(data), results_dir=str(tmp_path / "results"), models_dir=str(tmp_path / "models"),
+                          name="t", new=True, image_size=32, network_capacity=4, fmap_max=64, batch_size=2,
+                          gradient_accumulate_every=2, num_train_steps=1, num_workers=0, save_every=1,
+                          evaluate_every=1, tensorboard_dir=None, classifier_path=None)
+    assert (tmp_path / "models" / "t" / "model_0.pt").exists()
+    cfg = json.loads((tmp_path / "models" / "t" / ".config.json").read_text())
+    assert cfg["image_size"] == 32 and cfg["network_capacity"] == 4
+    pngs = sorted(os.listdir(tmp_path / "results" / "t"))
+    assert pngs == ["0-from_encoder-ema.png", "0-from_encoder-mr.png", "0-from_encoder.png"]
+    ck = torch.load(tmp_path / "models" / "t" / "model_1.pt") if (tmp_path / "models" / "t" / "model_1.pt").exists() \
+        else torch.load(tmp_path / "models" / "t" / "model_0.pt")
+    assert ck["version"] == "1.8.7"

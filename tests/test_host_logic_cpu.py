@@ -15,7 +15,7 @@ from cpu_ops import CpuOracleOps
 from lpips_standin import LPIPSStandIn
 from ref_shim import TinyClassifier
 from conftest import load_golden
-from test_oracle_vs_golden import close, close_stats, stats, build_nets_model
+from test_oracle_vs_golden import assert_same_stats, close, close_stats, stats, build_nets_model
 
 
 @pytest.fixture(autouse=True)
@@ -35,7 +35,7 @@ def test_init_parity_product(size):
     assert list(sd.keys()) == [str(k) for k in g["keys"]]
     for i, (k, v) in enumerate(sd.items()):
         assert ",".join(map(str, v.shape)) == str(g["shapes"][i]), k
-        np.testing.assert_array_equal(g["stats"][i], stats(v), err_msg=k)
+        assert_same_stats(g["stats"][i], stats(v), k)
 
 
 @pytest.mark.parametrize("size", [16, 32])

@@ -31,6 +31,12 @@ def stats(t):
     return np.concatenate([[t.sum().item(), t.abs().sum().item()], head, np.zeros(max(0, 8 - t.numel()))])
 
 
+def assert_same_stats(gold, got, name=""):
+    """Head values bit-identical; the float64 sums may differ in the last bits with the thread count."""
+    np.testing.assert_array_equal(gold[2:], got[2:], err_msg=name)
+    np.testing.assert_allclose(gold[:2], got[:2], rtol=1e-12, err_msg=name)
+
+
 def close_stats(gold, t, tol=1e-4, head_atol=None):
     s = stats(t)
     scale = max(1.0, abs(gold[1]))
@@ -50,7 +56,7 @@ def test_init_parity(size):
     assert list(sd.keys()) == [str(k) for k in g["keys"]]
     for i, (k, v) in enumerate(sd.items()):
         assert ",".join(map(str, v.shape)) == str(g["shapes"][i]), k
-        np.testing.assert_array_equal(g["stats"][i], stats(v), err_msg=k)  # same RNG stream => bit-identical
+        assert_same_stats(g["stats"][i], stats(v), k)  # same RNG stream => bit-identical values
         if "full/" + k in g.files:
             np.testing.assert_array_equal(g["full/" + k], v.numpy(), err_msg=k)
 
@@ -228,4 +234,6 @@ def test_step_parity(tag):
     np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
     params = dict(tr.model.named_parameters())
     for n, gs in zip(g["param_names"], g["param_stats"]):
-        close_stats(gs, params[str(n)], 2e-3)
+        # after N Adam steps an element may differ by a fraction of lr (2e-4) when the summation order
+        # (thread count) differs
+        close_stats(gs, params[str(n)], 2e-3, head_atol=1e-4)
