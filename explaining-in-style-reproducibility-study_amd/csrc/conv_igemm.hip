@@ -327,20 +327,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     };
 
     // ---- main loop over the non-skipped K-tiles, double buffered
-    int kt = 0;
-    while (kt < nk && tile_skipped(kt)) ++kt;
+    // split-K: blockIdx.y selects a contiguous slice of K-tiles; partial sums go to p.partial
+    const int kslice = blockIdx.y;
+    int kt = kslice * p.kt_per_split;
+    const int kt_end = p.ksplit > 1 ? min(nk, kt + p.kt_per_split) : nk;
+    while (kt < kt_end && tile_skipped(kt)) ++kt;
     int st = 0;
-    if (kt < nk) {
+    if (kt < kt_end) {
         load_tile(kt);
         store_tile(0);
     }
     __syncthreads();
-    while (kt < nk) {
+    while (kt < kt_end) {
         int nxt = kt + 1;
-        while (nxt < nk && tile_skipped(nxt)) ++nxt;
-        if (nxt < nk) load_tile(nxt);
+        while (nxt < kt_end && tile_skipped(nxt)) ++nxt;
+        if (nxt < kt_end) load_tile(nxt);
         compute(st);
-        if (nxt < nk) store_tile(st ^ 1);
+        if (nxt < kt_end) store_tile(st ^ 1);
         __syncthreads();
         st ^= 1;
         kt = nxt;
@@ -367,6 +370,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 RowPix rp = decode_row(p, m);
                 long o = ((long)(rp.b * p.Ho + rp.oh) * p.Wo + rp.ow) * p.N + n;
                 float v = acc[i][j][r];
+                if (p.ksplit > 1) {  // raw slice sum; the epilogue runs in splitk_epilogue_kernel
+                    p.partial[(long)kslice * p.M * p.N + o] = v;
+                    continue;
+                }
                 if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)rp.b * p.N + n];
                 if (p.flags & STYLEX_EPI_BIAS) v += bias;
                 if (p.flags & STYLEX_EPI_NOISE)
@@ -635,6 +642,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, OUT* __restrict_
     }
 }
 
+// y[o] = epilogue( sum_s partial[s][o] )   (fixed order => deterministic), o = ((b*Ho+oh)*Wo+ow)*N + n
+__global__ void splitk_epilogue_kernel(ConvKParams p) {
+    const long total = (long)p.M * p.N;
+    for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.partial[(long)s * total + o];
+        int n = (int)(o % p.N);
+        long pix = o / p.N;
+        int hw = p.Ho * p.Wo;
+        int b = (int)(pix / hw);
+        int q = (int)(pix - (long)b * hw);
+        int oh = q / p.Wo, ow = q - oh * p.Wo;
+        if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)b * p.N + n];
+        if (p.flags & STYLEX_EPI_BIAS) v += p.bias[n];
+        if (p.flags & STYLEX_EPI_NOISE)
+            v += p.noise[((long)b * p.noise_stride + ow) * p.noise_stride + oh] * p.noise_w[n] + p.noise_b[n];
+        if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + p.residual[o]) * p.res_scale;
+        if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
+        p.y[o] = v;
+    }
+}
+
 template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
 constexpr size_t igemm_smem() {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -658,7 +687,7 @@ int launch_igemm(const ConvKParams& p, hipStream_t s) {
         attr_done = true;
     }
     long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), sm, s, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), dim3(256), sm, s, p);
     return (int)hipGetLastError();
 }
 
@@ -689,16 +718,73 @@ int launch_wgrad(const ConvKParams& p, int blocks, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // host-side entry points used by stylex_capi.hip
 // ------------------------------------------------------------------------------------------
-int stylex_launch_igemm(const ConvKParams& p, int precision, hipStream_t s) {
-    bool vec = (p.Ck % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
-               ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0) &&
-               (!p.a_scale || (reinterpret_cast<uintptr_t>(p.a_scale) & 15) == 0);
+// tile geometry chosen by dispatch_igemm (must stay in sync with it)
+static void igemm_tile(const ConvKParams& p, int* bm, int* bn) {
+    if (p.N > 64) { *bm = 128; *bn = 128; }
+    else if (p.N > 32) { *bm = 256; *bn = 64; }
+    else { *bm = 256; *bn = 32; }
+}
+
+// split-K plan for launches that cannot fill the chip: few output tiles and a long K loop
+static void igemm_splitk_plan(const ConvKParams& p, bool vec, int* ksplit, int* kt_per) {
+    int bm, bn;
+    igemm_tile(p, &bm, &bn);
+    long blocks = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    int T = p.KH * p.KW;
+    int nk = vec ? T * ((p.Ck + BK - 1) / BK) : (T * p.Ck + BK - 1) / BK;
+    *ksplit = 1;
+    *kt_per = nk;
+    if (blocks >= 192 || nk < 16) return;
+    long want = (512 + blocks - 1) / blocks;
+    long maxs = nk / 4;  // at least 4 K-tiles per slice
+    if (want > maxs) want = maxs;
+    if (want > 36) want = 36;
+    if (want < 2) return;
+    int per = (int)((nk + want - 1) / want);
+    *kt_per = per;
+    *ksplit = (nk + per - 1) / per;
+}
+
+static bool igemm_vec_ok(const ConvKParams& p) {
+    return (p.Ck % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.a) & 15) == 0) &&
+           ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0) &&
+           (!p.a_scale || (reinterpret_cast<uintptr_t>(p.a_scale) & 15) == 0);
+}
+
+int64_t stylex_igemm_workspace_bytes(const ConvKParams& p, int precision) {
+    (void)precision;
+    int ks, per;
+    igemm_splitk_plan(p, p.Ck % 4 == 0, &ks, &per);
+    return ks > 1 ? (int64_t)ks * p.M * p.N * (int64_t)sizeof(float) : 0;
+}
+
+int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    bool vec = igemm_vec_ok(p);
     if (precision == STYLEX_BF16 && !p.transposed) {
         int rc = stylex_launch_halo(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
-    if (precision == STYLEX_BF16) return vec ? dispatch_igemm<true, true>(p, s) : dispatch_igemm<false, true>(p, s);
-    return vec ? dispatch_igemm<true, false>(p, s) : dispatch_igemm<false, false>(p, s);
+    p.ksplit = 1;
+    p.kt_per_split = 0;
+    p.partial = nullptr;
+    if (workspace) {
+        int ks, per;
+        igemm_splitk_plan(p, vec, &ks, &per);
+        if (ks > 1 && workspace_bytes >= (int64_t)ks * p.M * p.N * (int64_t)sizeof(float)) {
+            p.ksplit = ks;
+            p.kt_per_split = per;
+            p.partial = (float*)workspace;
+        }
+    }
+    int rc;
+    if (precision == STYLEX_BF16) rc = vec ? dispatch_igemm<true, true>(p, s) : dispatch_igemm<false, true>(p, s);
+    else rc = vec ? dispatch_igemm<true, false>(p, s) : dispatch_igemm<false, false>(p, s);
+    if (rc || p.ksplit <= 1) return rc;
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
 }
 
 void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len) {

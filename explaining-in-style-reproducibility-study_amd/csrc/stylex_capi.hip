@@ -121,15 +121,8 @@ int stylex_pack_weight(const float* w, void* wf, void* wb, const int64_t* sh, in
     return stylex_launch_pack(w, wf, wb, (int)sh[0], (int)sh[1], (int)(sh[2] * sh[3]), precision, (hipStream_t)stream);
 }
 
-int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* sh, int flags,
-                      const stylex_conv_epilogue* epi, int precision, void* stream) {
-    if (!x || !w_fwd || !y || !conv_shape_ok(sh)) return STYLEX_EINVAL;
-    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
-    ConvKParams p;
+static void fwd_params(ConvKParams& p, const int64_t* sh) {
     fill_common(p, sh);
-    p.a = x;
-    p.w = w_fwd;
-    p.y = y;
     p.Hi = (int)sh[1];
     p.Wi = (int)sh[2];
     p.Ck = (int)sh[3];
@@ -137,6 +130,41 @@ int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t
     p.Ho = (int)sh[9];
     p.Wo = (int)sh[10];
     p.M = p.B * p.Ho * p.Wo;
+}
+
+static void bwd_data_params(ConvKParams& p, const int64_t* sh) {
+    fill_common(p, sh);
+    // source = dy [B][Ho_f][Wo_f][N_f];  dest = dx [B][Hi_f][Wi_f][C_f]
+    p.Hi = (int)sh[9];
+    p.Wi = (int)sh[10];
+    p.Ck = (int)sh[4];
+    p.N = (int)sh[3];
+    p.Ho = (int)sh[1];
+    p.Wo = (int)sh[2];
+    p.M = p.B * p.Ho * p.Wo;
+}
+
+int64_t stylex_conv2d_workspace_bytes(const int64_t* sh, int which, int precision) {
+    if (!conv_shape_ok(sh) || (which != 0 && which != 1)) return STYLEX_EINVAL;
+    ConvKParams p;
+    if (which == 0) fwd_params(p, sh);
+    else {
+        bwd_data_params(p, sh);
+        p.transposed = 1;
+    }
+    return stylex_igemm_workspace_bytes(p, precision);
+}
+
+int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* sh, int flags,
+                      const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
+    if (!x || !w_fwd || !y || !conv_shape_ok(sh)) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    ConvKParams p;
+    fwd_params(p, sh);
+    p.a = x;
+    p.w = w_fwd;
+    p.y = y;
     p.flags = flags;
     if (epi) {
         p.a_scale = epi->in_scale;
@@ -156,27 +184,20 @@ int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t
     if ((flags & STYLEX_EPI_RESIDUAL) && !p.residual) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW;
     ScopedTimer tm(0, flops, (hipStream_t)stream);
-    return stylex_launch_igemm(p, precision, (hipStream_t)stream);
+    return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const int64_t* sh, int flags,
-                           const stylex_conv_epilogue* epi, int precision, void* stream) {
+                           const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
+                           void* stream) {
     if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
     if (flags & ~(STYLEX_EPI_OSCALE)) return STYLEX_EINVAL;
     ConvKParams p;
-    fill_common(p, sh);
+    bwd_data_params(p, sh);
     p.a = dy;
     p.w = w_bwd;
     p.y = dx;
-    // source = dy [B][Ho_f][Wo_f][N_f];  dest = dx [B][Hi_f][Wi_f][C_f]
-    p.Hi = (int)sh[9];
-    p.Wi = (int)sh[10];
-    p.Ck = (int)sh[4];
-    p.N = (int)sh[3];
-    p.Ho = (int)sh[1];
-    p.Wo = (int)sh[2];
-    p.M = p.B * p.Ho * p.Wo;
     if (precision == STYLEX_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1) {
         // dx = conv3x3(dy, flipped taps): forward-gather form, eligible for the LDS-halo kernel
         ConvKParams q = p;
@@ -209,7 +230,7 @@ int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const 
     // algorithmic FLOPs of a data gradient = those of the forward conv
     double flops = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6];
     ScopedTimer tm(1, flops, (hipStream_t)stream);
-    return stylex_launch_igemm(p, precision, (hipStream_t)stream);
+    return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static void wgrad_params(ConvKParams& p, const int64_t* sh) {

@@ -29,9 +29,13 @@ struct ConvKParams {
     int M;            // B*Ho*Wo
     int flags;
     long split_len;   // wgrad: pixels per split (multiple of 32)
+    int ksplit;       // igemm split-K: number of K slices (1 = none)
+    int kt_per_split; // igemm split-K: K-tiles per slice
+    float* partial;   // igemm split-K: [ksplit][B*Ho*Wo*N] raw accumulators
 };
 
-int stylex_launch_igemm(const ConvKParams& p, int precision, hipStream_t s);
+int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s);
+int64_t stylex_igemm_workspace_bytes(const ConvKParams& p, int precision);
 void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len);
 int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s);
 int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, int dtype, hipStream_t s);

@@ -6,6 +6,7 @@ call raises.  PyTorch is used for device memory and the current HIP stream only.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -38,10 +39,11 @@ SIGNATURES = {
     "stylex_init": (ctypes.c_int, [ctypes.c_int]),
     "stylex_version": (ctypes.c_char_p, []),
     "stylex_pack_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_conv2d_workspace_bytes": (ctypes.c_int64, [_i64p, ctypes.c_int, ctypes.c_int]),
     "stylex_conv2d_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.POINTER(ConvEpilogue),
-                                         ctypes.c_int, ctypes.c_void_p]),
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_conv2d_bwd_data": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.POINTER(ConvEpilogue),
-                                              ctypes.c_int, ctypes.c_void_p]),
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_conv2d_bwd_weight_workspace_bytes": (ctypes.c_int64, [_i64p]),
     "stylex_conv2d_bwd_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p, _c_f, _c_f,
                                                 ctypes.c_int, ctypes.c_void_p]),
@@ -136,9 +138,28 @@ def empty_cl(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
 
 
+_PACK_CACHE = {}
+_PACK_CACHE_MAX = 512
+
+
+def pack_cache_clear():
+    _PACK_CACHE.clear()
+
+
 def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
-    """OIHW fp32 parameter -> K-contiguous operand layouts, fp32 or bf16 according to `precision`."""
+    """OIHW fp32 parameter -> K-contiguous operand layouts, fp32 or bf16 according to `precision`.
+    Packs of nn.Parameters are cached until the parameter is modified in place (optimizer step):
+    D runs three forwards per step on the same weights."""
     lib = _ensure_device(w)
+    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+    key = None
+    if cacheable:
+        key = (w.data_ptr(), w._version, tuple(w.shape), precision)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is w:  # same live Parameter object (its address cannot be recycled)
+            return hit[1], hit[2]
+        want_fwd = want_bwd = True
+    w_param = w
     w = w.contiguous()
     if w.dtype != torch.float32:
         w = w.float()
@@ -148,7 +169,18 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     wb = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_bwd else None
     _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
            "stylex_pack_weight")
+    if key is not None:
+        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb)
     return wf, wb
+
+
+def _split_workspace(lib, shp, which, precision, like):
+    nbytes = lib.stylex_conv2d_workspace_bytes(shp, which, precision)
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=like.device), nbytes
 
 
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
@@ -189,8 +221,10 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
         flags |= EPI_RESIDUAL
         epi.residual = residual.data_ptr()
         epi.res_scale = res_scale
-    _check(lib.stylex_conv2d_fwd(_ptr(x), _ptr(wf), _ptr(y), _shape(*sh), flags, ctypes.byref(epi), precision,
-                                 _stream()), "stylex_conv2d_fwd")
+    shp = _shape(*sh)
+    ws, ws_bytes = _split_workspace(lib, shp, 0, precision, x)
+    _check(lib.stylex_conv2d_fwd(_ptr(x), _ptr(wf), _ptr(y), shp, flags, ctypes.byref(epi), precision, _ptr(ws),
+                                 ws_bytes, _stream()), "stylex_conv2d_fwd")
     return y
 
 
@@ -210,8 +244,10 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
         out_scale = out_scale.contiguous()
         flags |= EPI_OSCALE
         epi.out_scale = out_scale.data_ptr()
-    _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), _shape(*sh), flags, ctypes.byref(epi), precision,
-                                      _stream()), "stylex_conv2d_bwd_data")
+    shp = _shape(*sh)
+    ws, ws_bytes = _split_workspace(lib, shp, 1, precision, dy)
+    _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), shp, flags, ctypes.byref(epi), precision,
+                                      _ptr(ws), ws_bytes, _stream()), "stylex_conv2d_bwd_data")
     return dx
 
 

@@ -84,8 +84,15 @@ typedef struct {
     float res_scale;
 } stylex_conv_epilogue;
 
+/* Optional split-K workspace for launches that cannot fill the chip (few output tiles, long K):
+ * query with stylex_conv2d_workspace_bytes(shape, which, precision) (which: 0 = fwd, 1 = bwd_data;
+ * may return 0).  Passing workspace = NULL is always valid (no split, same result up to summation
+ * order); with a workspace the slices are reduced in fixed order (deterministic). */
+int64_t stylex_conv2d_workspace_bytes(const int64_t* shape, int which, int precision);
+
 int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* shape, int flags,
-                      const stylex_conv_epilogue* epi, int precision, void* stream);
+                      const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 
 /* dx[b,hi,wi,c] = sum_{kh,kw,n} dy[b,(hi+p-kh)/s,(wi+p-kw)/s,n] * w_bwd[c][t][n]   (exact division only)
  * Replaces the input-gradient half of aten::convolution_backward issued by
@@ -95,7 +102,8 @@ int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t
  * coefficient) and, with STYLEX_EPI_OSCALE, epi->out_scale [B][C] scales dx
  * (style+1).  flags may only contain STYLEX_EPI_OSCALE; epi may be NULL. */
 int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const int64_t* shape, int flags,
-                           const stylex_conv_epilogue* epi, int precision, void* stream);
+                           const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 
 /* dw[n][c][kh][kw] (OIHW, fp32) = sum_{b,ho,wo} dy[b,ho,wo,n] * x[b,ho*s+kh-p,wo*s+kw-p,c]
  * Deterministic two-stage split-K reduction through `workspace`.
