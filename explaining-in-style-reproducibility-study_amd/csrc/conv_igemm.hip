@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     const int T = p.KH * p.KW;
     // K-tiles: VEC4 -> (tap, 32-channel chunk); scalar -> flattened k = tap*Ck + c
     const int chunks = (p.Ck + BK - 1) / BK;
-    const int nk = VEC4 ? T * chunks : (T * p.Ck + BK - 1) / BK;
+    // Ck == 4 (RGB padded to 4): tap-major flattening k = tap*4 + c, each float4 slot is one tap
+    const bool c4 = VEC4 && p.Ck == 4;
+    const int nk = VEC4 ? (c4 ? (T + 7) / 8 : T * chunks) : (T * p.Ck + BK - 1) / BK;
 
     // tile-uniform tap skipping for the phase-major transposed stride-2 gather
     int skip_ph = -1, skip_pw = -1;
@@ -163,9 +165,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
 
     auto load_tile = [&](int kt) {
         if (VEC4) {
-            int tap = kt / chunks, c0 = (kt - tap * chunks) * BK + kq * 4;
+            int tap = c4 ? kt * 8 + kq : kt / chunks;
+            int c0 = c4 ? 0 : (kt - tap * chunks) * BK + kq * 4;
             int kh = tap / p.KW, kw = tap - kh * p.KW;
-            bool cok = c0 < p.Ck;
+            bool cok = c4 ? tap < T : c0 < p.Ck;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
                 long off = cok ? src_offset(p, rows[j], kh, kw) : -1;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto tile_skipped = [&](int kt) -> bool {
-        if (skip_ph < 0 || !VEC4) return false;
+        if (skip_ph < 0 || !VEC4 || c4) return false;
         int tap = kt / chunks;
         int kh = tap / p.KW, kw = tap - kh * p.KW;
         return ((kh & 1) != skip_ph) || ((kw & 1) != skip_pw);
@@ -609,9 +612,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
 // dw_oihw[n][c][t] = sum_split partial[split][n][t][c]   (fixed order => deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int C, int T,
                                     int splits) {
-    long total = (long)N * C * T;
+    const long total = (long)N * C * T;
+    if ((C & 3) == 0) {  // 4 consecutive c per thread: 16-byte coalesced reads of every slice
+        const long total4 = total >> 2;
+        for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+            const long i = i4 << 2;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < splits; ++k) {
+                float4 v = *reinterpret_cast<const float4*>(partial + (long)k * total + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            int c = (int)(i % C);
+            int t = (int)((i / C) % T);
+            int n = (int)(i / ((long)C * T));
+            float* d = dw + ((long)n * C + c) * T + t;
+            d[0] = s.x; d[T] = s.y; d[2 * T] = s.z; d[3 * T] = s.w;
+        }
+        return;
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        // i indexes the packed layout [n][t][c] so reads are coalesced
         int c = (int)(i % C);
         int t = (int)((i / C) % T);
         int n = (int)(i / ((long)C * T));
@@ -731,7 +750,7 @@ static void igemm_splitk_plan(const ConvKParams& p, bool vec, int* ksplit, int* 
     igemm_tile(p, &bm, &bn);
     long blocks = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     int T = p.KH * p.KW;
-    int nk = vec ? T * ((p.Ck + BK - 1) / BK) : (T * p.Ck + BK - 1) / BK;
+    int nk = vec ? (p.Ck == 4 ? (T + 7) / 8 : T * ((p.Ck + BK - 1) / BK)) : (T * p.Ck + BK - 1) / BK;
     *ksplit = 1;
     *kt_per = nk;
     if (blocks >= 192 || nk < 16) return;
@@ -794,7 +813,7 @@ void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long
     *tc = big ? 2 : 1;
     int bt = big ? 128 : 64;
     long tiles = (long)((p.N + bt - 1) / bt) * ((p.Ck + bt - 1) / bt) * p.KH * p.KW;
-    long want = (2048 + tiles - 1) / tiles;                 // aim at ~2048 blocks (8 per CU)
+    long want = (1024 + tiles - 1) / tiles;                 // aim at ~1024 blocks (4 per CU)
     long max_by_len = ((long)p.M + 4 * BK - 1) / (4 * BK);  // at least 4 K-tiles per split
     long sp = want < 1 ? 1 : want;
     if (sp > max_by_len) sp = max_by_len;

@@ -54,6 +54,12 @@ SIGNATURES = {
     "stylex_bias_act_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_bias_act_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_rowwise_sumsq": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_reduce_chunks": (ctypes.c_int, [_i64p]),
+    "stylex_act_bwd_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                             ctypes.c_void_p]),
+    "stylex_modconv_bwd_prep": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _c_f, _i64p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double)]),
@@ -327,6 +333,53 @@ def rowwise_sumsq(x2d):
     _check(lib.stylex_rowwise_sumsq(_ptr(x2d), _ptr(out), _shape(x2d.shape[0], x2d.shape[1]), _stream()),
            "stylex_rowwise_sumsq")
     return out
+
+
+def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True):
+    """dx = dy*scale*lrelu'(y); returns (dx or None, per-channel sum over b,h,w [C])."""
+    lib = _ensure_device(dy)
+    assert is_cl(dy) and (y is None or is_cl(y))
+    b, c, h, w = dy.shape
+    shp = _shape(b, h, w, c)
+    nch = lib.stylex_reduce_chunks(shp)
+    partial = torch.empty((b, nch, c), dtype=torch.float32, device=dy.device)
+    dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
+    _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, int(bool(lrelu)),
+                                     float(scale), _stream()), "stylex_act_bwd_reduce")
+    return dx, partial.sum(dim=(0, 1))
+
+
+def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu):
+    """gz = gy*lrelu'(y); returns gz and S[3][B][C] = per-image sums (gz*(d*z), gz*noise, gz)."""
+    lib = _ensure_device(gy)
+    assert is_cl(gy) and is_cl(y)
+    b, c, h, w = gy.shape
+    shp = _shape(b, h, w, c)
+    nch = lib.stylex_reduce_chunks(shp)
+    partial = torch.empty((b, nch, 3, c), dtype=torch.float32, device=gy.device)
+    gz = empty_cl(tuple(gy.shape), gy)
+    ns = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        ns = noise.shape[1]
+    _check(lib.stylex_modconv_bwd_prep(_ptr(gy), _ptr(y), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(gz),
+                                       _ptr(partial), shp, nch, int(bool(lrelu)), _stream()), "stylex_modconv_bwd_prep")
+    return gz, partial.sum(dim=1)  # [B, 3, C]
+
+
+def scale_reduce(x, t, s, want_gx=True):
+    """gx = t*s[b,c]; returns (gx or None, per-image sum of x*t [B, C])."""
+    lib = _ensure_device(x)
+    assert is_cl(x) and is_cl(t)
+    b, c, h, w = x.shape
+    shp = _shape(b, h, w, c)
+    nch = lib.stylex_reduce_chunks(shp)
+    partial = torch.empty((b, nch, c), dtype=torch.float32, device=x.device)
+    gx = empty_cl(tuple(x.shape), x) if want_gx else None
+    s = s.contiguous()
+    _check(lib.stylex_scale_reduce(_ptr(x), _ptr(t), _ptr(s), _ptr(gx), _ptr(partial), shp, nch, _stream()),
+           "stylex_scale_reduce")
+    return gx, partial.sum(dim=1)
 
 
 def timing_enable(on):

@@ -146,9 +146,11 @@ class GeneratorBlock(nn.Module):  # reference :670-718
         if exists(self.upsample):
             x = self.upsample(x)
         style1 = self.to_style1(istyle)
-        x = ops.noise_act(self.conv1(x, style1), inoise, self.to_noise1.weight[:, 0], self.to_noise1.bias)
+        x = ops.modconv_noise_act(x, style1, self.conv1.weight, inoise, self.to_noise1.weight[:, 0],
+                                  self.to_noise1.bias, demod=self.conv1.demod, eps=self.conv1.eps)
         style2 = self.to_style2(istyle)
-        x = ops.noise_act(self.conv2(x, style2), inoise, self.to_noise2.weight[:, 0], self.to_noise2.bias)
+        x = ops.modconv_noise_act(x, style2, self.conv2.weight, inoise, self.to_noise2.weight[:, 0],
+                                  self.to_noise2.bias, demod=self.conv2.demod, eps=self.conv2.eps)
         rgb = self.to_rgb(x, prev_rgb, istyle)
         return x, rgb, torch.cat([style1, style2], dim=-1)
 
@@ -165,7 +167,10 @@ class DiscriminatorBlock(nn.Module):  # reference :721-744
         res = self.conv_res(x)
         x = self.net(x)
         if exists(self.downsample):
-            x = self.downsample(x)
+            blur, down = self.downsample[0], self.downsample[1]
+            # (conv(blur(x)) + bias + res) / sqrt(2): the merge of :743 rides in the conv epilogue
+            return ops.conv2d(blur(x), down.weight, down.bias, stride=2, padding=1, residual=res,
+                              res_scale=1 / math.sqrt(2))
         return ops.residual_merge(x, res)
 
 

@@ -196,8 +196,131 @@ class _RowSumSq(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------
+# fused fast path: ONE forward kernel per conv (scales, bias, noise, residual merge, LeakyReLU in the
+# epilogue) and fused backward bookkeeping.  Backward is NOT differentiable again, so it is used
+# only when no double backward can be requested: under no_grad, or when the Trainer has declared
+# the phase free of gradient-penalty / path-length terms (set_fast).
+# ------------------------------------------------------------------------------------------
+
+_FAST = False
+
+
+def set_fast(flag):
+    """Trainer hook: True when the coming forward/backward needs first-order gradients only."""
+    global _FAST
+    prev = _FAST
+    _FAST = bool(flag)
+    return prev
+
+
+def fast_enabled():
+    return _FAST or not torch.is_grad_enabled()
+
+
+def _reducible(c):
+    return c % 4 == 0 and c <= 1024
+
+
+class _ConvBiasActFast(torch.autograd.Function):
+    """y = lrelu?( (conv(x, w) + bias + residual) * res_scale )"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, stride, pad, lrelu, res_scale):
+        x = hb.to_cl(x)
+        if residual is not None:
+            residual = hb.to_cl(residual)
+        y = hb.conv2d_fwd(x, w, stride, pad, _PRECISION, bias=bias, lrelu=lrelu, residual=residual,
+                          res_scale=res_scale)
+        ctx.save_for_backward(x, w, y if lrelu else None)
+        ctx.cfg = (stride, pad, lrelu, float(res_scale) if residual is not None else 1.0, bias is not None,
+                   residual is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, lrelu, scale, has_bias, has_res = ctx.cfg
+        gy = hb.to_cl(gy)
+        gb = None
+        if _reducible(gy.shape[1]):
+            want_dx = lrelu or scale != 1.0
+            if want_dx or has_bias:
+                gz, gsum = hb.act_bwd_reduce(gy, y, lrelu, scale, want_dx=want_dx)
+                gb = gsum if has_bias else None
+                if not want_dx:
+                    gz = gy
+            else:
+                gz = gy
+        else:
+            gz = hb.bias_act_bwd(gy, y) if lrelu else gy
+            if scale != 1.0:
+                gz = gz * scale
+            gb = gz.sum(dim=(0, 2, 3)) if has_bias else None
+        gx = hb.conv2d_bwd_data(gz, w, tuple(x.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[0] else None
+        gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[1] else None
+        if not ctx.needs_input_grad[2]:
+            gb = None
+        return gx, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None, None, None, None
+
+
+class _ModConvFast(torch.autograd.Function):
+    """y = lrelu?( d[b,o] * conv(x * s1[b,i], w) + noise[b,w,h]*nw[o] + nb[o] )   (Conv2DMod + noise + act)"""
+
+    @staticmethod
+    def forward(ctx, x, s1, d, w, noise, nw, nb, pad, lrelu):
+        x = hb.to_cl(x)
+        y = hb.conv2d_fwd(x, w, 1, pad, _PRECISION, in_scale=s1, out_scale=d, noise=noise, noise_w=nw, noise_b=nb,
+                          lrelu=lrelu)
+        ctx.save_for_backward(x, s1, d, w, noise, nw, nb, y if (lrelu or d is not None or noise is not None) else None)
+        ctx.cfg = (pad, lrelu)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, s1, d, w, noise, nw, nb, y = ctx.saved_tensors
+        pad, lrelu = ctx.cfg
+        gy = hb.to_cl(gy)
+        gd = gnw = gnb = None
+        if y is not None and _reducible(gy.shape[1]):
+            gz, sums = hb.modconv_bwd_prep(gy, y, noise, nw, nb, lrelu)
+            if d is not None:
+                gd = sums[:, 0] / d
+            if noise is not None:
+                gnw, gnb = sums[:, 1].sum(0), sums[:, 2].sum(0)
+        elif y is not None:
+            raise hb.StylexHipError("fused modulated conv needs C_out % 4 == 0")
+        else:
+            gz = gy
+        gx = gs1 = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            t = hb.conv2d_bwd_data(gz, w, tuple(x.shape), 1, pad, _PRECISION, in_scale=d)
+            if _reducible(x.shape[1]):
+                gx, gs1 = hb.scale_reduce(x, t, s1, want_gx=ctx.needs_input_grad[0])
+            else:
+                gs1 = (x * t).sum(dim=(2, 3))
+                gx = t * s1[:, :, None, None]
+        if ctx.needs_input_grad[3]:
+            gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), 1, pad, _PRECISION, x_scale=s1, dy_scale=d)
+        return gx, gs1, gd, gw, None, gnw, gnb, None, None
+
+
+# ------------------------------------------------------------------------------------------
 # the HIP implementation object
 # ------------------------------------------------------------------------------------------
+
+
+def _pad_rgb(x, weight):
+    """RGB tensors have 3 channels; the vector (16-byte) load paths of the kernels want multiples of 4.
+    Zero-pad C_in 3->4 (input + weight) and N 3->4 (weight; the caller slices the output): exact."""
+    n_out = weight.shape[0]
+    if weight.shape[1] == 3:
+        x = torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2], x.shape[3])], dim=1)
+        weight = torch.cat([weight, weight.new_zeros(weight.shape[0], 1, weight.shape[2], weight.shape[3])], dim=1)
+    if n_out == 3:
+        weight = torch.cat([weight, weight.new_zeros(1, *weight.shape[1:])], dim=0)
+    return x, weight, n_out
 
 
 class HipOps:
@@ -206,13 +329,24 @@ class HipOps:
     name = "hip"
 
     @staticmethod
-    def conv2d(x, weight, bias=None, stride=1, padding=0, lrelu=False):
-        """nn.Conv2d (+ LeakyReLU(0.2)) — reference :724-736, :771, :881."""
+    def conv2d(x, weight, bias=None, stride=1, padding=0, lrelu=False, residual=None, res_scale=1.0):
+        """nn.Conv2d (+ LeakyReLU(0.2)) — reference :724-736, :771, :881; with `residual` the block
+        merge (conv + bias + residual) * res_scale of :743 is fused into the same kernel."""
+        x, weight, n_out = _pad_rgb(x, weight)
+        padded_out = n_out != weight.shape[0]
+        if fast_enabled() and not padded_out:
+            y = _ConvBiasActFast.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)
+            return y
         y = _Conv.apply(x, weight, stride, padding)
+        if padded_out:
+            y = y[:, :n_out]
         if lrelu:
+            assert residual is None
             return _BiasAct.apply(y, bias)
         if bias is not None:
             y = y + bias.view(1, -1, 1, 1)
+        if residual is not None:
+            y = (y + residual) * res_scale
         return y
 
     @staticmethod
@@ -222,12 +356,41 @@ class HipOps:
         s1 = style + 1
         k = weight.shape[2]
         pad = (k - 1) // 2  # _get_same_padding for stride 1, dilation 1 (:644-645)
-        y = _Conv.apply(x * s1[:, :, None, None], weight, 1, pad)
+        n_out = weight.shape[0]
+        w_run = weight
+        if n_out == 3:
+            w_run = torch.cat([weight, weight.new_zeros(1, *weight.shape[1:])], dim=0)
+        if fast_enabled() and w_run.shape[0] % 4 == 0:
+            d = None
+            if demod:
+                wsq = weight.pow(2).sum(dim=(2, 3))
+                d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)
+                if n_out == 3:
+                    d = torch.cat([d, d.new_ones(d.shape[0], 1)], dim=1)
+            y = _ModConvFast.apply(x, s1, d, w_run, None, None, None, pad, False)
+            return y[:, :3] if n_out == 3 else y
+        y = _Conv.apply(x * s1[:, :, None, None], w_run, 1, pad)
+        if n_out == 3:
+            y = y[:, :3]
         if demod:
             wsq = weight.pow(2).sum(dim=(2, 3))  # [O, I]
             d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)  # [B, O]
             y = y * d[:, :, None, None]
         return y
+
+    @staticmethod
+    def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8):
+        """lrelu(Conv2DMod(x, style) + noise) of GeneratorBlock (:696-714) as one fused kernel when no
+        double backward can be requested, else the differentiable composition."""
+        if fast_enabled() and weight.shape[0] % 4 == 0:
+            s1 = style + 1
+            d = None
+            if demod:
+                wsq = weight.pow(2).sum(dim=(2, 3))
+                d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)
+            plane = inoise[:, :, :, 0]
+            return _ModConvFast.apply(x, s1, d, weight, plane, noise_w, noise_b, (weight.shape[2] - 1) // 2, True)
+        return HipOps.noise_act(HipOps.modulated_conv2d(x, style, weight, demod, eps), inoise, noise_w, noise_b)
 
     @staticmethod
     def noise_act(x, inoise, noise_w, noise_b):
@@ -280,6 +443,10 @@ def modulated_conv2d(*a, **k):
 
 def noise_act(*a, **k):
     return _IMPL.noise_act(*a, **k)
+
+
+def modconv_noise_act(*a, **k):
+    return _IMPL.modconv_noise_act(*a, **k)
 
 
 def upsample2x(x):

@@ -507,6 +507,8 @@ class Trainer:
         latents_fn = None
 
         # ---------------- discriminator phase ----------------
+        # fused once-differentiable kernels unless this phase differentiates twice (gradient penalty)
+        ops.set_fast(not apply_gp)
         m.D_opt.zero_grad()
         encoder_input = False
         for micro in range(gae):
@@ -546,6 +548,7 @@ class Trainer:
         # ---------------- generator phase ----------------
         if self.alternating_training:
             encoder_input = False
+        ops.set_fast(not apply_pl)  # path-length regularisation is the only double backward of this phase
         m.G_opt.zero_grad()
         set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
         try:
@@ -584,6 +587,7 @@ class Trainer:
                 encoder_input = not encoder_input
         finally:
             set_requires_grad(m.D, True)
+            ops.set_fast(False)
         if self.is_ddp:
             self._g_sync.all_reduce()
         self.g_loss, rec_f, kl_f = (float(v) for v in torch.stack((tot_g, tot_rec, tot_kl)).tolist())

@@ -139,6 +139,27 @@ int stylex_bias_act_bwd(const float* dy, const float* y, float* dx, const int64_
  * reduction per row block; deterministic. */
 int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void* stream);
 
+/* ---- fused fast path (steps that need no double backward) ------------------------------------
+ * Backward-side kernels that fold the LeakyReLU mask, a scale and the per-(image, channel)
+ * reductions into ONE pass.  Tensors NHWC fp32, shape = {B, H, W, C}, C % 4 == 0, C <= 1024.
+ * Each launch writes partial[b][chunk][k][C] with nchunks = stylex_reduce_chunks(shape); the caller
+ * sums over chunks (and over b where the parameter is per channel).  Deterministic.
+ *
+ * stylex_act_bwd_reduce:   dx = dy * scale * (lrelu ? (y>0 ? 1 : .2) : 1);  partial = sum_pixels dx
+ *   -> backward of lrelu(conv + bias) (stylex_train.py:726-731) and of (x+res)/sqrt(2) (:743);
+ *      dx may be NULL (reduction only).
+ * stylex_modconv_bwd_prep: for y = lrelu(d*z + noise[b,w,h]*nw[c] + nb[c]) (:700-714):
+ *      gz = gy * lrelu'(y);  partial[.][0] = sum gz*(d*z), [1] = sum gz*noise, [2] = sum gz
+ * stylex_scale_reduce:     gx = t * s[b][c];  partial = sum_pixels x*t   (gradient wrt style+1, :650) */
+int stylex_reduce_chunks(const int64_t* shape);
+int stylex_act_bwd_reduce(const float* dy, const float* y, float* dx, float* partial, const int64_t* shape, int nchunks,
+                          int lrelu, float scale, void* stream);
+int stylex_modconv_bwd_prep(const float* gy, const float* y, const float* noise, int64_t noise_stride,
+                            const float* noise_w, const float* noise_b, float* gz, float* partial,
+                            const int64_t* shape, int nchunks, int lrelu, void* stream);
+int stylex_scale_reduce(const float* x, const float* t, const float* s, float* gx, float* partial, const int64_t* shape,
+                        int nchunks, void* stream);
+
 /* Per-kernel timing hook: when enabled every conv launch is bracketed
  * by hipEvents on its stream; stylex_timing_report returns, per kernel class
  * (0=fwd,1=bwd_data,2=bwd_weight): launches, total ms, total algorithmic FLOPs. */

@@ -18,9 +18,15 @@ class CpuOracleOps:
     name = "cpu-oracle-test-double"
 
     @staticmethod
-    def conv2d(x, weight, bias=None, stride=1, padding=0, lrelu=False):
+    def conv2d(x, weight, bias=None, stride=1, padding=0, lrelu=False, residual=None, res_scale=1.0):
         y = F.conv2d(x, weight, bias, stride=stride, padding=padding)
+        if residual is not None:
+            y = (y + residual) * res_scale
         return so.lrelu(y) if lrelu else y
+
+    @staticmethod
+    def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8):
+        return CpuOracleOps.noise_act(so.modulated_conv2d(x, style, weight, demod, eps), inoise, noise_w, noise_b)
 
     @staticmethod
     def modulated_conv2d(x, style, weight, demod=True, eps=1e-8):

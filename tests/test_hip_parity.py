@@ -125,6 +125,48 @@ def test_fused_conv_epilogue_and_scales(shape, prec):
     close(wr.grad, dw, tol, "scaled wgrad")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fast_fused_path_matches_differentiable_path(prec):
+    """The once-differentiable fused Functions (one forward kernel; fused backward bookkeeping) give the
+    same outputs and first-order gradients as the fully differentiable composition."""
+    ops.set_precision(prec)
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    g = torch.Generator().manual_seed(3)
+    B, C, N, H = 2, 16, 24, 16
+    x0 = torch.randn(B, C, H, H, generator=g)
+    w0 = torch.randn(N, C, 3, 3, generator=g) / 12
+    b0 = torch.randn(N, generator=g)
+    res0 = torch.randn(B, N, H // 2, H // 2, generator=g)
+    st0 = torch.randn(B, C, generator=g) * 0.5
+    inoise = torch.rand(B, 32, 32, 1, generator=g).to(DEV)
+    nw0, nb0 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    wr0 = torch.randn(3, C, 1, 1, generator=g)
+
+    def run(fast):
+        prev = ops.set_fast(fast)
+        try:
+            leaves = [t.clone().to(DEV).requires_grad_() for t in (x0, w0, b0, res0, st0, nw0, nb0, wr0)]
+            x, w, b, res, st_, nw, nb, wr = leaves
+            xc = x.contiguous(memory_format=torch.channels_last)
+            y1 = ops.conv2d(xc, w, b, 1, 1, lrelu=True)                                  # conv+bias+lrelu
+
+            y3 = ops.conv2d(xc, w, b, 2, 1, residual=res, res_scale=0.7)                  # merge epilogue
+            y4 = ops.modconv_noise_act(xc, st_, w, inoise, nw, nb)                        # G conv
+            y5 = ops.modulated_conv2d(xc, st_, wr, demod=False)                           # toRGB
+            loss = (y1 * y1).mean() + (y3 * y3).mean() + (y4 * y4).mean() + (y5 * y5).mean()
+            loss.backward()
+            return [y1, y3, y4, y5], [t.grad for t in leaves]
+        finally:
+            ops.set_fast(prev)
+
+    ys_s, gs_s = run(False)
+    ys_f, gs_f = run(True)
+    for i, (a, b_) in enumerate(zip(ys_s, ys_f)):
+        close(a, b_, tol, "fast fwd %d" % i)
+    for nm, a, b_ in zip(("x", "w", "bias", "res", "style", "nw", "nb", "w_rgb"), gs_s, gs_f):
+        close(a, b_, tol * 5, "fast grad " + nm)
+
+
 def test_conv_bias_lrelu_and_second_order():
     """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
     g = torch.Generator().manual_seed(5)

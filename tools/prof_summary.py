@@ -1,0 +1,33 @@
+"""Summarise a rocprofv3 kernel_stats.csv: per-step ms grouped into families."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+fam = {}
+def family(n):
+    if "conv3x3_halo" in n: return "halo fwd/dgrad"
+    if "wgrad_halo" in n: return "halo wgrad"
+    if "conv_igemm" in n: return "igemm v1 fwd/dgrad"
+    if "conv_wgrad_kernel" in n: return "wgrad v1"
+    if "wgrad_reduce" in n or "splitk_epilogue" in n: return "split reduce"
+    if "pack_weight" in n: return "pack_weight"
+    if "bias_act" in n: return "bias_act"
+    if "blur3x3" in n: return "blur"
+    if "upsample2x" in n: return "upsample"
+    if "rowwise" in n or "modconv" in n or "scale_reduce" in n: return "other stylex"
+    if "at::native" in n and "reduce" in n: return "torch reduce"
+    if "at::native" in n: return "torch elementwise"
+    if "miopen" in n.lower() or "igemm_" in n or "naive_conv" in n or "Im2d2Col" in n or "Col2Im" in n or "ck::" in n or "_ZN2ck" in n or "BatchNorm" in n: return "MIOpen (classifier/LPIPS)"
+    if n.startswith("Cijk"): return "rocBLAS"
+    return "misc"
+tot = 0
+for r in rows:
+    f = family(r["Name"]); t = float(r["TotalDurationNs"]) / 1e6
+    fam[f] = fam.get(f, 0) + t; tot += t
+print("total %.1f ms  (%.1f ms/step over %g steps)" % (tot, tot / steps, steps))
+for f, t in sorted(fam.items(), key=lambda kv: -kv[1]):
+    print("  %-28s %8.1f ms/step  %5.1f%%" % (f, t / steps, 100 * t / tot))
+if len(sys.argv) > 3:
+    for r in rows[:int(sys.argv[3])]:
+        print("%-100s %6s %9.2f ms avg %8.1f us" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6 / steps, float(r["AverageNs"]) / 1e3))
