@@ -107,15 +107,17 @@ __device__ __forceinline__ long src_offset(const ConvKParams& p, const RowPix& r
 // ------------------------------------------------------------------------------------------
 // fprop / dgrad kernel.  Block = 256 threads = WM x WN waves, wave tile (TM*32) x (TN*32).
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread for A / B
+    constexpr int KQ = BKT / 4;      // float4 slots per staged row
+    constexpr int RPP = 256 / KQ;    // rows staged per pass of the 256 threads
+    constexpr int RA = BM / RPP, RB = BN / RPP;  // rows staged per thread for A / B
     // fp32 LDS image: [k][row] with row stride +1 dword.  bf16 image: [row][k] bf16, 80-byte rows.
     constexpr int LDA = BM + 1, LDB = BN + 1;
-    constexpr int LDH = 40;  // bf16 elements per LDS row (32 + 8 pad -> 80 B rows, 16-B aligned)
-    constexpr int A_ELEMS = BF16 ? (BM * LDH / 2) : (BK * LDA);
-    constexpr int B_ELEMS = BF16 ? (BN * LDH / 2) : (BK * LDB);
+    constexpr int LDH = BKT + 8;  // bf16 elements per LDS row (+8 pad: 16-B aligned rows, odd 16-B slot stride)
+    constexpr int A_ELEMS = BF16 ? (BM * LDH / 2) : (BKT * LDA);
+    constexpr int B_ELEMS = BF16 ? (BN * LDH / 2) : (BKT * LDB);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     auto As = [&](int st) -> float* { return smem + st * (A_ELEMS + B_ELEMS); };
     auto Bs = [&](int st) -> float* { return smem + st * (A_ELEMS + B_ELEMS) + A_ELEMS; };
@@ -135,19 +137,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     const int m0 = (bid / n_tiles) * BM;
     const int n0 = (bid % n_tiles) * BN;
 
-    const int kq = tid & 7;   // which float4 of the 32-deep K chunk
-    const int r0 = tid >> 3;  // 0..31
+    const int kq = tid % KQ;  // which float4 of the BKT-deep K chunk
+    const int r0 = tid / KQ;  // 0..RPP-1
 
     RowPix rows[RA];
 #pragma unroll
-    for (int j = 0; j < RA; ++j) rows[j] = decode_row(p, m0 + r0 + 32 * j);
+    for (int j = 0; j < RA; ++j) rows[j] = decode_row(p, m0 + r0 + RPP * j);
 
     const int T = p.KH * p.KW;
     // K-tiles: VEC4 -> (tap, 32-channel chunk); scalar -> flattened k = tap*Ck + c
-    const int chunks = (p.Ck + BK - 1) / BK;
+    const int chunks = (p.Ck + BKT - 1) / BKT;
     // Ck == 4 (RGB padded to 4): tap-major flattening k = tap*4 + c, each float4 slot is one tap
     const bool c4 = VEC4 && p.Ck == 4;
-    const int nk = VEC4 ? (c4 ? (T + 7) / 8 : T * chunks) : (T * p.Ck + BK - 1) / BK;
+    const int nk = VEC4 ? (c4 ? (T + KQ - 1) / KQ : T * chunks) : (T * p.Ck + BKT - 1) / BKT;
 
     // tile-uniform tap skipping for the phase-major transposed stride-2 gather
     int skip_ph = -1, skip_pw = -1;
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
 
     auto load_tile = [&](int kt) {
         if (VEC4) {
-            int tap = c4 ? kt * 8 + kq : kt / chunks;
-            int c0 = c4 ? 0 : (kt - tap * chunks) * BK + kq * 4;
+            int tap = c4 ? kt * KQ + kq : kt / chunks;
+            int c0 = c4 ? 0 : (kt - tap * chunks) * BKT + kq * 4;
             int kh = tap / p.KW, kw = tap - kh * p.KW;
             bool cok = c4 ? tap < T : c0 < p.Ck;
 #pragma unroll
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                int n = n0 + r0 + 32 * j;
+                int n = n0 + r0 + RPP * j;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (cok && n < p.N) {
                     long wo = ((long)n * T + tap) * p.Ck + c0;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 rb[j] = v;
             }
         } else {
-            int kbase = kt * BK + kq * 4;
+            int kbase = kt * BKT + kq * 4;
             int KT = T * p.Ck;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                int n = n0 + r0 + 32 * j;
+                int n = n0 + r0 + RPP * j;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -252,24 +254,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 uint2 v;
                 v.x = pack_bf16(ra[j].x, ra[j].y);
                 v.y = pack_bf16(ra[j].z, ra[j].w);
-                *reinterpret_cast<uint2*>(a + (r0 + 32 * j) * LDH + kq * 4) = v;
+                *reinterpret_cast<uint2*>(a + (r0 + RPP * j) * LDH + kq * 4) = v;
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 uint2 v;
                 v.x = __float_as_uint(rb[j].x);
                 v.y = __float_as_uint(rb[j].y);
-                *reinterpret_cast<uint2*>(b + (r0 + 32 * j) * LDH + kq * 4) = v;
+                *reinterpret_cast<uint2*>(b + (r0 + RPP * j) * LDH + kq * 4) = v;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
-                float* d = As(st) + (kq * 4) * LDA + r0 + 32 * j;
+                float* d = As(st) + (kq * 4) * LDA + r0 + RPP * j;
                 d[0] = ra[j].x; d[LDA] = ra[j].y; d[2 * LDA] = ra[j].z; d[3 * LDA] = ra[j].w;
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                float* d = Bs(st) + (kq * 4) * LDB + r0 + 32 * j;
+                float* d = Bs(st) + (kq * 4) * LDB + r0 + RPP * j;
                 d[0] = rb[j].x; d[LDB] = rb[j].y; d[2 * LDB] = rb[j].z; d[3 * LDB] = rb[j].w;
             }
         }
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             const unsigned short* a = reinterpret_cast<const unsigned short*>(As(st));
             const unsigned short* b = reinterpret_cast<const unsigned short*>(Bs(st));
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
+            for (int ks = 0; ks < BKT / 16; ++ks) {
                 bf16x8 av[TM], bv[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             const float* a = As(st) + wm * TM * 32 + li;
             const float* b = Bs(st) + wn * TN * 32 + li;
 #pragma unroll
-            for (int ks = 0; ks < BK / 2; ++ks) {
+            for (int ks = 0; ks < BKT / 2; ++ks) {
                 float av[TM], bv[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[i] = a[(ks * 2 + lk) * LDA + i * 32];
@@ -683,10 +685,10 @@ __global__ void splitk_epilogue_kernel(ConvKParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT>
 constexpr size_t igemm_smem() {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    return BF16 ? (size_t)2 * (BM + BN) * 40 * 2 : (size_t)2 * BK * (BM + 1 + BN + 1) * 4;
+    return BF16 ? (size_t)2 * (BM + BN) * (BKT + 8) * 2 : (size_t)2 * BKT * (BM + 1 + BN + 1) * 4;
 }
 template <int TN_, int TC_, bool BF16>
 constexpr size_t wgrad_smem() {
@@ -694,11 +696,11 @@ constexpr size_t wgrad_smem() {
     return BF16 ? (size_t)2 * (BNn + BC) * (BK + 8) * 2 : (size_t)2 * BK * (BNn + 4 + BC + 4) * 4;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16>
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT>
 int launch_igemm(const ConvKParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    auto k = conv_igemm_kernel<WM, WN, TM, TN, VEC4, BF16>;
-    constexpr size_t sm = igemm_smem<WM, WN, TM, TN, VEC4, BF16>();
+    auto k = conv_igemm_kernel<WM, WN, TM, TN, VEC4, BF16, BKT>;
+    constexpr size_t sm = igemm_smem<WM, WN, TM, TN, VEC4, BF16, BKT>();
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -710,12 +712,12 @@ int launch_igemm(const ConvKParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <bool VEC4, bool BF16>
+template <bool VEC4, bool BF16, int BKT>
 int dispatch_igemm(const ConvKParams& p, hipStream_t s) {
-    // tile choice by output-channel count; small-M layers take the narrow-M tile to fill more CUs
-    if (p.N > 64) return launch_igemm<2, 2, 2, 2, VEC4, BF16>(p, s);
-    if (p.N > 32) return launch_igemm<4, 1, 2, 2, VEC4, BF16>(p, s);
-    return launch_igemm<4, 1, 2, 1, VEC4, BF16>(p, s);
+    // tile choice by output-channel count
+    if (p.N > 64) return launch_igemm<2, 2, 2, 2, VEC4, BF16, BKT>(p, s);
+    if (p.N > 32) return launch_igemm<4, 1, 2, 2, VEC4, BF16, BKT>(p, s);
+    return launch_igemm<4, 1, 2, 1, VEC4, BF16, BKT>(p, s);
 }
 
 template <int TN_, int TC_, bool VEC4, bool BF16>
@@ -744,13 +746,23 @@ static void igemm_tile(const ConvKParams& p, int* bm, int* bn) {
     else { *bm = 256; *bn = 32; }
 }
 
+// K-tile depth: the bf16 path is load-latency bound per K-tile, so deeper tiles (more bytes in flight and
+// more MFMAs per barrier) are used whenever the channel count allows
+static int igemm_bk(const ConvKParams& p, bool vec, int precision) {
+    // Measured (profiles/r01_c notes): BKT = 64/128 is SLOWER on this kernel — the big strided layers are
+    // L2/HBM-bound on the fp32 gather and lose occupancy, the small ones are launch-bound.  Keep 32.
+    (void)p; (void)vec; (void)precision;
+    return 32;
+}
+
 // split-K plan for launches that cannot fill the chip: few output tiles and a long K loop
-static void igemm_splitk_plan(const ConvKParams& p, bool vec, int* ksplit, int* kt_per) {
+static void igemm_splitk_plan(const ConvKParams& p, bool vec, int precision, int* ksplit, int* kt_per) {
     int bm, bn;
     igemm_tile(p, &bm, &bn);
     long blocks = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     int T = p.KH * p.KW;
-    int nk = vec ? (p.Ck == 4 ? (T + 7) / 8 : T * ((p.Ck + BK - 1) / BK)) : (T * p.Ck + BK - 1) / BK;
+    const int bk = igemm_bk(p, vec, precision);
+    int nk = vec ? (p.Ck == 4 ? (T + 7) / 8 : T * ((p.Ck + bk - 1) / bk)) : (T * p.Ck + BK - 1) / BK;
     *ksplit = 1;
     *kt_per = nk;
     if (blocks >= 192 || nk < 16) return;
@@ -771,9 +783,8 @@ static bool igemm_vec_ok(const ConvKParams& p) {
 }
 
 int64_t stylex_igemm_workspace_bytes(const ConvKParams& p, int precision) {
-    (void)precision;
     int ks, per;
-    igemm_splitk_plan(p, p.Ck % 4 == 0, &ks, &per);
+    igemm_splitk_plan(p, p.Ck % 4 == 0, precision, &ks, &per);
     return ks > 1 ? (int64_t)ks * p.M * p.N * (int64_t)sizeof(float) : 0;
 }
 
@@ -788,7 +799,7 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
     p.partial = nullptr;
     if (workspace) {
         int ks, per;
-        igemm_splitk_plan(p, vec, &ks, &per);
+        igemm_splitk_plan(p, vec, precision, &ks, &per);
         if (ks > 1 && workspace_bytes >= (int64_t)ks * p.M * p.N * (int64_t)sizeof(float)) {
             p.ksplit = ks;
             p.kt_per_split = per;
@@ -796,8 +807,13 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
         }
     }
     int rc;
-    if (precision == STYLEX_BF16) rc = vec ? dispatch_igemm<true, true>(p, s) : dispatch_igemm<false, true>(p, s);
-    else rc = vec ? dispatch_igemm<true, false>(p, s) : dispatch_igemm<false, false>(p, s);
+    if (precision == STYLEX_BF16) {
+        const int bk = igemm_bk(p, vec, precision);
+        (void)bk;
+        rc = vec ? dispatch_igemm<true, true, 32>(p, s) : dispatch_igemm<false, true, 32>(p, s);
+    } else {
+        rc = vec ? dispatch_igemm<true, false, 32>(p, s) : dispatch_igemm<false, false, 32>(p, s);
+    }
     if (rc || p.ksplit <= 1) return rc;
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
