@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16_f32act": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 G_FWD, D_FWD, E_FWD = 17.767, 35.511, 35.513  # conv GFLOP per image @256 px
 
 
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--precision", default=os.environ.get("STYLEX_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=os.environ.get("STYLEX_PRECISION", "bf16"), choices=["bf16", "bf16_f32act", "fp32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per micro-batch")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--gae", type=int, default=2, help="gradient_accumulate_every (2 = noise + encoder micro-step)")

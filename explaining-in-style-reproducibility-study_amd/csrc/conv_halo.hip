@@ -33,11 +33,15 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 
 constexpr int ROWB = 80;  // LDS row pitch in bytes (32 bf16 + 16 B pad)
 
-template <int TW, int TN>
+// ABF: activations are bf16 in HBM -> the halo is staged with raw 16-byte (8-channel) loads and no
+// conversion; otherwise fp32 activations are converted to bf16 on the way into LDS.
+template <int TW, int TN, bool ABF>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p) {
     constexpr int TH = 256 / TW, HWD = TW + 2, NP = (TH + 2) * HWD;
     constexpr int BN = TN * 32;
-    constexpr int HALO_SLOTS = (NP * 8 + 255) / 256;     // float4 global loads per thread per chunk
+    constexpr int SPP = ABF ? 4 : 8;                     // staging slots per halo pixel (32 channels)
+    constexpr int SLOT_SHIFT = ABF ? 2 : 3;
+    constexpr int HALO_SLOTS = (NP * SPP + 255) / 256;   // global loads per thread per chunk
     constexpr int W_ROWS = BN * 9;
     constexpr int W_SLOTS = (W_ROWS * 4 + 255) / 256;    // 16-byte global loads per thread per chunk
     constexpr int W_OFF = NP * ROWB;
@@ -60,28 +64,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     const int y0 = (pt / tiles_x) * TH, x0 = (pt % tiles_x) * TW;
 
     // per-thread halo slots: pixel index in the image batch, or -1 for padding / beyond the halo
-    const int q8 = tid & 7;
+    const int q8 = tid & (SPP - 1);
     int hoff[HALO_SLOTS];
 #pragma unroll
     for (int it = 0; it < HALO_SLOTS; ++it) {
-        int hp = (tid + 256 * it) >> 3;
+        int hp = (tid + 256 * it) >> SLOT_SHIFT;
         int hh = hp / HWD, ww = hp - hh * HWD;
         int y = y0 - 1 + hh, x = x0 - 1 + ww;
         bool ok = hp < NP && y >= 0 && y < H && x >= 0 && x < W;
         hoff[it] = ok ? (b * H + y) * W + x : -1;
     }
 
-    float4 hreg[HALO_SLOTS];
+    float4 hreg[HALO_SLOTS];  // fp32 x4, or (ABF) raw bf16 x8 bit patterns
     uint4 wreg[W_SLOTS];
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
 
     auto issue_loads = [&](int c0) {
-        const int cc = c0 + q8 * 4;
+        const int cc = c0 + q8 * (ABF ? 8 : 4);
         const bool cok = cc < C;
 #pragma unroll
         for (int it = 0; it < HALO_SLOTS; ++it) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cok && hoff[it] >= 0) v = *reinterpret_cast<const float4*>(p.a + (long)hoff[it] * C + cc);
+            if (cok && hoff[it] >= 0) {
+                if (ABF)  // raw bits: unpacking here would force the load to complete before the MFMAs
+                    v = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.a) + (long)hoff[it] * C + cc);
+                else
+                    v = *reinterpret_cast<const float4*>(p.a + (long)hoff[it] * C + cc);
+            }
             hreg[it] = v;
         }
 #pragma unroll
@@ -100,17 +109,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     };
 
     auto write_lds = [&](int c0) {
-        const int cc = c0 + q8 * 4;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.a_scale && cc < C) sc = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+        const int cc = c0 + q8 * (ABF ? 8 : 4);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sc2 = sc;
+        if (p.a_scale && cc < C) {
+            sc = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+            if (ABF) sc2 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc + 4);
+        }
 #pragma unroll
         for (int it = 0; it < HALO_SLOTS; ++it) {
-            int hp = (tid + 256 * it) >> 3;
+            int hp = (tid + 256 * it) >> SLOT_SHIFT;
             if (hp < NP) {
-                uint2 v;
-                v.x = pack_bf16(hreg[it].x * sc.x, hreg[it].y * sc.y);
-                v.y = pack_bf16(hreg[it].z * sc.z, hreg[it].w * sc.w);
-                *reinterpret_cast<uint2*>(smem + hp * ROWB + q8 * 8) = v;
+                if (ABF) {
+                    uint4 v = make_uint4(__float_as_uint(hreg[it].x), __float_as_uint(hreg[it].y),
+                                         __float_as_uint(hreg[it].z), __float_as_uint(hreg[it].w));
+                    if (p.a_scale) {
+                        float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
+                        v.x = pack_bf16(f0.x * sc.x, f0.y * sc.y); v.y = pack_bf16(f0.z * sc.z, f0.w * sc.w);
+                        v.z = pack_bf16(f1.x * sc2.x, f1.y * sc2.y); v.w = pack_bf16(f1.z * sc2.z, f1.w * sc2.w);
+                    }
+                    *reinterpret_cast<uint4*>(smem + hp * ROWB + q8 * 16) = v;
+                } else {
+                    uint2 v;
+                    v.x = pack_bf16(hreg[it].x * sc.x, hreg[it].y * sc.y);
+                    v.y = pack_bf16(hreg[it].z * sc.z, hreg[it].w * sc.w);
+                    *reinterpret_cast<uint2*>(smem + hp * ROWB + q8 * 8) = v;
+                }
             }
         }
 #pragma unroll
@@ -205,19 +228,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 float v = acc[i][j][r] * osc;
                 if (p.flags & STYLEX_EPI_BIAS) v += bias;
                 if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
-                if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + p.residual[o]) * p.res_scale;
+                if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
                 if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
-                p.y[o] = v;
+                act_st1(p.y, o, v, p.act_bf16);
             }
         }
     }
 }
 
-template <int TW, int TN>
+template <int TW, int TN, bool ABF>
 int launch_halo(const ConvKParams& p, hipStream_t s) {
     constexpr int TH = 256 / TW, NP = (TH + 2) * (TW + 2), BN = TN * 32;
     constexpr size_t sm = (size_t)NP * ROWB + (size_t)BN * 9 * ROWB;
-    auto k = conv3x3_halo_bf16_kernel<TW, TN>;
+    auto k = conv3x3_halo_bf16_kernel<TW, TN, ABF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -240,6 +263,10 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return STYLEX_NOT_APPLICABLE;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return STYLEX_NOT_APPLICABLE;
     const bool wide = p.Wo >= 32;
-    if (p.N > 32) return wide ? launch_halo<32, 2>(p, s) : launch_halo<16, 2>(p, s);
-    return wide ? launch_halo<32, 1>(p, s) : launch_halo<16, 1>(p, s);
+    if (p.act_bf16) {
+        if (p.N > 32) return wide ? launch_halo<32, 2, true>(p, s) : launch_halo<16, 2, true>(p, s);
+        return wide ? launch_halo<32, 1, true>(p, s) : launch_halo<16, 1, true>(p, s);
+    }
+    if (p.N > 32) return wide ? launch_halo<32, 2, false>(p, s) : launch_halo<16, 2, false>(p, s);
+    return wide ? launch_halo<32, 1, false>(p, s) : launch_halo<16, 1, false>(p, s);
 }

@@ -107,10 +107,11 @@ __device__ __forceinline__ long src_offset(const ConvKParams& p, const RowPix& r
 // ------------------------------------------------------------------------------------------
 // fprop / dgrad kernel.  Block = 256 threads = WM x WN waves, wave tile (TM*32) x (TN*32).
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT>
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT, bool ABF = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int KQ = BKT / 4;      // float4 slots per staged row
+    // ABF: bf16 activations AND weights staged as raw 16-byte slots of 8 elements (no conversion, no unpack)
+    constexpr int KQ = ABF ? BKT / 8 : BKT / 4;  // slots per staged row
     constexpr int RPP = 256 / KQ;    // rows staged per pass of the 256 threads
     constexpr int RA = BM / RPP, RB = BN / RPP;  // rows staged per thread for A / B
     // fp32 LDS image: [k][row] with row stride +1 dword.  bf16 image: [row][k] bf16, 80-byte rows.
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     // K-tiles: VEC4 -> (tap, 32-channel chunk); scalar -> flattened k = tap*Ck + c
     const int chunks = (p.Ck + BKT - 1) / BKT;
     // Ck == 4 (RGB padded to 4): tap-major flattening k = tap*4 + c, each float4 slot is one tap
-    const bool c4 = VEC4 && p.Ck == 4;
+    const bool c4 = VEC4 && (ABF ? p.Ck == 8 : p.Ck == 4);
     const int nk = VEC4 ? (c4 ? (T + KQ - 1) / KQ : T * chunks) : (T * p.Ck + BKT - 1) / BKT;
 
     // tile-uniform tap skipping for the phase-major transposed stride-2 gather
@@ -164,8 +165,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     }
 
     float4 ra[RA], rb[RB];
+    uint4 rah[RA], rbh[RB];  // ABF staging registers (raw bf16 x8)
+    int cur_kt = 0;          // K-tile held in the staging registers (ABF scale lookup)
 
     auto load_tile = [&](int kt) {
+        if (ABF) {
+            cur_kt = kt;
+            const unsigned short* abase = reinterpret_cast<const unsigned short*>(p.a);
+            const unsigned short* wbase = reinterpret_cast<const unsigned short*>(p.w);
+            int tap = c4 ? kt * KQ + kq : kt / chunks;
+            int c0 = c4 ? 0 : (kt - tap * chunks) * BKT + kq * 8;
+            int kh = tap / p.KW, kw = tap - kh * p.KW;
+            bool cok = c4 ? tap < T : c0 < p.Ck;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                long off = cok ? src_offset(p, rows[j], kh, kw) : -1;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (off >= 0) v = *reinterpret_cast<const uint4*>(abase + off + c0);
+                rah[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                int n = n0 + r0 + RPP * j;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (cok && n < p.N) v = *reinterpret_cast<const uint4*>(wbase + ((long)n * T + tap) * p.Ck + c0);
+                rbh[j] = v;
+            }
+            return;
+        }
         if (VEC4) {
             int tap = c4 ? kt * KQ + kq : kt / chunks;
             int c0 = c4 ? 0 : (kt - tap * chunks) * BKT + kq * 4;
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 long off = cok ? src_offset(p, rows[j], kh, kw) : -1;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (off >= 0) {
-                    v = *reinterpret_cast<const float4*>(p.a + off + c0);
+                    v = act_ld4(p.a, off + c0, p.act_bf16);
                     if (p.a_scale) {
                         float4 s = *reinterpret_cast<const float4*>(p.a_scale + (long)rows[j].b * p.Ck + c0);
                         v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
@@ -215,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                         int kh = tap / p.KW, kw = tap - kh * p.KW;
                         long off = src_offset(p, rows[j], kh, kw);
                         if (off >= 0) {
-                            v[e] = p.a[off + c];
+                            v[e] = act_ld1(p.a, off + c, p.act_bf16);
                             if (p.a_scale) v[e] *= p.a_scale[(long)rows[j].b * p.Ck + c];
                         }
                     }
@@ -246,6 +273,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     };
 
     auto store_tile = [&](int st) {
+        if (ABF) {
+            unsigned short* a = reinterpret_cast<unsigned short*>(As(st));
+            unsigned short* b = reinterpret_cast<unsigned short*>(Bs(st));
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                uint4 v = rah[j];
+                if (p.a_scale && rows[j].valid) {  // modulation scale: unpack, scale, repack
+                    int c0 = c4 ? 0 : (cur_kt % chunks) * BKT + kq * 8;
+                    if (c0 < p.Ck) {
+                        const float* sp = p.a_scale + (long)rows[j].b * p.Ck + c0;
+                        float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+                        float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
+                        v.x = pack_bf16(f0.x * s0.x, f0.y * s0.y); v.y = pack_bf16(f0.z * s0.z, f0.w * s0.w);
+                        v.z = pack_bf16(f1.x * s1.x, f1.y * s1.y); v.w = pack_bf16(f1.z * s1.z, f1.w * s1.w);
+                    }
+                }
+                *reinterpret_cast<uint4*>(a + (r0 + RPP * j) * LDH + kq * 8) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) *reinterpret_cast<uint4*>(b + (r0 + RPP * j) * LDH + kq * 8) = rbh[j];
+            return;
+        }
         if (BF16) {
             unsigned short* a = reinterpret_cast<unsigned short*>(As(st));
             unsigned short* b = reinterpret_cast<unsigned short*>(Bs(st));
@@ -383,9 +432,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 if (p.flags & STYLEX_EPI_BIAS) v += bias;
                 if (p.flags & STYLEX_EPI_NOISE)
                     v += p.noise[((long)rp.b * p.noise_stride + rp.ow) * p.noise_stride + rp.oh] * nw + nb;
-                if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + p.residual[o]) * p.res_scale;
+                if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
                 if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
-                p.y[o] = v;
+                act_st1(p.y, o, v, p.act_bf16);
             }
         }
     }
@@ -440,11 +489,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
             int n = n0 + q * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < m_end) {
-                const float* src = p.a2 + m * p.N + n;
+                const long src = m * p.N + n;
                 int bb = (int)(m / ((long)p.Ho * p.Wo));
                 if (VEC4) {
                     if (n < p.N) {
-                        v = *reinterpret_cast<const float4*>(src);
+                        v = act_ld4(p.a2, src, p.act_bf16);
                         if (p.a2_scale) {
                             float4 s = *reinterpret_cast<const float4*>(p.a2_scale + (long)bb * p.N + n);
                             v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
@@ -454,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
                     float t[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        t[e] = (n + e < p.N) ? src[e] : 0.f;
+                        t[e] = (n + e < p.N) ? act_ld1(p.a2, src + e, p.act_bf16) : 0.f;
                         if (p.a2_scale && n + e < p.N) t[e] *= p.a2_scale[(long)bb * p.N + n + e];
                     }
                     v = make_float4(t[0], t[1], t[2], t[3]);
@@ -475,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
                 if (off >= 0) {
                     if (VEC4) {
                         if (c < p.Ck) {
-                            v = *reinterpret_cast<const float4*>(p.a + off + c);
+                            v = act_ld4(p.a, off + c, p.act_bf16);
                             if (p.a_scale) {
                                 float4 s = *reinterpret_cast<const float4*>(p.a_scale + (long)rp.b * p.Ck + c);
                                 v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
@@ -485,7 +534,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
                         float t[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            t[e] = (c + e < p.Ck) ? p.a[off + c + e] : 0.f;
+                            t[e] = (c + e < p.Ck) ? act_ld1(p.a, off + c + e, p.act_bf16) : 0.f;
                             if (p.a_scale && c + e < p.Ck) t[e] *= p.a_scale[(long)rp.b * p.Ck + c + e];
                         }
                         v = make_float4(t[0], t[1], t[2], t[3]);
@@ -679,9 +728,9 @@ __global__ void splitk_epilogue_kernel(ConvKParams p) {
         if (p.flags & STYLEX_EPI_BIAS) v += p.bias[n];
         if (p.flags & STYLEX_EPI_NOISE)
             v += p.noise[((long)b * p.noise_stride + ow) * p.noise_stride + oh] * p.noise_w[n] + p.noise_b[n];
-        if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + p.residual[o]) * p.res_scale;
+        if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
         if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
-        p.y[o] = v;
+        act_st1(p.y, o, v, p.act_bf16);
     }
 }
 
@@ -696,10 +745,10 @@ constexpr size_t wgrad_smem() {
     return BF16 ? (size_t)2 * (BNn + BC) * (BK + 8) * 2 : (size_t)2 * BK * (BNn + 4 + BC + 4) * 4;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT>
+template <int WM, int WN, int TM, int TN, bool VEC4, bool BF16, int BKT, bool ABF = false>
 int launch_igemm(const ConvKParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    auto k = conv_igemm_kernel<WM, WN, TM, TN, VEC4, BF16, BKT>;
+    auto k = conv_igemm_kernel<WM, WN, TM, TN, VEC4, BF16, BKT, ABF>;
     constexpr size_t sm = igemm_smem<WM, WN, TM, TN, VEC4, BF16, BKT>();
     static bool attr_done = false;
     if (!attr_done) {
@@ -712,12 +761,12 @@ int launch_igemm(const ConvKParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <bool VEC4, bool BF16, int BKT>
+template <bool VEC4, bool BF16, int BKT, bool ABF = false>
 int dispatch_igemm(const ConvKParams& p, hipStream_t s) {
     // tile choice by output-channel count
-    if (p.N > 64) return launch_igemm<2, 2, 2, 2, VEC4, BF16, BKT>(p, s);
-    if (p.N > 32) return launch_igemm<4, 1, 2, 2, VEC4, BF16, BKT>(p, s);
-    return launch_igemm<4, 1, 2, 1, VEC4, BF16, BKT>(p, s);
+    if (p.N > 64) return launch_igemm<2, 2, 2, 2, VEC4, BF16, BKT, ABF>(p, s);
+    if (p.N > 32) return launch_igemm<4, 1, 2, 2, VEC4, BF16, BKT, ABF>(p, s);
+    return launch_igemm<4, 1, 2, 1, VEC4, BF16, BKT, ABF>(p, s);
 }
 
 template <int TN_, int TC_, bool VEC4, bool BF16>
@@ -749,9 +798,10 @@ static void igemm_tile(const ConvKParams& p, int* bm, int* bn) {
 // K-tile depth: the bf16 path is load-latency bound per K-tile, so deeper tiles (more bytes in flight and
 // more MFMAs per barrier) are used whenever the channel count allows
 static int igemm_bk(const ConvKParams& p, bool vec, int precision) {
-    // Measured (profiles/r01_c notes): BKT = 64/128 is SLOWER on this kernel — the big strided layers are
-    // L2/HBM-bound on the fp32 gather and lose occupancy, the small ones are launch-bound.  Keep 32.
-    (void)p; (void)vec; (void)precision;
+    // bf16 activations: 16-byte slots of 8 elements => 64-deep tiles with the same thread mapping.
+    if (precision == STYLEX_BF16 && p.act_bf16 && p.Ck % 8 == 0 && vec) return 64;
+    // fp32 activations: BKT = 64/128 measured SLOWER (the big strided layers are L2/HBM-bound on the fp32
+    // gather and lose occupancy, the small ones are launch-bound).  Keep 32.
     return 32;
 }
 
@@ -762,7 +812,7 @@ static void igemm_splitk_plan(const ConvKParams& p, bool vec, int precision, int
     long blocks = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     int T = p.KH * p.KW;
     const int bk = igemm_bk(p, vec, precision);
-    int nk = vec ? (p.Ck == 4 ? (T + 7) / 8 : T * ((p.Ck + bk - 1) / bk)) : (T * p.Ck + BK - 1) / BK;
+    int nk = vec ? ((p.Ck == 4 || (bk == 64 && p.Ck == 8)) ? (T + 7) / 8 : T * ((p.Ck + bk - 1) / bk)) : (T * p.Ck + BK - 1) / BK;
     *ksplit = 1;
     *kt_per = nk;
     if (blocks >= 192 || nk < 16) return;
@@ -784,7 +834,7 @@ static bool igemm_vec_ok(const ConvKParams& p) {
 
 int64_t stylex_igemm_workspace_bytes(const ConvKParams& p, int precision) {
     int ks, per;
-    igemm_splitk_plan(p, p.Ck % 4 == 0, precision, &ks, &per);
+    igemm_splitk_plan(p, p.Ck % 4 == 0, precision == STYLEX_F32 ? STYLEX_F32 : STYLEX_BF16, &ks, &per);
     return ks > 1 ? (int64_t)ks * p.M * p.N * (int64_t)sizeof(float) : 0;
 }
 
@@ -809,8 +859,8 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
     int rc;
     if (precision == STYLEX_BF16) {
         const int bk = igemm_bk(p, vec, precision);
-        (void)bk;
-        rc = vec ? dispatch_igemm<true, true, 32>(p, s) : dispatch_igemm<false, true, 32>(p, s);
+        if (bk == 64) rc = dispatch_igemm<true, true, 64, true>(p, s);
+        else rc = vec ? dispatch_igemm<true, true, 32>(p, s) : dispatch_igemm<false, true, 32>(p, s);
     } else {
         rc = vec ? dispatch_igemm<true, false, 32>(p, s) : dispatch_igemm<false, false, 32>(p, s);
     }

@@ -49,16 +49,24 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* smem_base, int byte_off, 
     return r;
 }
 
-constexpr int TW = 32, TH = 8, HWD = TW + 2, NP = (TH + 2) * HWD;  // 8x32 pixel tile, 10x34 halo
-constexpr int PIX_ROW = 64;                                          // bytes per pixel row of a 32-channel panel
-// panel strides carry a 64-byte skew so that the two panels a 16-lane staging store touches fall on
-// different bank halves
-constexpr int DY_PANEL = 256 * PIX_ROW + 64;                         // 16 KiB (+skew)
-constexpr int X_PANEL = NP * PIX_ROW + 64;                           // 21.25 KiB (+skew)
-constexpr int X_OFF = 2 * DY_PANEL;
-constexpr int SMEM_BYTES = 2 * DY_PANEL + 2 * X_PANEL;               // 75.5 KiB -> 2 blocks / CU
+constexpr int PIX_ROW = 64;  // bytes per pixel row of a 32-channel panel
+// pixel tile: 8x32 (10x34 halo) or, for 16-pixel-wide images, 16x16 (18x18 halo)
+template <int TW>
+struct Geom {
+    static constexpr int TH = 256 / TW, HWD = TW + 2, NP = (TH + 2) * HWD;
+    // panel strides carry a 64-byte skew so that the two panels a 16-lane staging store touches fall on
+    // different bank halves
+    static constexpr int DY_PANEL = 256 * PIX_ROW + 64;  // 16 KiB (+skew)
+    static constexpr int X_PANEL = NP * PIX_ROW + 64;    // ~21 KiB (+skew)
+    static constexpr int X_OFF = 2 * DY_PANEL;
+    static constexpr int SMEM_BYTES = 2 * DY_PANEL + 2 * X_PANEL;  // ~75 KiB -> 2 blocks / CU
+};
 
+template <int TW, bool ABF>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams p) {
+    constexpr int TH = Geom<TW>::TH, HWD = Geom<TW>::HWD, NP = Geom<TW>::NP;
+    constexpr int DY_PANEL = Geom<TW>::DY_PANEL, X_PANEL = Geom<TW>::X_PANEL, X_OFF = Geom<TW>::X_OFF;
+    constexpr int KS_PER_ROW = TW / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
@@ -90,43 +98,95 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
         const int tt = tile - b * tiles_img;
         const int y0 = (tt / tiles_x) * TH, x0 = (tt % tiles_x) * TW;
 
-        // ---- stage dy tile: 256 px x 64 n (16 float4 per pixel), 16 float4 per thread
-        {
-            const int q = tid & 15;  // float4 index within the 64 channels
-            const int nn = n0 + q * 4;
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p.a2_scale && nn < N) sc = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn);
+        if (ABF) {
+            // bf16 activations: raw 16-byte slots (8 channels), 8 slots per 64-channel pixel row, no conversion
+            const int q = tid & 7;
+            {
+                const int nn = n0 + q * 8;
+                float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+                if (p.a2_scale && nn < N) {
+                    s0 = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn);
+                    s1 = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn + 4);
+                }
 #pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                int px = (tid >> 4) + 16 * it;
-                int y = y0 + px / TW, x = x0 + (px % TW);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nn < N && y < H && x < W) v = *reinterpret_cast<const float4*>(p.a2 + ((long)(b * H + y) * W + x) * N + nn);
-                uint2 h;
-                h.x = pack_bf16(v.x * sc.x, v.y * sc.y);
-                h.y = pack_bf16(v.z * sc.z, v.w * sc.w);
-                *reinterpret_cast<uint2*>(smem + (q >> 3) * DY_PANEL + px * PIX_ROW + (q & 7) * 8) = h;
+                for (int it = 0; it < 8; ++it) {
+                    int px = (tid >> 3) + 32 * it;
+                    int y = y0 + px / TW, x = x0 + (px % TW);
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (nn < N && y < H && x < W)
+                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.a2) + ((long)(b * H + y) * W + x) * N + nn);
+                    if (p.a2_scale) {
+                        float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
+                        v.x = pack_bf16(f0.x * s0.x, f0.y * s0.y); v.y = pack_bf16(f0.z * s0.z, f0.w * s0.w);
+                        v.z = pack_bf16(f1.x * s1.x, f1.y * s1.y); v.w = pack_bf16(f1.z * s1.z, f1.w * s1.w);
+                    }
+                    *reinterpret_cast<uint4*>(smem + (q >> 2) * DY_PANEL + px * PIX_ROW + (q & 3) * 16) = v;
+                }
             }
-        }
-        // ---- stage x halo: 340 px x 64 c
-        {
-            const int q = tid & 15;
-            const int cc = c0 + q * 4;
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p.a_scale && cc < C) sc = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+            {
+                const int cc = c0 + q * 8;
+                float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+                if (p.a_scale && cc < C) {
+                    s0 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+                    s1 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc + 4);
+                }
 #pragma unroll 4
-            for (int it = 0; it < (NP + 15) / 16; ++it) {
-                int hp = (tid >> 4) + 16 * it;
-                if (hp < NP) {
-                    int hh = hp / HWD, ww = hp - hh * HWD;
-                    int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                for (int it = 0; it < (NP + 31) / 32; ++it) {
+                    int hp = (tid >> 3) + 32 * it;
+                    if (hp < NP) {
+                        int hh = hp / HWD, ww = hp - hh * HWD;
+                        int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (cc < C && y >= 0 && y < H && x >= 0 && x < W)
+                            v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.a) + ((long)(b * H + y) * W + x) * C + cc);
+                        if (p.a_scale) {
+                            float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
+                            v.x = pack_bf16(f0.x * s0.x, f0.y * s0.y); v.y = pack_bf16(f0.z * s0.z, f0.w * s0.w);
+                            v.z = pack_bf16(f1.x * s1.x, f1.y * s1.y); v.w = pack_bf16(f1.z * s1.z, f1.w * s1.w);
+                        }
+                        *reinterpret_cast<uint4*>(smem + X_OFF + (q >> 2) * X_PANEL + hp * PIX_ROW + (q & 3) * 16) = v;
+                    }
+                }
+            }
+        } else {
+            // ---- stage dy tile: 256 px x 64 n (16 float4 per pixel), 16 float4 per thread
+            {
+                const int q = tid & 15;  // float4 index within the 64 channels
+                const int nn = n0 + q * 4;
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (p.a2_scale && nn < N) sc = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn);
+    #pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    int px = (tid >> 4) + 16 * it;
+                    int y = y0 + px / TW, x = x0 + (px % TW);
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (cc < C && y >= 0 && y < H && x >= 0 && x < W)
-                        v = *reinterpret_cast<const float4*>(p.a + ((long)(b * H + y) * W + x) * C + cc);
+                    if (nn < N && y < H && x < W) v = act_ld4(p.a2, ((long)(b * H + y) * W + x) * N + nn, p.act_bf16);
                     uint2 h;
                     h.x = pack_bf16(v.x * sc.x, v.y * sc.y);
                     h.y = pack_bf16(v.z * sc.z, v.w * sc.w);
-                    *reinterpret_cast<uint2*>(smem + X_OFF + (q >> 3) * X_PANEL + hp * PIX_ROW + (q & 7) * 8) = h;
+                    *reinterpret_cast<uint2*>(smem + (q >> 3) * DY_PANEL + px * PIX_ROW + (q & 7) * 8) = h;
+                }
+            }
+            // ---- stage x halo: 340 px x 64 c
+            {
+                const int q = tid & 15;
+                const int cc = c0 + q * 4;
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (p.a_scale && cc < C) sc = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+    #pragma unroll 4
+                for (int it = 0; it < (NP + 15) / 16; ++it) {
+                    int hp = (tid >> 4) + 16 * it;
+                    if (hp < NP) {
+                        int hh = hp / HWD, ww = hp - hh * HWD;
+                        int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (cc < C && y >= 0 && y < H && x >= 0 && x < W)
+                            v = act_ld4(p.a, ((long)(b * H + y) * W + x) * C + cc, p.act_bf16);
+                        uint2 h;
+                        h.x = pack_bf16(v.x * sc.x, v.y * sc.y);
+                        h.y = pack_bf16(v.z * sc.z, v.w * sc.w);
+                        *reinterpret_cast<uint2*>(smem + X_OFF + (q >> 3) * X_PANEL + hp * PIX_ROW + (q & 7) * 8) = h;
+                    }
                 }
             }
         }
@@ -137,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
         const char* b_base = smem + X_OFF + wc * X_PANEL + lane_off;
 #pragma unroll 2
         for (int ks = 0; ks < 16; ++ks) {
-            const int r = ks >> 1, pw0 = (ks & 1) * 16;
+            const int r = ks / KS_PER_ROW, pw0 = (ks % KS_PER_ROW) * 16;
             bf16x8 av = tr_read8(a_base, (r * TW + pw0) * PIX_ROW, PIX_ROW);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -169,15 +229,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
 bool stylex_wgrad_halo_applicable(const ConvKParams& p) {
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
     if (p.Hi != p.Ho || p.Wi != p.Wo) return false;
-    if (p.Ck % 4 != 0 || p.N % 4 != 0 || p.Wo < 32 || p.Ho < 8) return false;
+    if (p.Ck % 4 != 0 || p.N % 4 != 0 || p.Wo < 16 || p.Ho < 8 || (long)p.Ho * p.Wo < 256) return false;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.a2) & 15)) return false;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return false;
     if (p.a2_scale && (reinterpret_cast<uintptr_t>(p.a2_scale) & 15)) return false;
     return true;
 }
 
+static void tile_dims(const ConvKParams& p, int* tw, int* th) {
+    *tw = p.Wo >= 32 ? 32 : 16;
+    *th = 256 / *tw;
+}
+
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split) {
-    long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    int tw, th;
+    tile_dims(p, &tw, &th);
+    long tiles = (long)p.B * ((p.Wo + tw - 1) / tw) * ((p.Ho + th - 1) / th);
     long otiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64);
     long want = (512 + otiles - 1) / otiles;  // ~2 resident blocks per CU
     if (want > tiles) want = tiles;
@@ -187,20 +254,28 @@ void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_sp
     *splits = (int)((tiles + tps - 1) / tps);
 }
 
+template <int TW, bool ABF>
+static int launch_wgrad_halo(const ConvKParams& p, int blocks, hipStream_t s) {
+    auto k = conv3x3_wgrad_halo_kernel<TW, ABF>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Geom<TW>::SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), Geom<TW>::SMEM_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
 int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out) {
     int splits, tps;
     stylex_wgrad_halo_plan(p, &splits, &tps);
     p.split_len = tps;
     p.y = partial;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_halo_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
     int blocks = ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * splits;
-    hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3(blocks), dim3(256), SMEM_BYTES, s, p);
     *splits_out = splits;
-    return (int)hipGetLastError();
+    if (p.act_bf16 && p.Ck % 8 == 0 && p.N % 8 == 0)
+        return p.Wo >= 32 ? launch_wgrad_halo<32, true>(p, blocks, s) : launch_wgrad_halo<16, true>(p, blocks, s);
+    return p.Wo >= 32 ? launch_wgrad_halo<32, false>(p, blocks, s) : launch_wgrad_halo<16, false>(p, blocks, s);
 }

@@ -19,8 +19,8 @@ template <>
 struct Vec<4> {
     typedef float4 T;
     static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-    static __device__ __forceinline__ T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
-    static __device__ __forceinline__ void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ T ld(const void* p, long off, int bf) { return act_ld4(p, off, bf); }
+    static __device__ __forceinline__ void st(void* p, long off, T v, int bf) { act_st4(p, off, v, bf); }
     static __device__ __forceinline__ void fma(T& a, float w, T x) {
         a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);
     }
@@ -29,8 +29,8 @@ template <>
 struct Vec<1> {
     typedef float T;
     static __device__ __forceinline__ T zero() { return 0.f; }
-    static __device__ __forceinline__ T ld(const float* p) { return *p; }
-    static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+    static __device__ __forceinline__ T ld(const void* p, long off, int bf) { return act_ld1(p, off, bf); }
+    static __device__ __forceinline__ void st(void* p, long off, T v, int bf) { act_st1(p, off, v, bf); }
     static __device__ __forceinline__ void fma(T& a, float w, T x) { a = fmaf(w, x, a); }
 };
 
@@ -58,7 +58,7 @@ __device__ __forceinline__ float up_coef(int o, int i, int n) {
 }
 
 template <int V>
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+__global__ void upsample2x_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int C, int bf) {
     const int cv = C / V;
     const long total = (long)B * 2 * H * 2 * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -71,22 +71,22 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
         float fh, fw;
         up_rule(oh, H, hl, hh, fh);
         up_rule(ow, W, wl, wh_, fw);
-        const float* base = x + (long)b * H * W * C + c;
+        const long base = (long)b * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
         // same association as the reference kernel: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
         typename Vec<V>::T r0 = Vec<V>::zero(), r1 = Vec<V>::zero();
-        Vec<V>::fma(r0, 1.f - fw, Vec<V>::ld(base + ((long)hl * W + wl) * C));
-        Vec<V>::fma(r0, fw, Vec<V>::ld(base + ((long)hl * W + wh_) * C));
-        Vec<V>::fma(r1, 1.f - fw, Vec<V>::ld(base + ((long)hh * W + wl) * C));
-        Vec<V>::fma(r1, fw, Vec<V>::ld(base + ((long)hh * W + wh_) * C));
+        Vec<V>::fma(r0, 1.f - fw, Vec<V>::ld(x, base + ((long)hl * W + wl) * C, bf));
+        Vec<V>::fma(r0, fw, Vec<V>::ld(x, base + ((long)hl * W + wh_) * C, bf));
+        Vec<V>::fma(r1, 1.f - fw, Vec<V>::ld(x, base + ((long)hh * W + wl) * C, bf));
+        Vec<V>::fma(r1, fw, Vec<V>::ld(x, base + ((long)hh * W + wh_) * C, bf));
         Vec<V>::fma(acc, 1.f - fh, r0);
         Vec<V>::fma(acc, fh, r1);
-        Vec<V>::st(y + pix * C + c, acc);
+        Vec<V>::st(y, pix * C + c, acc, bf);
     }
 }
 
 template <int V>
-__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+__global__ void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C, int bf) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -95,7 +95,7 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
         int iw = (int)(pix % W);
         int ih = (int)((pix / W) % H);
         int b = (int)(pix / ((long)H * W));
-        const float* base = dy + (long)b * 4 * H * W * C + c;
+        const long base = (long)b * 4 * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
 #pragma unroll
         for (int a = -1; a <= 2; ++a) {
@@ -109,10 +109,10 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
                 if (ow < 0 || ow >= 2 * W) continue;
                 float cw = up_coef(ow, iw, W);
                 if (cw == 0.f) continue;
-                Vec<V>::fma(acc, ch * cw, Vec<V>::ld(base + ((long)oh * 2 * W + ow) * C));
+                Vec<V>::fma(acc, ch * cw, Vec<V>::ld(dy, base + ((long)oh * 2 * W + ow) * C, bf));
             }
         }
-        Vec<V>::st(dx + pix * C + c, acc);
+        Vec<V>::st(dx, pix * C + c, acc, bf);
     }
 }
 
@@ -120,7 +120,7 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 template <int V>
-__global__ void blur3x3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+__global__ void blur3x3_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int C, int bf) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     const float f[3] = {1.f, 2.f, 1.f};
@@ -130,7 +130,7 @@ __global__ void blur3x3_fwd_kernel(const float* __restrict__ x, float* __restric
         int w = (int)(pix % W);
         int h = (int)((pix / W) % H);
         int b = (int)(pix / ((long)H * W));
-        const float* base = x + (long)b * H * W * C + c;
+        const long base = (long)b * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
 #pragma unroll
         for (int dh = -1; dh <= 1; ++dh) {
@@ -138,10 +138,10 @@ __global__ void blur3x3_fwd_kernel(const float* __restrict__ x, float* __restric
 #pragma unroll
             for (int dw = -1; dw <= 1; ++dw) {
                 int ww = reflect1(w + dw, W);
-                Vec<V>::fma(acc, f[dh + 1] * f[dw + 1] * (1.f / 16.f), Vec<V>::ld(base + ((long)hh * W + ww) * C));
+                Vec<V>::fma(acc, f[dh + 1] * f[dw + 1] * (1.f / 16.f), Vec<V>::ld(x, base + ((long)hh * W + ww) * C, bf));
             }
         }
-        Vec<V>::st(y + pix * C + c, acc);
+        Vec<V>::st(y, pix * C + c, acc, bf);
     }
 }
 
@@ -155,7 +155,7 @@ __device__ __forceinline__ float blur_coef(int o, int i, int n) {
 }
 
 template <int V>
-__global__ void blur3x3_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+__global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C, int bf) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -164,7 +164,7 @@ __global__ void blur3x3_bwd_kernel(const float* __restrict__ dy, float* __restri
         int w = (int)(pix % W);
         int h = (int)((pix / W) % H);
         int b = (int)(pix / ((long)H * W));
-        const float* base = dy + (long)b * H * W * C + c;
+        const long base = (long)b * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
 #pragma unroll
         for (int a = -1; a <= 1; ++a) {
@@ -176,18 +176,19 @@ __global__ void blur3x3_bwd_kernel(const float* __restrict__ dy, float* __restri
                 int ow = w + e;
                 if (ow < 0 || ow >= W) continue;
                 float cw = blur_coef(ow, w, W);
-                Vec<V>::fma(acc, ch * cw * (1.f / 16.f), Vec<V>::ld(base + ((long)oh * W + ow) * C));
+                Vec<V>::fma(acc, ch * cw * (1.f / 16.f), Vec<V>::ld(dy, base + ((long)oh * W + ow) * C, bf));
             }
         }
-        Vec<V>::st(dx + pix * C + c, acc);
+        Vec<V>::st(dx, pix * C + c, acc, bf);
     }
 }
 
 // ---- bias (+ transposed noise) + LeakyReLU(0.2) ----------------------------------------------
 template <int V>
-__global__ void bias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+__global__ void bias_act_fwd_kernel(const void* __restrict__ x, const float* __restrict__ bias,
                                     const float* __restrict__ noise, long ns, const float* __restrict__ nw,
-                                    const float* __restrict__ nb, float* __restrict__ y, int B, int H, int W, int C) {
+                                    const float* __restrict__ nb, void* __restrict__ y, int B, int H, int W, int C,
+                                    int bf) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -201,7 +202,7 @@ __global__ void bias_act_fwd_kernel(const float* __restrict__ x, const float* __
             nz = noise[((long)b * ns + w) * ns + h];  // (sic) spatially transposed, stylex_train.py:696-698
         }
         float v[V];
-        *reinterpret_cast<typename Vec<V>::T*>(v) = Vec<V>::ld(x + pix * C + c);
+        *reinterpret_cast<typename Vec<V>::T*>(v) = Vec<V>::ld(x, pix * C + c, bf);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float t = v[e];
@@ -209,21 +210,21 @@ __global__ void bias_act_fwd_kernel(const float* __restrict__ x, const float* __
             if (noise) t += fmaf(nz, nw[c + e], nb[c + e]);
             v[e] = t > 0.f ? t : 0.2f * t;
         }
-        Vec<V>::st(y + pix * C + c, *reinterpret_cast<typename Vec<V>::T*>(v));
+        Vec<V>::st(y, pix * C + c, *reinterpret_cast<typename Vec<V>::T*>(v), bf);
     }
 }
 
 template <int V>
-__global__ void bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
-                                    long n) {
+__global__ void bias_act_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ y, void* __restrict__ dx,
+                                    long n, int bf) {
     const long total = n / V;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float g[V], o[V];
-        *reinterpret_cast<typename Vec<V>::T*>(g) = Vec<V>::ld(dy + i * V);
-        *reinterpret_cast<typename Vec<V>::T*>(o) = Vec<V>::ld(y + i * V);
+        *reinterpret_cast<typename Vec<V>::T*>(g) = Vec<V>::ld(dy, i * V, bf);
+        *reinterpret_cast<typename Vec<V>::T*>(o) = Vec<V>::ld(y, i * V, bf);
 #pragma unroll
         for (int e = 0; e < V; ++e) g[e] = o[e] > 0.f ? g[e] : 0.2f * g[e];
-        Vec<V>::st(dx + i * V, *reinterpret_cast<typename Vec<V>::T*>(g));
+        Vec<V>::st(dx, i * V, *reinterpret_cast<typename Vec<V>::T*>(g), bf);
     }
 }
 
@@ -276,49 +277,52 @@ inline bool vec_ok(int C, const void* a, const void* b) {
 
 extern "C" {
 
-int stylex_upsample2x_bilinear_fwd(const float* x, float* y, const int64_t* sh, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+#define EW_ARGS const int64_t* sh, int act_dtype, void* stream
+#define EW_UNPACK                                                     \
+    hipStream_t s = (hipStream_t)stream;                               \
+    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3]; \
+    int bf = act_dtype == 1;                                           \
+    if (act_dtype != 0 && act_dtype != 1) return STYLEX_EINVAL;
+
+int stylex_upsample2x_bilinear_fwd(const void* x, void* y, EW_ARGS) {
+    EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
-    LAUNCH_EW(upsample2x_fwd_kernel, (long)B * 4 * H * W * C, x, y, x, y, B, H, W, C);
+    LAUNCH_EW(upsample2x_fwd_kernel, (long)B * 4 * H * W * C, x, y, x, y, B, H, W, C, bf);
 }
-int stylex_upsample2x_bilinear_bwd(const float* dy, float* dx, const int64_t* sh, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, EW_ARGS) {
+    EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
-    LAUNCH_EW(upsample2x_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C);
+    LAUNCH_EW(upsample2x_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
 }
-int stylex_blur3x3_reflect_fwd(const float* x, float* y, const int64_t* sh, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+int stylex_blur3x3_reflect_fwd(const void* x, void* y, EW_ARGS) {
+    EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
-    LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C);
+    LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf);
 }
-int stylex_blur3x3_reflect_bwd(const float* dy, float* dx, const int64_t* sh, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, EW_ARGS) {
+    EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
-    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C);
+    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
 }
-int stylex_bias_act_fwd(const float* x, const float* bias, const float* noise, int64_t noise_stride,
-                        const float* noise_w, const float* noise_b, float* y, const int64_t* sh, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    int B = (int)sh[0], H = (int)sh[1], W = (int)sh[2], C = (int)sh[3];
+int stylex_bias_act_fwd(const void* x, const float* bias, const float* noise, int64_t noise_stride,
+                        const float* noise_w, const float* noise_b, void* y, EW_ARGS) {
+    EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
     if (noise && (!noise_w || !noise_b || noise_stride < H || noise_stride < W)) return STYLEX_EINVAL;
     LAUNCH_EW(bias_act_fwd_kernel, (long)B * H * W * C, x, y, x, bias, noise, (long)noise_stride, noise_w, noise_b, y, B,
-              H, W, C);
+              H, W, C, bf);
 }
-int stylex_bias_act_bwd(const float* dy, const float* y, float* dx, const int64_t* sh, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+int stylex_bias_act_bwd(const void* dy, const void* y, void* dx, EW_ARGS) {
+    EW_UNPACK
+    (void)B; (void)H; (void)W; (void)C;
     long n = (long)sh[0] * sh[1] * sh[2] * sh[3];
     if (n <= 0) return STYLEX_EINVAL;
     bool v = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
     if (v)
-        hipLaunchKernelGGL(bias_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, s, dy, y, dx, n);
+        hipLaunchKernelGGL(bias_act_bwd_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, s, dy, y, dx, n, bf);
     else
-        hipLaunchKernelGGL(bias_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, s, dy, y, dx, n);
+        hipLaunchKernelGGL(bias_act_bwd_kernel<1>, dim3(grid_for(n)), dim3(256), 0, s, dy, y, dx, n, bf);
     return (int)hipGetLastError();
 }
 int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* sh, void* stream) {

@@ -80,25 +80,15 @@ __device__ __forceinline__ Geo make_geo(int HW, int C, int nchunks) {
     return g;
 }
 
-__device__ __forceinline__ float4 ld4(const float* p, int c, int C) {
-    if (c + 3 < C) return *reinterpret_cast<const float4*>(p);
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int e = 0; e < 4 && c + e < C; ++e) t[e] = p[e];
-    return make_float4(t[0], t[1], t[2], t[3]);
-}
-__device__ __forceinline__ void st4(float* p, float4 v, int c, int C) {
-    if (c + 3 < C) {
-        *reinterpret_cast<float4*>(p) = v;
-        return;
-    }
-    float t[4] = {v.x, v.y, v.z, v.w};
-    for (int e = 0; e < 4 && c + e < C; ++e) p[e] = t[e];
-}
+// activation loads/stores (fp32 or bf16 by runtime flag); C % 4 == 0 is checked on the host
+__device__ __forceinline__ float4 ld4(const void* p, long off, int bf) { return act_ld4(p, off, bf); }
+__device__ __forceinline__ void st4(void* p, long off, float4 v, int bf) { act_st4(p, off, v, bf); }
+__device__ __forceinline__ float4 ldp4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // dx = dy * scale * (lrelu ? (y > 0 ? 1 : 0.2) : 1);  partial[b][chunk][c] = sum_pixels dx
-__global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                           float* __restrict__ dx, float* __restrict__ partial, int HW,
-                                                           int C, int nchunks, int lrelu, float scale) {
+__global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const void* __restrict__ dy, const void* __restrict__ y,
+                                                           void* __restrict__ dx, float* __restrict__ partial, int HW,
+                                                           int C, int nchunks, int lrelu, float scale, int bf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Geo g = make_geo(HW, C, nchunks);
     Acc<1> a;
@@ -108,16 +98,16 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const float* __restr
         const long base = (long)g.b * HW;
         for (long p = g.p_begin + g.prow; p < g.p_end; p += g.rpp) {
             const long o = (base + p) * C + c;
-            float4 gv = ld4(dy + o, c, C);
+            float4 gv = ld4(dy, o, bf);
             gv.x *= scale; gv.y *= scale; gv.z *= scale; gv.w *= scale;
             if (lrelu) {
-                float4 yv = ld4(y + o, c, C);
+                float4 yv = ld4(y, o, bf);
                 gv.x = yv.x > 0.f ? gv.x : 0.2f * gv.x;
                 gv.y = yv.y > 0.f ? gv.y : 0.2f * gv.y;
                 gv.z = yv.z > 0.f ? gv.z : 0.2f * gv.z;
                 gv.w = yv.w > 0.f ? gv.w : 0.2f * gv.w;
             }
-            if (dx) st4(dx + o, gv, c, C);
+            if (dx) st4(dx, o, gv, bf);
             a.v[0].x += gv.x; a.v[0].y += gv.y; a.v[0].z += gv.z; a.v[0].w += gv.w;
         }
     }
@@ -130,11 +120,11 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const float* __restr
 //   S0[b,c] = sum gz * (d*z)   with d*z = lrelu^-1(y) - noise   => grad wrt d is S0 / d
 //   S1[b,c] = sum gz * noise_plane[b,w,h]     => grad wrt noise weight (summed over b by the caller)
 //   S2[b,c] = sum gz                          => grad wrt noise bias
-__global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+__global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const void* __restrict__ gy, const void* __restrict__ y,
                                                              const float* __restrict__ noise, int ns,
                                                              const float* __restrict__ nw, const float* __restrict__ nb,
-                                                             float* __restrict__ gz, float* __restrict__ partial, int H,
-                                                             int W, int C, int nchunks, int lrelu) {
+                                                             void* __restrict__ gz, float* __restrict__ partial, int H,
+                                                             int W, int C, int nchunks, int lrelu, int bf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W;
     Geo g = make_geo(HW, C, nchunks);
@@ -144,14 +134,14 @@ __global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const float* __res
     if (g.active && c < C) {
         float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = w4;
         if (noise) {
-            w4 = ld4(nw + c, c, C);
-            b4 = ld4(nb + c, c, C);
+            w4 = ldp4(nw + c);
+            b4 = ldp4(nb + c);
         }
         const long base = (long)g.b * HW;
         for (long p = g.p_begin + g.prow; p < g.p_end; p += g.rpp) {
             const long o = (base + p) * C + c;
-            float4 gv = ld4(gy + o, c, C);
-            float4 yv = ld4(y + o, c, C);
+            float4 gv = ld4(gy, o, bf);
+            float4 yv = ld4(y, o, bf);
             float nz = 0.f;
             if (noise) {
                 int h = (int)(p / W), w = (int)(p - (long)h * W);
@@ -164,7 +154,7 @@ __global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const float* __res
                 gv.z = yv.z > 0.f ? gv.z : 0.2f * gv.z; t.z = yv.z > 0.f ? yv.z : 5.f * yv.z;
                 gv.w = yv.w > 0.f ? gv.w : 0.2f * gv.w; t.w = yv.w > 0.f ? yv.w : 5.f * yv.w;
             }
-            st4(gz + o, gv, c, C);
+            st4(gz, o, gv, bf);
             a.v[0].x += gv.x * (t.x - (nz * w4.x + b4.x));
             a.v[0].y += gv.y * (t.y - (nz * w4.y + b4.y));
             a.v[0].z += gv.z * (t.z - (nz * w4.z + b4.z));
@@ -178,25 +168,25 @@ __global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const float* __res
 }
 
 // gx = t * s[b,c];  partial[b][chunk][c] = sum_pixels x * t     (grad wrt the modulation scale)
-__global__ __launch_bounds__(NT) void scale_reduce_kernel(const float* __restrict__ x, const float* __restrict__ t,
-                                                         const float* __restrict__ s, float* __restrict__ gx,
-                                                         float* __restrict__ partial, int HW, int C, int nchunks) {
+__global__ __launch_bounds__(NT) void scale_reduce_kernel(const void* __restrict__ x, const void* __restrict__ t,
+                                                         const float* __restrict__ s, void* __restrict__ gx,
+                                                         float* __restrict__ partial, int HW, int C, int nchunks, int bf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Geo g = make_geo(HW, C, nchunks);
     Acc<1> a;
     a.zero();
     const int c = g.cv * 4;
     if (g.active && c < C) {
-        float4 s4 = ld4(s + (long)g.b * C + c, c, C);
+        float4 s4 = ldp4(s + (long)g.b * C + c);
         const long base = (long)g.b * HW;
         for (long p = g.p_begin + g.prow; p < g.p_end; p += g.rpp) {
             const long o = (base + p) * C + c;
-            float4 tv = ld4(t + o, c, C);
-            float4 xv = ld4(x + o, c, C);
+            float4 tv = ld4(t, o, bf);
+            float4 xv = ld4(x, o, bf);
             a.v[0].x += xv.x * tv.x; a.v[0].y += xv.y * tv.y; a.v[0].z += xv.z * tv.z; a.v[0].w += xv.w * tv.w;
             if (gx) {
                 tv.x *= s4.x; tv.y *= s4.y; tv.z *= s4.z; tv.w *= s4.w;
-                st4(gx + o, tv, c, C);
+                st4(gx, o, tv, bf);
             }
         }
     }
@@ -230,33 +220,36 @@ int stylex_reduce_chunks(const int64_t* sh) {
     return (int)n;
 }
 
-int stylex_act_bwd_reduce(const float* dy, const float* y, float* dx, float* partial, const int64_t* sh, int nchunks,
-                          int lrelu, float scale, void* stream) {
+int stylex_act_bwd_reduce(const void* dy, const void* y, void* dx, float* partial, const int64_t* sh, int nchunks,
+                          int lrelu, float scale, int act_dtype, void* stream) {
+    if (act_dtype != 0 && act_dtype != 1) return STYLEX_EINVAL;
     if (!dy || !partial || !ok_shape(sh, nchunks) || (lrelu && !y)) return STYLEX_EINVAL;
     int HW = (int)(sh[1] * sh[2]), C = (int)sh[3];
     hipLaunchKernelGGL(act_bwd_reduce_kernel, dim3(nchunks, (unsigned)sh[0]), dim3(NT), reduce_smem(C, 1),
-                       (hipStream_t)stream, dy, y, dx, partial, HW, C, nchunks, lrelu, scale);
+                       (hipStream_t)stream, dy, y, dx, partial, HW, C, nchunks, lrelu, scale, act_dtype);
     return (int)hipGetLastError();
 }
 
-int stylex_modconv_bwd_prep(const float* gy, const float* y, const float* noise, int64_t noise_stride,
-                            const float* noise_w, const float* noise_b, float* gz, float* partial, const int64_t* sh,
-                            int nchunks, int lrelu, void* stream) {
+int stylex_modconv_bwd_prep(const void* gy, const void* y, const float* noise, int64_t noise_stride,
+                            const float* noise_w, const float* noise_b, void* gz, float* partial, const int64_t* sh,
+                            int nchunks, int lrelu, int act_dtype, void* stream) {
+    if (act_dtype != 0 && act_dtype != 1) return STYLEX_EINVAL;
     if (!gy || !y || !gz || !partial || !ok_shape(sh, nchunks)) return STYLEX_EINVAL;
     if (noise && (!noise_w || !noise_b || noise_stride < sh[1] || noise_stride < sh[2])) return STYLEX_EINVAL;
     int C = (int)sh[3];
     hipLaunchKernelGGL(modconv_bwd_prep_kernel, dim3(nchunks, (unsigned)sh[0]), dim3(NT), reduce_smem(C, 3),
                        (hipStream_t)stream, gy, y, noise, (int)noise_stride, noise_w, noise_b, gz, partial, (int)sh[1],
-                       (int)sh[2], C, nchunks, lrelu);
+                       (int)sh[2], C, nchunks, lrelu, act_dtype);
     return (int)hipGetLastError();
 }
 
-int stylex_scale_reduce(const float* x, const float* t, const float* s, float* gx, float* partial, const int64_t* sh,
-                        int nchunks, void* stream) {
+int stylex_scale_reduce(const void* x, const void* t, const float* s, void* gx, float* partial, const int64_t* sh,
+                        int nchunks, int act_dtype, void* stream) {
+    if (act_dtype != 0 && act_dtype != 1) return STYLEX_EINVAL;
     if (!x || !t || !s || !partial || !ok_shape(sh, nchunks)) return STYLEX_EINVAL;
     int HW = (int)(sh[1] * sh[2]), C = (int)sh[3];
     hipLaunchKernelGGL(scale_reduce_kernel, dim3(nchunks, (unsigned)sh[0]), dim3(NT), reduce_smem(C, 1),
-                       (hipStream_t)stream, x, t, s, gx, partial, HW, C, nchunks);
+                       (hipStream_t)stream, x, t, s, gx, partial, HW, C, nchunks, act_dtype);
     return (int)hipGetLastError();
 }
 

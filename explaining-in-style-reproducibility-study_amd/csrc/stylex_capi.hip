@@ -117,8 +117,9 @@ int stylex_timing_report(int cls, int64_t* launches, double* total_ms, double* t
 
 int stylex_pack_weight(const float* w, void* wf, void* wb, const int64_t* sh, int precision, void* stream) {
     if (!w || sh[0] < 1 || sh[1] < 1 || sh[2] < 1 || sh[3] < 1) return STYLEX_EINVAL;
-    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
-    return stylex_launch_pack(w, wf, wb, (int)sh[0], (int)sh[1], (int)(sh[2] * sh[3]), precision, (hipStream_t)stream);
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
+    return stylex_launch_pack(w, wf, wb, (int)sh[0], (int)sh[1], (int)(sh[2] * sh[3]),
+                              precision == STYLEX_F32 ? STYLEX_F32 : STYLEX_BF16, (hipStream_t)stream);
 }
 
 static void fwd_params(ConvKParams& p, const int64_t* sh) {
@@ -152,20 +153,23 @@ int64_t stylex_conv2d_workspace_bytes(const int64_t* sh, int which, int precisio
         bwd_data_params(p, sh);
         p.transposed = 1;
     }
+    p.act_bf16 = precision == STYLEX_BF16_ACT;
     return stylex_igemm_workspace_bytes(p, precision);
 }
 
-int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* sh, int flags,
+int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* sh, int flags,
                       const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                       void* stream) {
     if (!x || !w_fwd || !y || !conv_shape_ok(sh)) return STYLEX_EINVAL;
-    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
     ConvKParams p;
     fwd_params(p, sh);
-    p.a = x;
+    p.a = (const float*)x;
     p.w = w_fwd;
-    p.y = y;
+    p.y = (float*)y;
     p.flags = flags;
+    p.act_bf16 = precision == STYLEX_BF16_ACT;
+    if (p.act_bf16) precision = STYLEX_BF16;
     if (epi) {
         p.a_scale = epi->in_scale;
         p.bias = epi->bias;
@@ -174,7 +178,7 @@ int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t
         p.noise_stride = (int)epi->noise_stride;
         p.noise_w = epi->noise_w;
         p.noise_b = epi->noise_b;
-        p.residual = epi->residual;
+        p.residual = (const float*)epi->residual;
         p.res_scale = epi->res_scale;
     }
     if ((flags & STYLEX_EPI_BIAS) && !p.bias) return STYLEX_EINVAL;
@@ -187,17 +191,19 @@ int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const int64_t* sh, int flags,
+int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const int64_t* sh, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                            void* stream) {
     if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
-    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
     if (flags & ~(STYLEX_EPI_OSCALE)) return STYLEX_EINVAL;
     ConvKParams p;
     bwd_data_params(p, sh);
-    p.a = dy;
+    p.a = (const float*)dy;
     p.w = w_bwd;
-    p.y = dx;
+    p.y = (float*)dx;
+    p.act_bf16 = precision == STYLEX_BF16_ACT;
+    if (p.act_bf16) precision = STYLEX_BF16;
     if (precision == STYLEX_BF16 && p.KH == 3 && p.stride == 1 && p.pad == 1) {
         // dx = conv3x3(dy, flipped taps): forward-gather form, eligible for the LDS-halo kernel
         ConvKParams q = p;
@@ -251,7 +257,7 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
     int tn, tc, splits;
     long len;
     stylex_wgrad_plan(p, &tn, &tc, &splits, &len);
-    if (p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Wo >= 32 && p.Ho >= 8) {  // halo plan may use more splits
+    if (p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Wo >= 16 && p.Ho >= 8) {  // halo plan may use more splits
         int hs, tps;
         stylex_wgrad_halo_plan(p, &hs, &tps);
         if (hs > splits) splits = hs;
@@ -259,18 +265,20 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
     return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float);
 }
 
-int stylex_conv2d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes,
+int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
                              const int64_t* sh, const float* x_scale, const float* dy_scale, int precision,
                              void* stream) {
     if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh)) return STYLEX_EINVAL;
-    if (precision != STYLEX_F32 && precision != STYLEX_BF16) return STYLEX_EINVAL;
+    if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
     if (workspace_bytes < stylex_conv2d_bwd_weight_workspace_bytes(sh)) return STYLEX_EWORKSPACE;
     ConvKParams p;
     wgrad_params(p, sh);
-    p.a = x;
+    p.a = (const float*)x;
     p.a_scale = x_scale;
-    p.a2 = dy;
+    p.a2 = (const float*)dy;
     p.a2_scale = dy_scale;
+    p.act_bf16 = precision == STYLEX_BF16_ACT;
+    if (p.act_bf16) precision = STYLEX_BF16;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW;
     ScopedTimer tm(2, flops, (hipStream_t)stream);
     return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/stylex_hip.h"
+#include "act_io.h"
 
 // GEMM-view of one convolution launch.  "source" = gathered activation tensor
 // [B][Hi][Wi][Ck] (x for fprop/wgrad, dy for dgrad); "dest" = [B][Ho][Wo][N].
@@ -25,6 +26,7 @@ struct ConvKParams {
     int B, Hi, Wi, Ck, N, KH, KW, Ho, Wo, stride, pad;
     int transposed;   // 0: forward gather  ih = oh*s + kh - p ; 1: data-gradient gather ih = (oh + p - kh)/s
     int phase_major;  // rows ordered by (oh&1, ow&1) first (transposed stride-2 only)
+    int act_bf16;     // activation tensors (a, a2, y, residual) are bf16 instead of fp32 (STYLEX_BF16_ACT)
     int flip_taps;    // halo kernel: read weight tap 8-t for compute tap t (data gradient of a 3x3/s1/p1 conv)
     int M;            // B*Ho*Wo
     int flags;

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylex_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16_ACT = 0, 1, 2  # BF16_ACT: bf16 MFMA + bf16 activation tensors in HBM
 EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL = 1, 2, 4, 8, 16
 
 _c_f = ctypes.c_void_p  # device pointers travel as void*
@@ -47,19 +47,21 @@ SIGNATURES = {
     "stylex_conv2d_bwd_weight_workspace_bytes": (ctypes.c_int64, [_i64p]),
     "stylex_conv2d_bwd_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p, _c_f, _c_f,
                                                 ctypes.c_int, ctypes.c_void_p]),
-    "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
-    "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
-    "stylex_blur3x3_reflect_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
-    "stylex_blur3x3_reflect_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
-    "stylex_bias_act_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
-    "stylex_bias_act_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_reflect_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_reflect_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_bias_act_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _i64p, ctypes.c_int,
+                                           ctypes.c_void_p]),
+    "stylex_bias_act_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_rowwise_sumsq": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_reduce_chunks": (ctypes.c_int, [_i64p]),
     "stylex_act_bwd_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-                                             ctypes.c_void_p]),
+                                             ctypes.c_int, ctypes.c_void_p]),
     "stylex_modconv_bwd_prep": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _c_f, _i64p,
-                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double)]),
@@ -124,11 +126,29 @@ def is_cl(t):
     return t.is_contiguous(memory_format=torch.channels_last)
 
 
-def to_cl(t):
-    """Logical NCHW, physical NHWC fp32 — the layout every kernel reads."""
-    if t.dtype != torch.float32:
+def act_dtype(precision):
+    """Storage type of activation tensors for a precision mode."""
+    return torch.bfloat16 if precision == BF16_ACT else torch.float32
+
+
+def to_cl(t, dtype=None):
+    """Logical NCHW, physical NHWC — the layout every kernel reads; optionally cast to `dtype`."""
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    elif t.dtype not in (torch.float32, torch.bfloat16):
         t = t.float()
     return t.contiguous(memory_format=torch.channels_last)
+
+
+def _adt(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _f32(t):
+    """Per-channel / per-sample parameter vectors are always fp32 on the device side."""
+    if t is None:
+        return None
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
 def conv_shape(x_shape, w_shape, stride, pad):
@@ -140,8 +160,8 @@ def conv_shape(x_shape, w_shape, stride, pad):
     return (b, h, w, c, n, kh, kw, stride, pad, ho, wo)
 
 
-def empty_cl(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
+def empty_cl(shape, like, dtype=None):
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device, memory_format=torch.channels_last)
 
 
 _PACK_CACHE = {}
@@ -170,7 +190,7 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     if w.dtype != torch.float32:
         w = w.float()
     n, c, kh, kw = w.shape
-    dt = torch.bfloat16 if precision == BF16 else torch.float32
+    dt = torch.float32 if precision == F32 else torch.bfloat16
     wf = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_fwd else None
     wb = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_bwd else None
     _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
@@ -191,39 +211,43 @@ def _split_workspace(lib, shp, which, precision, like):
 
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
                noise_w=None, noise_b=None, residual=None, res_scale=1.0):
-    """x: channels_last [B,C,H,W]; w: OIHW parameter.  Returns channels_last [B,N,Ho,Wo]."""
+    """x: channels_last [B,C,H,W] in the precision's activation dtype; w: OIHW parameter.
+    Returns channels_last [B,N,Ho,Wo] of the same dtype."""
     lib = _ensure_device(x)
-    assert is_cl(x) and x.dtype == torch.float32
+    adt = act_dtype(precision)
+    assert is_cl(x) and x.dtype == adt, (x.dtype, adt)
     sh = conv_shape(x.shape, w.shape, stride, pad)
     wf, _ = pack_weight(w, True, False, precision)
-    y = empty_cl((sh[0], sh[4], sh[9], sh[10]), x)
+    y = empty_cl((sh[0], sh[4], sh[9], sh[10]), x, adt)
     flags = 0
     epi = ConvEpilogue()
     keep = []
     if in_scale is not None:
-        in_scale = in_scale.contiguous()
+        in_scale = _f32(in_scale)
         keep.append(in_scale)
         epi.in_scale = in_scale.data_ptr()
     if bias is not None:
+        bias = _f32(bias)
+        keep.append(bias)
         flags |= EPI_BIAS
         epi.bias = bias.data_ptr()
     if lrelu:
         flags |= EPI_LRELU
     if out_scale is not None:
-        out_scale = out_scale.contiguous()
+        out_scale = _f32(out_scale)
         keep.append(out_scale)
         flags |= EPI_OSCALE
         epi.out_scale = out_scale.data_ptr()
     if noise is not None:
-        noise = noise.contiguous()
-        keep.append(noise)
+        noise, noise_w, noise_b = _f32(noise), _f32(noise_w), _f32(noise_b)
+        keep += [noise, noise_w, noise_b]
         flags |= EPI_NOISE
         epi.noise = noise.data_ptr()
         epi.noise_stride = noise.shape[1]
         epi.noise_w = noise_w.data_ptr()
         epi.noise_b = noise_b.data_ptr()
     if residual is not None:
-        assert is_cl(residual) and residual.shape == y.shape
+        assert is_cl(residual) and residual.shape == y.shape and residual.dtype == adt
         flags |= EPI_RESIDUAL
         epi.residual = residual.data_ptr()
         epi.res_scale = res_scale
@@ -236,18 +260,18 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
 
 def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_scale=None):
     lib = _ensure_device(dy)
-    assert is_cl(dy) and dy.dtype == torch.float32
+    adt = act_dtype(precision)
+    assert is_cl(dy) and dy.dtype == adt, (dy.dtype, adt)
     sh = conv_shape(x_shape, w.shape, stride, pad)
     assert tuple(dy.shape) == (sh[0], sh[4], sh[9], sh[10]), (dy.shape, sh)
     _, wb = pack_weight(w, False, True, precision)
-    dx = empty_cl(tuple(x_shape), dy)
+    dx = empty_cl(tuple(x_shape), dy, adt)
     epi = ConvEpilogue()
     flags = 0
+    in_scale, out_scale = _f32(in_scale), _f32(out_scale)
     if in_scale is not None:
-        in_scale = in_scale.contiguous()
         epi.in_scale = in_scale.data_ptr()
     if out_scale is not None:
-        out_scale = out_scale.contiguous()
         flags |= EPI_OSCALE
         epi.out_scale = out_scale.data_ptr()
     shp = _shape(*sh)
@@ -259,7 +283,8 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
 
 def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None):
     lib = _ensure_device(x)
-    assert is_cl(x) and is_cl(dy)
+    adt = act_dtype(precision)
+    assert is_cl(x) and is_cl(dy) and x.dtype == adt and dy.dtype == adt, (x.dtype, dy.dtype, adt)
     sh = conv_shape(x.shape, w_shape, stride, pad)
     shp = _shape(*sh)
     nbytes = lib.stylex_conv2d_bwd_weight_workspace_bytes(shp)
@@ -267,10 +292,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
         raise StylexHipError("bad wgrad shape %r" % (sh,))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
-    if x_scale is not None:
-        x_scale = x_scale.contiguous()
-    if dy_scale is not None:
-        dy_scale = dy_scale.contiguous()
+    x_scale, dy_scale = _f32(x_scale), _f32(dy_scale)
     _check(lib.stylex_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, _ptr(x_scale),
                                         _ptr(dy_scale), precision, _stream()), "stylex_conv2d_bwd_weight")
     return dw
@@ -278,10 +300,10 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
 
 def _ew(fn_name, x, out_shape, in_shape_for_kernel):
     lib = _ensure_device(x)
-    assert is_cl(x) and x.dtype == torch.float32
+    assert is_cl(x) and x.dtype in (torch.float32, torch.bfloat16)
     y = empty_cl(out_shape, x)
     b, c, h, w = in_shape_for_kernel
-    _check(getattr(lib, fn_name)(_ptr(x), _ptr(y), _shape(b, h, w, c), _stream()), fn_name)
+    _check(getattr(lib, fn_name)(_ptr(x), _ptr(y), _shape(b, h, w, c), _adt(x), _stream()), fn_name)
     return y
 
 
@@ -309,26 +331,27 @@ def bias_act_fwd(x, bias=None, noise=None, noise_w=None, noise_b=None):
     b, c, h, w = x.shape
     y = empty_cl(tuple(x.shape), x)
     ns = 0
+    bias, noise, noise_w, noise_b = _f32(bias), _f32(noise), _f32(noise_w), _f32(noise_b)
     if noise is not None:
-        noise = noise.contiguous()
         ns = noise.shape[1]
     _check(lib.stylex_bias_act_fwd(_ptr(x), _ptr(bias), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(y),
-                                   _shape(b, h, w, c), _stream()), "stylex_bias_act_fwd")
+                                   _shape(b, h, w, c), _adt(x), _stream()), "stylex_bias_act_fwd")
     return y
 
 
 def bias_act_bwd(dy, y):
     lib = _ensure_device(dy)
-    assert is_cl(dy) and is_cl(y)
+    assert is_cl(dy) and is_cl(y) and dy.dtype == y.dtype
     b, c, h, w = dy.shape
     dx = empty_cl(tuple(dy.shape), dy)
-    _check(lib.stylex_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), _shape(b, h, w, c), _stream()), "stylex_bias_act_bwd")
+    _check(lib.stylex_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), _shape(b, h, w, c), _adt(dy), _stream()),
+           "stylex_bias_act_bwd")
     return dx
 
 
 def rowwise_sumsq(x2d):
     lib = _ensure_device(x2d)
-    x2d = x2d.contiguous()
+    x2d = x2d.float().contiguous()
     out = torch.empty(x2d.shape[0], dtype=torch.float32, device=x2d.device)
     _check(lib.stylex_rowwise_sumsq(_ptr(x2d), _ptr(out), _shape(x2d.shape[0], x2d.shape[1]), _stream()),
            "stylex_rowwise_sumsq")
@@ -338,46 +361,47 @@ def rowwise_sumsq(x2d):
 def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True):
     """dx = dy*scale*lrelu'(y); returns (dx or None, per-channel sum over b,h,w [C])."""
     lib = _ensure_device(dy)
-    assert is_cl(dy) and (y is None or is_cl(y))
+    assert is_cl(dy) and (y is None or (is_cl(y) and y.dtype == dy.dtype))
     b, c, h, w = dy.shape
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
     partial = torch.empty((b, nch, c), dtype=torch.float32, device=dy.device)
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
     _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, int(bool(lrelu)),
-                                     float(scale), _stream()), "stylex_act_bwd_reduce")
+                                     float(scale), _adt(dy), _stream()), "stylex_act_bwd_reduce")
     return dx, partial.sum(dim=(0, 1))
 
 
 def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu):
     """gz = gy*lrelu'(y); returns gz and S[3][B][C] = per-image sums (gz*(d*z), gz*noise, gz)."""
     lib = _ensure_device(gy)
-    assert is_cl(gy) and is_cl(y)
+    assert is_cl(gy) and is_cl(y) and gy.dtype == y.dtype
     b, c, h, w = gy.shape
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
     partial = torch.empty((b, nch, 3, c), dtype=torch.float32, device=gy.device)
     gz = empty_cl(tuple(gy.shape), gy)
     ns = 0
+    noise, noise_w, noise_b = _f32(noise), _f32(noise_w), _f32(noise_b)
     if noise is not None:
-        noise = noise.contiguous()
         ns = noise.shape[1]
     _check(lib.stylex_modconv_bwd_prep(_ptr(gy), _ptr(y), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(gz),
-                                       _ptr(partial), shp, nch, int(bool(lrelu)), _stream()), "stylex_modconv_bwd_prep")
+                                       _ptr(partial), shp, nch, int(bool(lrelu)), _adt(gy), _stream()),
+           "stylex_modconv_bwd_prep")
     return gz, partial.sum(dim=1)  # [B, 3, C]
 
 
 def scale_reduce(x, t, s, want_gx=True):
     """gx = t*s[b,c]; returns (gx or None, per-image sum of x*t [B, C])."""
     lib = _ensure_device(x)
-    assert is_cl(x) and is_cl(t)
+    assert is_cl(x) and is_cl(t) and x.dtype == t.dtype
     b, c, h, w = x.shape
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
     partial = torch.empty((b, nch, c), dtype=torch.float32, device=x.device)
     gx = empty_cl(tuple(x.shape), x) if want_gx else None
-    s = s.contiguous()
-    _check(lib.stylex_scale_reduce(_ptr(x), _ptr(t), _ptr(s), _ptr(gx), _ptr(partial), shp, nch, _stream()),
+    s = _f32(s)
+    _check(lib.stylex_scale_reduce(_ptr(x), _ptr(t), _ptr(s), _ptr(gx), _ptr(partial), shp, nch, _adt(x), _stream()),
            "stylex_scale_reduce")
     return gx, partial.sum(dim=1)
 

@@ -210,6 +210,7 @@ class Generator(nn.Module):  # reference :747-825
         for li, block in enumerate(self.blocks):
             x, rgb, sc = block(x, rgb, styles[:, li], input_noise)
             coords.append(sc)
+        rgb = rgb.float()  # activations may be stored in bf16; the module API returns fp32 images
         if get_style_coords:
             return rgb, torch.cat(coords, dim=1)
         return rgb
@@ -236,4 +237,4 @@ class DiscriminatorE(nn.Module):  # reference :842-909 (D: 1 logit; encoder: enc
         for block in self.blocks:
             x = block(x)
         x = self.final_conv(x)
-        return self.fc(self.flatten(x)).squeeze()
+        return self.fc(self.flatten(x).float()).squeeze()

@@ -27,14 +27,36 @@ import hip_backend as hb
 _PRECISION = hb.F32
 
 
+_NAMES = {"fp32": hb.F32, "f32": hb.F32, "bf16": hb.BF16_ACT, "bf16_f32act": hb.BF16}
+
+
 def set_precision(name):
-    """'fp32' -> exact f32 MFMA (parity mode); 'bf16' -> bf16 MFMA operands, fp32 accumulate."""
+    """'fp32'        exact f32 MFMA, fp32 tensors (parity mode);
+    'bf16'        bf16 MFMA operands + bf16 activation tensors in HBM, fp32 accumulate / parameters / reductions;
+    'bf16_f32act' bf16 MFMA operands with fp32 activation tensors."""
     global _PRECISION
-    _PRECISION = {"fp32": hb.F32, "f32": hb.F32, "bf16": hb.BF16}[name]
+    _PRECISION = _NAMES[name]
 
 
 def get_precision():
-    return "bf16" if _PRECISION == hb.BF16 else "fp32"
+    return {hb.F32: "fp32", hb.BF16_ACT: "bf16", hb.BF16: "bf16_f32act"}[_PRECISION]
+
+
+def act_dtype():
+    return hb.act_dtype(_PRECISION)
+
+
+def _cl(t):
+    """channels_last + the activation dtype of the current precision mode."""
+    return hb.to_cl(t, hb.act_dtype(_PRECISION))
+
+
+def _act(t):
+    """Differentiable cast of an incoming tensor to the activation dtype (no-op in fp32 modes)."""
+    if t is None:
+        return None
+    adt = hb.act_dtype(_PRECISION)
+    return t if t.dtype == adt else t.to(adt)
 
 
 # ------------------------------------------------------------------------------------------
@@ -45,7 +67,7 @@ def get_precision():
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad):
-        x = hb.to_cl(x)
+        x = _cl(x)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, _PRECISION)
         return hb.conv2d_fwd(x, w, stride, pad, _PRECISION)
@@ -65,7 +87,7 @@ class _Conv(torch.autograd.Function):
 class _Dgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gy, w, x_shape, stride, pad):
-        gy = hb.to_cl(gy)
+        gy = _cl(gy)
         ctx.save_for_backward(gy, w)
         ctx.cfg = (x_shape, stride, pad)
         return hb.conv2d_bwd_data(gy, w, x_shape, stride, pad, _PRECISION)
@@ -85,7 +107,7 @@ class _Dgrad(torch.autograd.Function):
 class _Wgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gy, w_shape, stride, pad):
-        x, gy = hb.to_cl(x), hb.to_cl(gy)
+        x, gy = _cl(x), _cl(gy)
         ctx.save_for_backward(x, gy)
         ctx.cfg = (w_shape, stride, pad)
         return hb.conv2d_bwd_weight(x, gy, w_shape, stride, pad, _PRECISION)
@@ -111,7 +133,7 @@ class _Wgrad(torch.autograd.Function):
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias):
-        x = hb.to_cl(x)
+        x = _cl(x)
         y = hb.bias_act_fwd(x, bias)
         ctx.save_for_backward(y)
         ctx.has_bias = bias is not None
@@ -121,14 +143,14 @@ class _BiasAct(torch.autograd.Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         gx = _BiasActBwd.apply(gy, y)
-        gb = gx.sum(dim=(0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        gb = gx.sum(dim=(0, 2, 3), dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         return gx, gb
 
 
 class _BiasActBwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gy, y):
-        gy = hb.to_cl(gy)
+        gy = _cl(gy)
         ctx.save_for_backward(y)
         return hb.bias_act_bwd(gy, y)
 
@@ -146,7 +168,7 @@ class _BiasActBwd(torch.autograd.Function):
 class _Up(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        return hb.upsample2x_fwd(hb.to_cl(x))
+        return hb.upsample2x_fwd(_cl(x))
 
     @staticmethod
     def backward(ctx, gy):
@@ -156,7 +178,7 @@ class _Up(torch.autograd.Function):
 class _UpBwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gy):
-        return hb.upsample2x_bwd(hb.to_cl(gy))
+        return hb.upsample2x_bwd(_cl(gy))
 
     @staticmethod
     def backward(ctx, ggx):
@@ -166,7 +188,7 @@ class _UpBwd(torch.autograd.Function):
 class _Blur(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        return hb.blur3x3_fwd(hb.to_cl(x))
+        return hb.blur3x3_fwd(_cl(x))
 
     @staticmethod
     def backward(ctx, gy):
@@ -176,7 +198,7 @@ class _Blur(torch.autograd.Function):
 class _BlurBwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gy):
-        return hb.blur3x3_bwd(hb.to_cl(gy))
+        return hb.blur3x3_bwd(_cl(gy))
 
     @staticmethod
     def backward(ctx, ggx):
@@ -226,9 +248,9 @@ class _ConvBiasActFast(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, stride, pad, lrelu, res_scale):
-        x = hb.to_cl(x)
+        x = _cl(x)
         if residual is not None:
-            residual = hb.to_cl(residual)
+            residual = _cl(residual)
         y = hb.conv2d_fwd(x, w, stride, pad, _PRECISION, bias=bias, lrelu=lrelu, residual=residual,
                           res_scale=res_scale)
         ctx.save_for_backward(x, w, y if lrelu else None)
@@ -241,7 +263,7 @@ class _ConvBiasActFast(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         stride, pad, lrelu, scale, has_bias, has_res = ctx.cfg
-        gy = hb.to_cl(gy)
+        gy = _cl(gy)
         gb = None
         if _reducible(gy.shape[1]):
             want_dx = lrelu or scale != 1.0
@@ -256,7 +278,7 @@ class _ConvBiasActFast(torch.autograd.Function):
             gz = hb.bias_act_bwd(gy, y) if lrelu else gy
             if scale != 1.0:
                 gz = gz * scale
-            gb = gz.sum(dim=(0, 2, 3)) if has_bias else None
+            gb = gz.sum(dim=(0, 2, 3), dtype=torch.float32) if has_bias else None
         gx = hb.conv2d_bwd_data(gz, w, tuple(x.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[0] else None
         gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[1] else None
         if not ctx.needs_input_grad[2]:
@@ -269,7 +291,7 @@ class _ModConvFast(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, s1, d, w, noise, nw, nb, pad, lrelu):
-        x = hb.to_cl(x)
+        x = _cl(x)
         y = hb.conv2d_fwd(x, w, 1, pad, _PRECISION, in_scale=s1, out_scale=d, noise=noise, noise_w=nw, noise_b=nb,
                           lrelu=lrelu)
         ctx.save_for_backward(x, s1, d, w, noise, nw, nb, y if (lrelu or d is not None or noise is not None) else None)
@@ -281,7 +303,7 @@ class _ModConvFast(torch.autograd.Function):
     def backward(ctx, gy):
         x, s1, d, w, noise, nw, nb, y = ctx.saved_tensors
         pad, lrelu = ctx.cfg
-        gy = hb.to_cl(gy)
+        gy = _cl(gy)
         gd = gnw = gnb = None
         if y is not None and _reducible(gy.shape[1]):
             gz, sums = hb.modconv_bwd_prep(gy, y, noise, nw, nb, lrelu)
@@ -299,8 +321,8 @@ class _ModConvFast(torch.autograd.Function):
             if _reducible(x.shape[1]):
                 gx, gs1 = hb.scale_reduce(x, t, s1, want_gx=ctx.needs_input_grad[0])
             else:
-                gs1 = (x * t).sum(dim=(2, 3))
-                gx = t * s1[:, :, None, None]
+                gs1 = (x.float() * t.float()).sum(dim=(2, 3))
+                gx = (t.float() * s1[:, :, None, None]).to(t.dtype)
         if ctx.needs_input_grad[3]:
             gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), 1, pad, _PRECISION, x_scale=s1, dy_scale=d)
         return gx, gs1, gd, gw, None, gnw, gnb, None, None
@@ -316,8 +338,9 @@ def _pad_rgb(x, weight):
     Zero-pad C_in 3->4 (input + weight) and N 3->4 (weight; the caller slices the output): exact."""
     n_out = weight.shape[0]
     if weight.shape[1] == 3:
-        x = torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2], x.shape[3])], dim=1)
-        weight = torch.cat([weight, weight.new_zeros(weight.shape[0], 1, weight.shape[2], weight.shape[3])], dim=1)
+        extra = 5 if x.dtype == torch.bfloat16 else 1  # 16-byte slots: 8 bf16 or 4 fp32 channels
+        x = torch.cat([x, x.new_zeros(x.shape[0], extra, x.shape[2], x.shape[3])], dim=1)
+        weight = torch.cat([weight, weight.new_zeros(weight.shape[0], extra, weight.shape[2], weight.shape[3])], dim=1)
     if n_out == 3:
         weight = torch.cat([weight, weight.new_zeros(1, *weight.shape[1:])], dim=0)
     return x, weight, n_out
@@ -332,7 +355,8 @@ class HipOps:
     def conv2d(x, weight, bias=None, stride=1, padding=0, lrelu=False, residual=None, res_scale=1.0):
         """nn.Conv2d (+ LeakyReLU(0.2)) — reference :724-736, :771, :881; with `residual` the block
         merge (conv + bias + residual) * res_scale of :743 is fused into the same kernel."""
-        x, weight, n_out = _pad_rgb(x, weight)
+        x, weight, n_out = _pad_rgb(_act(x), weight)
+        residual = _act(residual)
         padded_out = n_out != weight.shape[0]
         if fast_enabled() and not padded_out:
             y = _ConvBiasActFast.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)
@@ -353,6 +377,7 @@ class HipOps:
     def modulated_conv2d(x, style, weight, demod=True, eps=1e-8):
         """Conv2DMod.forward (:647-667) without materialising per-sample weights:
         y = d[b,o] * conv(x * (style+1)[b,i], W),  d = rsqrt(((style+1)^2) @ sum_k W^2 + eps)."""
+        x = _act(x)
         s1 = style + 1
         k = weight.shape[2]
         pad = (k - 1) // 2  # _get_same_padding for stride 1, dilation 1 (:644-645)
@@ -382,6 +407,7 @@ class HipOps:
     def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8):
         """lrelu(Conv2DMod(x, style) + noise) of GeneratorBlock (:696-714) as one fused kernel when no
         double backward can be requested, else the differentiable composition."""
+        x = _act(x)
         if fast_enabled() and weight.shape[0] % 4 == 0:
             s1 = style + 1
             d = None
@@ -399,15 +425,15 @@ class HipOps:
         h, w = x.shape[2], x.shape[3]
         plane = inoise[:, :h, :w, 0].transpose(1, 2)  # [B, h(w-index), ...] -> value at (h,w) = inoise[b,w,h]
         n = plane[:, None, :, :] * noise_w.view(1, -1, 1, 1) + noise_b.view(1, -1, 1, 1)
-        return _BiasAct.apply(x + n, None)
+        return _BiasAct.apply(_act(x + n), None)
 
     @staticmethod
     def upsample2x(x):
-        return _Up.apply(x)
+        return _Up.apply(_act(x))
 
     @staticmethod
     def blur3x3(x):
-        return _Blur.apply(x)
+        return _Blur.apply(_act(x))
 
     @staticmethod
     def residual_merge(x, res):

@@ -21,7 +21,10 @@
  *  - `precision`: arithmetic of the MFMA contraction —
  *      STYLEX_F32  v_mfma_f32_32x32x2_f32   (exact fp32, parity mode)
  *      STYLEX_BF16 v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 when staged
- *                                            into LDS, fp32 accumulate).
+ *                                            into LDS, fp32 accumulate), fp32 activation tensors.
+ *      STYLEX_BF16_ACT  the same MFMA path with bf16 ACTIVATION tensors in HBM (every
+ *                       pointer documented as "activation" is then bf16; scales, biases,
+ *                       weight gradients and workspaces stay fp32).
  */
 #ifndef STYLEX_HIP_H
 #define STYLEX_HIP_H
@@ -34,6 +37,7 @@ extern "C" {
 
 #define STYLEX_F32 0
 #define STYLEX_BF16 1
+#define STYLEX_BF16_ACT 2 /* bf16 MFMA AND bf16 activation tensors (x, y, dy, dx, residual); halves HBM traffic */
 
 #define STYLEX_EINVAL (-1)   /* bad shape / unsupported configuration */
 #define STYLEX_EWORKSPACE (-2) /* workspace too small */
@@ -80,7 +84,7 @@ typedef struct {
     int64_t noise_stride;   /* S */
     const float* noise_w;   /* [N] */
     const float* noise_b;   /* [N] */
-    const float* residual;  /* [B][Ho][Wo][N] */
+    const void* residual;   /* [B][Ho][Wo][N], activation dtype */
     float res_scale;
 } stylex_conv_epilogue;
 
@@ -90,7 +94,7 @@ typedef struct {
  * order); with a workspace the slices are reduced in fixed order (deterministic). */
 int64_t stylex_conv2d_workspace_bytes(const int64_t* shape, int which, int precision);
 
-int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t* shape, int flags,
+int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* shape, int flags,
                       const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                       void* stream);
 
@@ -101,7 +105,7 @@ int stylex_conv2d_fwd(const float* x, const void* w_fwd, float* y, const int64_t
 /* Modulated form: epi->in_scale [B][N] scales dy while it is staged (demodulation
  * coefficient) and, with STYLEX_EPI_OSCALE, epi->out_scale [B][C] scales dx
  * (style+1).  flags may only contain STYLEX_EPI_OSCALE; epi may be NULL. */
-int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const int64_t* shape, int flags,
+int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const int64_t* shape, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                            void* stream);
 
@@ -111,28 +115,32 @@ int stylex_conv2d_bwd_data(const float* dy, const void* w_bwd, float* dx, const 
 int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* shape);
 /* x_scale [B][C] / dy_scale [B][N] (either may be NULL) are the per-sample
  * modulation / demodulation factors of the modulated conv, applied while staging. */
-int stylex_conv2d_bwd_weight(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes,
+int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
                              const int64_t* shape, const float* x_scale, const float* dy_scale, int precision,
                              void* stream);
 
-/* Bilinear x2, align_corners=False (nn.Upsample, stylex_train.py:614,679) and its adjoint.
+/* Elementwise / resampling entry points take `act_dtype`: 0 = fp32 activations, 1 = bf16 activations
+ * (the storage type of STYLEX_BF16_ACT); arithmetic is fp32 either way.
+ *
+ * Bilinear x2, align_corners=False (nn.Upsample, stylex_train.py:614,679) and its adjoint.
  * shape = {B, H, W, C} of the LOW-resolution tensor.  Index rule (exact):
  *   out[2k] = .25*in[max(k-1,0)] + .75*in[k];  out[2k+1] = .75*in[k] + .25*in[min(k+1,n-1)] */
-int stylex_upsample2x_bilinear_fwd(const float* x, float* y, const int64_t* shape, void* stream);
-int stylex_upsample2x_bilinear_bwd(const float* dy, float* dx, const int64_t* shape, void* stream);
+int stylex_upsample2x_bilinear_fwd(const void* x, void* y, const int64_t* shape, int act_dtype, void* stream);
+int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
 
 /* 3x3 binomial blur /16 with reflect border (Blur.forward, stylex_train.py:144-153 ->
  * kornia.filters.filter2d(normalized=True, border_type='reflect')) and its adjoint.
  * shape = {B, H, W, C}.  Index rule (exact): -1 -> 1, H -> H-2. */
-int stylex_blur3x3_reflect_fwd(const float* x, float* y, const int64_t* shape, void* stream);
-int stylex_blur3x3_reflect_bwd(const float* dy, float* dx, const int64_t* shape, void* stream);
+int stylex_blur3x3_reflect_fwd(const void* x, void* y, const int64_t* shape, int act_dtype, void* stream);
+int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
 
 /* y = leaky_relu(x + bias[c] (+ noise[b][w][h]*noise_w[c] + noise_b[c]), 0.2)
  * (nn.Conv2d bias + leaky_relu, stylex_train.py:340-341,726-731; noise add :696-714).
  * shape = {B, H, W, C}.  bias/noise pointers may be NULL.  bwd: dx = dy * (y>0 ? 1 : 0.2). */
-int stylex_bias_act_fwd(const float* x, const float* bias, const float* noise, int64_t noise_stride,
-                        const float* noise_w, const float* noise_b, float* y, const int64_t* shape, void* stream);
-int stylex_bias_act_bwd(const float* dy, const float* y, float* dx, const int64_t* shape, void* stream);
+int stylex_bias_act_fwd(const void* x, const float* bias, const float* noise, int64_t noise_stride,
+                        const float* noise_w, const float* noise_b, void* y, const int64_t* shape, int act_dtype,
+                        void* stream);
+int stylex_bias_act_bwd(const void* dy, const void* y, void* dx, const int64_t* shape, int act_dtype, void* stream);
 
 /* out[r] = sum_j x[r][j]^2   (per-sample squared L2 norm; gradient_penalty :302,
  * calc_pl_lengths :316).  shape = {rows, cols}.  One wavefront-shuffle + LDS
@@ -152,13 +160,13 @@ int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void*
  *      gz = gy * lrelu'(y);  partial[.][0] = sum gz*(d*z), [1] = sum gz*noise, [2] = sum gz
  * stylex_scale_reduce:     gx = t * s[b][c];  partial = sum_pixels x*t   (gradient wrt style+1, :650) */
 int stylex_reduce_chunks(const int64_t* shape);
-int stylex_act_bwd_reduce(const float* dy, const float* y, float* dx, float* partial, const int64_t* shape, int nchunks,
-                          int lrelu, float scale, void* stream);
-int stylex_modconv_bwd_prep(const float* gy, const float* y, const float* noise, int64_t noise_stride,
-                            const float* noise_w, const float* noise_b, float* gz, float* partial,
-                            const int64_t* shape, int nchunks, int lrelu, void* stream);
-int stylex_scale_reduce(const float* x, const float* t, const float* s, float* gx, float* partial, const int64_t* shape,
-                        int nchunks, void* stream);
+int stylex_act_bwd_reduce(const void* dy, const void* y, void* dx, float* partial, const int64_t* shape, int nchunks,
+                          int lrelu, float scale, int act_dtype, void* stream);
+int stylex_modconv_bwd_prep(const void* gy, const void* y, const float* noise, int64_t noise_stride,
+                            const float* noise_w, const float* noise_b, void* gz, float* partial,
+                            const int64_t* shape, int nchunks, int lrelu, int act_dtype, void* stream);
+int stylex_scale_reduce(const void* x, const void* t, const float* s, void* gx, float* partial, const int64_t* shape,
+                        int nchunks, int act_dtype, void* stream);
 
 /* Per-kernel timing hook: when enabled every conv launch is bracketed
  * by hipEvents on its stream; stylex_timing_report returns, per kernel class

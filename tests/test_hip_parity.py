@@ -21,7 +21,7 @@ from test_oracle_vs_golden import build_nets_model, close_stats  # noqa: E402
 from test_host_logic_cpu import make_trainer, run_steps  # noqa: E402
 
 DEV = "cuda:0"
-TOL32, TOLBF = 2e-5, 3e-2
+TOL32, TOLBF = 2e-5, 4e-2
 
 
 @pytest.fixture(autouse=True)
@@ -105,23 +105,25 @@ def test_fused_conv_epilogue_and_scales(shape, prec):
     S = max(H, W)
     inoise = torch.rand(B, S, S, generator=g)
     res = torch.randn(B, N, H, W, generator=g)
-    P = hb.BF16 if prec == "bf16" else hb.F32
+    P = hb.BF16_ACT if prec == "bf16" else hb.F32
+    adt = hb.act_dtype(P)
     tol = TOL32 if prec == "fp32" else TOLBF
+    cl_ = lambda t: cl(t).to(adt)
     ref = F.conv2d(x * s_in[:, :, None, None], w, None, 1, 1) * s_out[:, :, None, None] + bias.view(1, -1, 1, 1)
     ref = ref + inoise[:, :W, :H].transpose(1, 2)[:, None] * nw.view(1, -1, 1, 1) + nb.view(1, -1, 1, 1)
     ref = F.leaky_relu((ref + res) * 0.5, 0.2)
     d = lambda t: t.to(DEV)
-    y = hb.conv2d_fwd(cl(x), d(w), 1, 1, P, bias=d(bias), lrelu=True, in_scale=d(s_in), out_scale=d(s_out),
-                      noise=d(inoise), noise_w=d(nw), noise_b=d(nb), residual=cl(res), res_scale=0.5)
+    y = hb.conv2d_fwd(cl_(x), d(w), 1, 1, P, bias=d(bias), lrelu=True, in_scale=d(s_in), out_scale=d(s_out),
+                      noise=d(inoise), noise_w=d(nw), noise_b=d(nb), residual=cl_(res), res_scale=0.5)
     close(ref, y, tol, "fused fwd")
     dy = torch.randn(B, N, H, W, generator=g)
     xr = x.clone().requires_grad_()
     wr = w.clone().requires_grad_()
     z = F.conv2d(xr * s_in[:, :, None, None], wr, None, 1, 1) * s_out[:, :, None, None]
     (z * dy).sum().backward()
-    dx = hb.conv2d_bwd_data(cl(dy), d(w), tuple(x.shape), 1, 1, P, in_scale=d(s_out), out_scale=d(s_in))
+    dx = hb.conv2d_bwd_data(cl_(dy), d(w), tuple(x.shape), 1, 1, P, in_scale=d(s_out), out_scale=d(s_in))
     close(xr.grad, dx, tol, "scaled dgrad")
-    dw = hb.conv2d_bwd_weight(cl(x), cl(dy), tuple(w.shape), 1, 1, P, x_scale=d(s_in), dy_scale=d(s_out))
+    dw = hb.conv2d_bwd_weight(cl_(x), cl_(dy), tuple(w.shape), 1, 1, P, x_scale=d(s_in), dy_scale=d(s_out))
     close(wr.grad, dw, tol, "scaled wgrad")
 
 

@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    prec = hb.BF16 if a.precision == "bf16" else hb.F32
+    prec = {"bf16": hb.BF16_ACT, "bf16_f32act": hb.BF16, "fp32": hb.F32}[a.precision]
+    adt = hb.act_dtype(prec)
     dev = "cuda:0"
     print("%-10s %5s %5s %4s k s | %9s %9s %9s | TF/s fwd dgrad wgrad | GB/s fwd" % ("layer", "C", "N", "res", "fwd ms", "dgrad ms", "wgrad ms"))
     tot = [0.0, 0.0, 0.0]
@@ -61,7 +62,7 @@ def main():
     for (name, c, n, res, k, s, p) in layers(a.size):
         if a.only and a.only not in name:
             continue
-        x = torch.randn(a.batch, c, res, res, device=dev).contiguous(memory_format=torch.channels_last)
+        x = torch.randn(a.batch, c, res, res, device=dev).to(adt).contiguous(memory_format=torch.channels_last)
         w = torch.randn(n, c, k, k, device=dev) * 0.05
         y = hb.conv2d_fwd(x, w, s, p, prec)
         dy = torch.randn_like(y)
@@ -69,7 +70,7 @@ def main():
         t_d = timeit(lambda: hb.conv2d_bwd_data(dy, w, tuple(x.shape), s, p, prec), a.iters)
         t_w = timeit(lambda: hb.conv2d_bwd_weight(x, dy, tuple(w.shape), s, p, prec), a.iters)
         fl = 2.0 * y.numel() * c * k * k
-        byts = 4.0 * (x.numel() + y.numel() + w.numel())
+        byts = float(x.element_size()) * (x.numel() + y.numel()) + 4.0 * w.numel()
         print("%-10s %5d %5d %4d %d %d | %9.3f %9.3f %9.3f | %6.1f %6.1f %6.1f | %7.0f" % (
             name, c, n, res, k, s, t_f, t_d, t_w, fl / t_f / 1e9, fl / t_d / 1e9, fl / t_w / 1e9, byts / t_f / 1e6))
         tot[0] += t_f; tot[1] += t_d; tot[2] += t_w; totf += fl
