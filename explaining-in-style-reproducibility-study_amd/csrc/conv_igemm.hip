@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     // ABF: bf16 activations AND weights staged as raw 16-byte slots of 8 elements (no conversion, no unpack)
     constexpr int KQ = ABF ? BKT / 8 : BKT / 4;  // slots per staged row
     constexpr int RPP = 256 / KQ;    // rows staged per pass of the 256 threads
-    constexpr int RA = BM / RPP, RB = BN / RPP;  // rows staged per thread for A / B
+    constexpr int RA = BM / RPP, RB = (BN + RPP - 1) / RPP;  // rows staged per thread for A / B
+    constexpr bool B_PARTIAL = (BN % RPP) != 0;                // RPP = 64 with a 32-column tile
     // fp32 LDS image: [k][row] with row stride +1 dword.  bf16 image: [row][k] bf16, 80-byte rows.
     constexpr int LDA = BM + 1, LDB = BN + 1;
     constexpr int LDH = BKT + 8;  // bf16 elements per LDS row (+8 pad: 16-B aligned rows, odd 16-B slot stride)
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
             for (int j = 0; j < RB; ++j) {
                 int n = n0 + r0 + RPP * j;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (cok && n < p.N) v = *reinterpret_cast<const uint4*>(wbase + ((long)n * T + tap) * p.Ck + c0);
+                if (cok && n < p.N && (!B_PARTIAL || r0 + RPP * j < BN))
+                    v = *reinterpret_cast<const uint4*>(wbase + ((long)n * T + tap) * p.Ck + c0);
                 rbh[j] = v;
             }
             return;
@@ -292,7 +294,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 *reinterpret_cast<uint4*>(a + (r0 + RPP * j) * LDH + kq * 8) = v;
             }
 #pragma unroll
-            for (int j = 0; j < RB; ++j) *reinterpret_cast<uint4*>(b + (r0 + RPP * j) * LDH + kq * 8) = rbh[j];
+            for (int j = 0; j < RB; ++j)
+                if (!B_PARTIAL || r0 + RPP * j < BN) *reinterpret_cast<uint4*>(b + (r0 + RPP * j) * LDH + kq * 8) = rbh[j];
             return;
         }
         if (BF16) {
@@ -799,7 +802,8 @@ static void igemm_tile(const ConvKParams& p, int* bm, int* bn) {
 // more MFMAs per barrier) are used whenever the channel count allows
 static int igemm_bk(const ConvKParams& p, bool vec, int precision) {
     // bf16 activations: 16-byte slots of 8 elements => 64-deep tiles with the same thread mapping.
-    if (precision == STYLEX_BF16 && p.act_bf16 && p.Ck % 8 == 0 && vec) return 64;
+    if (precision == STYLEX_BF16 && p.act_bf16 && p.Ck % 8 == 0 && vec)
+        return p.N > 64 ? 64 : 33;  // 33 = "32-deep ABF": the 256-row tiles would drop to 1 block/CU at 64
     // fp32 activations: BKT = 64/128 measured SLOWER (the big strided layers are L2/HBM-bound on the fp32
     // gather and lose occupancy, the small ones are launch-bound).  Keep 32.
     return 32;
@@ -811,8 +815,10 @@ static void igemm_splitk_plan(const ConvKParams& p, bool vec, int precision, int
     igemm_tile(p, &bm, &bn);
     long blocks = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     int T = p.KH * p.KW;
-    const int bk = igemm_bk(p, vec, precision);
-    int nk = vec ? ((p.Ck == 4 || (bk == 64 && p.Ck == 8)) ? (T + 7) / 8 : T * ((p.Ck + bk - 1) / bk)) : (T * p.Ck + BK - 1) / BK;
+    int bk = igemm_bk(p, vec, precision);
+    const bool abf = bk == 64 || bk == 33;
+    if (bk == 33) bk = 32;
+    int nk = vec ? ((p.Ck == 4 && !abf) ? (T + 7) / 8 : (abf && p.Ck == 8) ? (T + bk / 8 - 1) / (bk / 8) : T * ((p.Ck + bk - 1) / bk)) : (T * p.Ck + BK - 1) / BK;
     *ksplit = 1;
     *kt_per = nk;
     if (blocks >= 192 || nk < 16) return;
@@ -860,6 +866,7 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
     if (precision == STYLEX_BF16) {
         const int bk = igemm_bk(p, vec, precision);
         if (bk == 64) rc = dispatch_igemm<true, true, 64, true>(p, s);
+        else if (bk == 33) rc = dispatch_igemm<true, true, 32, true>(p, s);
         else rc = vec ? dispatch_igemm<true, true, 32>(p, s) : dispatch_igemm<false, true, 32>(p, s);
     } else {
         rc = vec ? dispatch_igemm<true, false, 32>(p, s) : dispatch_igemm<false, false, 32>(p, s);
