@@ -75,11 +75,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
         hoff[it] = ok ? (b * H + y) * W + x : -1;
     }
 
+    // space-to-depth form of a stride-2 conv: which weight taps are structurally non-zero depends on the
+    // sub-position of the source-channel chunk (forward) or of this block's output-channel tile (dgrad)
+    const unsigned all_taps = 0x1ffu;
+    auto wmask_of_chunk = [&](int c0) -> unsigned {
+        if (!p.s2d_c) return all_taps;
+        return stylex_s2d_tap_mask(p.flip_taps ? n0 / p.s2d_c : c0 / p.s2d_c);
+    };
+    unsigned cur_wmask = all_taps;
+
     float4 hreg[HALO_SLOTS];  // fp32 x4, or (ABF) raw bf16 x8 bit patterns
     uint4 wreg[W_SLOTS];
     const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w);
 
     auto issue_loads = [&](int c0) {
+        const unsigned wm_next = wmask_of_chunk(c0);
         const int cc = c0 + q8 * (ABF ? 8 : 4);
         const bool cok = cc < C;
 #pragma unroll
@@ -100,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
             int nl = r / 9, tap = r - nl * 9;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             int ck = c0 + qq * 8;
-            if (r < W_ROWS && n0 + nl < p.N && ck < C) {
-                int gt = p.flip_taps ? 8 - tap : tap;
+            int gt = p.flip_taps ? 8 - tap : tap;
+            if (r < W_ROWS && n0 + nl < p.N && ck < C && ((wm_next >> gt) & 1)) {
                 v = *reinterpret_cast<const uint4*>(wsrc + ((long)(n0 + nl) * 9 + gt) * C + ck);
             }
             wreg[it] = v;
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     auto compute = [&]() {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            if (!((cur_wmask >> (p.flip_taps ? 8 - tap : tap)) & 1)) continue;  // block-uniform skip (s2d form)
             const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -195,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) issue_loads((ch + 1) * 32);
+        cur_wmask = wmask_of_chunk(ch * 32);
         compute();
         __syncthreads();
         if (more) {

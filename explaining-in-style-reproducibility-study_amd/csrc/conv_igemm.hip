@@ -664,33 +664,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
 }
 
 // dw_oihw[n][c][t] = sum_split partial[split][n][t][c]   (fixed order => deterministic)
+// One thread owns one (n, c): for each tap it reads the slices with lanes running along c (coalesced
+// 256-byte rows) and finally writes its T consecutive output floats (a wave covers one contiguous span).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int C, int T,
                                     int splits) {
     const long total = (long)N * C * T;
-    if ((C & 3) == 0) {  // 4 consecutive c per thread: 16-byte coalesced reads of every slice
-        const long total4 = total >> 2;
-        for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
-            const long i = i4 << 2;
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < splits; ++k) {
-                float4 v = *reinterpret_cast<const float4*>(partial + (long)k * total + i);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-            int c = (int)(i % C);
-            int t = (int)((i / C) % T);
-            int n = (int)(i / ((long)C * T));
-            float* d = dw + ((long)n * C + c) * T + t;
-            d[0] = s.x; d[T] = s.y; d[2 * T] = s.z; d[3 * T] = s.w;
-        }
-        return;
-    }
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pairs = (long)N * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
-        int t = (int)((i / C) % T);
-        int n = (int)(i / ((long)C * T));
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(long)k * total + i];
-        dw[((long)n * C + c) * T + t] = s;
+        long n = i / C;
+        const float* src = partial + (n * T) * C + c;
+        float* dst = dw + i * T;
+        if (T == 9) {
+            float acc[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+            for (int k = 0; k < splits; ++k) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] += src[(long)k * total + (long)t * C];
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) dst[t] = acc[t];
+        } else {
+            for (int t = 0; t < T; ++t) {
+                float a = 0.f;
+                for (int k = 0; k < splits; ++k) a += src[(long)k * total + (long)t * C];
+                dst[t] = a;
+            }
+        }
     }
 }
 
@@ -734,6 +735,45 @@ __global__ void splitk_epilogue_kernel(ConvKParams p) {
         if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
         if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
         act_st1(p.y, o, v, p.act_bf16);
+    }
+}
+
+// Stride-2 3x3/pad-1 conv rewritten over the space-to-depth input (4 sub-positions x C channels):
+//   W2[n][(s,c)][kh2][kw2] = W[n][c][kmap(kh2,sy)][kmap(kw2,sx)]  for kh2,kw2 in {0,1} and (kh2==1||sy==1)&&(kw2==1||sx==1)
+//   (frame offset -1 <-> kh2 = 0 reads the odd sub-row: original kh = 0; offset 0 <-> kh2 = 1: kh = 1 + sy), else 0.
+// Packed bf16 directly into the two operand layouts of a 3x3/s1 conv with Ck = 4C.
+__global__ void pack_weight_s2d_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                       unsigned short* __restrict__ wb, int N, int C) {
+    const int C4 = 4 * C;
+    const long total = (long)N * C4 * 9;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int sc = (int)(i % C4);           // fastest: source channel in s2d space (coalesced wf writes)
+        int t2 = (int)((i / C4) % 9);
+        int n = (int)(i / ((long)C4 * 9));
+        int s = sc / C, c = sc - s * C, sy = s >> 1, sx = s & 1;
+        int kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
+        float v = 0.f;
+        if (kh2 < 2 && kw2 < 2 && (kh2 == 1 || sy == 1) && (kw2 == 1 || sx == 1)) {
+            int kh = kh2 == 0 ? 0 : 1 + sy, kw = kw2 == 0 ? 0 : 1 + sx;
+            v = w[((long)n * C + c) * 9 + kh * 3 + kw];
+        }
+        unsigned short h = f2bf(v);
+        if (wf) wf[((long)n * 9 + t2) * C4 + sc] = h;
+        if (wb) wb[((long)sc * 9 + t2) * N + n] = h;
+    }
+}
+
+// dW[n][c][kh][kw] = dW2[n][(s,c)][kh2][kw2] for the unique (s, kh2, kw2) that maps onto (kh, kw)
+__global__ void fold_weight_s2d_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int N, int C) {
+    const long total = (long)N * C * 9;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int t = (int)(i % 9);
+        int c = (int)((i / 9) % C);
+        long n = i / (9L * C);
+        int kh = t / 3, kw = t - kh * 3;
+        int kh2 = kh == 0 ? 0 : 1, sy = kh == 0 ? 1 : kh - 1;
+        int kw2 = kw == 0 ? 0 : 1, sx = kw == 0 ? 1 : kw - 1;
+        dw[i] = dw2[((n * 4 * C) + (sy * 2 + sx) * C + c) * 9 + kh2 * 3 + kw2];
     }
 }
 
@@ -903,7 +943,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         int hs = 0;
         int rc = stylex_launch_wgrad_halo(p, partial, s, &hs);
         if (rc) return rc;
-        long total = (long)p.N * p.Ck * 9;
+        long total = (long)p.N * p.Ck;
         int rb = (int)((total + 255) / 256);
         if (rb > 4096) rb = 4096;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, 9, hs);
@@ -931,7 +971,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
                 : (vec ? launch_wgrad<1, 1, true, false>(p, blocks, s) : launch_wgrad<1, 1, false, false>(p, blocks, s));
     }
     if (rc) return rc;
-    long total = (long)p.N * p.Ck * T;
+    long total = (long)p.N * p.Ck;
     int rb = (int)((total + 255) / 256);
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, T, splits);
@@ -948,5 +988,21 @@ int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, 
                            (unsigned short*)wb, N, C, T);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)wf, (float*)wb, N, C, T);
+    return (int)hipGetLastError();
+}
+
+int stylex_launch_pack_s2d(const float* w, void* wf, void* wb, int N, int C, hipStream_t s) {
+    long total = (long)N * C * 36;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_s2d_kernel, dim3(blocks), dim3(256), 0, s, w, (unsigned short*)wf, (unsigned short*)wb, N, C);
+    return (int)hipGetLastError();
+}
+
+int stylex_launch_fold_s2d(const float* dw2, float* dw, int N, int C, hipStream_t s) {
+    long total = (long)N * C * 9;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fold_weight_s2d_kernel, dim3(blocks), dim3(256), 0, s, dw2, dw, N, C);
     return (int)hipGetLastError();
 }

@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    // space-to-depth form of a stride-2 conv: taps that are structurally zero for this c-tile's sub-position
+    const unsigned tapmask = p.s2d_c ? stylex_s2d_tap_mask((c0 + wc * 32) / p.s2d_c) : 0x1ffu;
+
     // tr-read lane addressing (see header): group g = lane>>4 -> channel block (g&1)*16, k half (g>>1)*8
     const int i16 = lane & 15, g = lane >> 4;
     const int lane_off = ((g >> 1) * 8 + (i16 >> 2)) * PIX_ROW + ((g & 1) * 16 + (i16 & 3) * 4) * 2;
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
             bf16x8 av = tr_read8(a_base, (r * TW + pw0) * PIX_ROW, PIX_ROW);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
+                if (!((tapmask >> t) & 1)) continue;
                 const int kh = t / 3, kw = t - kh * 3;
                 bf16x8 bv = tr_read8(b_base, ((r + kh) * HWD + pw0 + kw) * PIX_ROW, PIX_ROW);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);

@@ -119,8 +119,14 @@ __global__ void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restr
 // ---- 3x3 binomial blur, reflect border: index rule -1 -> 1, n -> n-2 -------------------------
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
+// space-to-depth address of element (b, h, w, c) of a [B,H,W,C] tensor stored as [B,H/2,W/2,4C]
+__device__ __forceinline__ long s2d_off(int b, int h, int w, int c, int H, int W, int C) {
+    return (((long)b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * (4L * C) + (((h & 1) * 2 + (w & 1)) * C) + c;
+}
+
 template <int V>
-__global__ void blur3x3_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int C, int bf) {
+__global__ void blur3x3_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int C, int bf,
+                                   int s2d) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     const float f[3] = {1.f, 2.f, 1.f};
@@ -141,7 +147,7 @@ __global__ void blur3x3_fwd_kernel(const void* __restrict__ x, void* __restrict_
                 Vec<V>::fma(acc, f[dh + 1] * f[dw + 1] * (1.f / 16.f), Vec<V>::ld(x, base + ((long)hh * W + ww) * C, bf));
             }
         }
-        Vec<V>::st(y, pix * C + c, acc, bf);
+        Vec<V>::st(y, s2d ? s2d_off(b, h, w, c, H, W, C) : pix * C + c, acc, bf);
     }
 }
 
@@ -155,7 +161,8 @@ __device__ __forceinline__ float blur_coef(int o, int i, int n) {
 }
 
 template <int V>
-__global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C, int bf) {
+__global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C, int bf,
+                                   int s2d) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -176,7 +183,8 @@ __global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict
                 int ow = w + e;
                 if (ow < 0 || ow >= W) continue;
                 float cw = blur_coef(ow, w, W);
-                Vec<V>::fma(acc, ch * cw * (1.f / 16.f), Vec<V>::ld(dy, base + ((long)oh * W + ow) * C, bf));
+                Vec<V>::fma(acc, ch * cw * (1.f / 16.f),
+                            Vec<V>::ld(dy, s2d ? s2d_off(b, oh, ow, c, H, W, C) : base + ((long)oh * W + ow) * C, bf));
             }
         }
         Vec<V>::st(dx, pix * C + c, acc, bf);
@@ -297,12 +305,22 @@ int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, EW_ARGS) {
 int stylex_blur3x3_reflect_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
-    LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf);
+    LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 0);
 }
 int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
-    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
+    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 0);
+}
+int stylex_blur3x3_s2d_fwd(const void* x, void* y, EW_ARGS) {
+    EW_UNPACK
+    if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
+    LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 1);
+}
+int stylex_blur3x3_s2d_bwd(const void* dy, void* dx, EW_ARGS) {
+    EW_UNPACK
+    if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
+    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 1);
 }
 int stylex_bias_act_fwd(const void* x, const float* bias, const float* noise, int64_t noise_stride,
                         const float* noise_w, const float* noise_b, void* y, EW_ARGS) {

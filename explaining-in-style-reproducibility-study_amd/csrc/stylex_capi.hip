@@ -180,13 +180,15 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
         p.noise_b = epi->noise_b;
         p.residual = (const float*)epi->residual;
         p.res_scale = epi->res_scale;
+        p.s2d_c = (int)epi->s2d_c;
     }
     if ((flags & STYLEX_EPI_BIAS) && !p.bias) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_NOISE) && (!p.noise || !p.noise_w || !p.noise_b || p.noise_stride < p.Ho || p.noise_stride < p.Wo))
         return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_RESIDUAL) && !p.residual) return STYLEX_EINVAL;
-    double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW;
+    if (p.s2d_c && (p.Ck != 4 * p.s2d_c || p.KH != 3 || p.stride != 1 || p.pad != 1 || p.s2d_c % 64)) return STYLEX_EINVAL;
+    double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (p.s2d_c ? 4.0 : 1.0);  // algorithmic: 9*C, not 36*C
     ScopedTimer tm(0, flops, (hipStream_t)stream);
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -212,9 +214,11 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
         if (epi) {
             q.a_scale = epi->in_scale;
             q.out_scale = epi->out_scale;
+            q.s2d_c = (int)epi->s2d_c;
+            if (q.s2d_c && (q.N != 4 * q.s2d_c || q.s2d_c % 64)) return STYLEX_EINVAL;
         }
         if (!((flags & STYLEX_EPI_OSCALE) && !q.out_scale)) {
-            double fl = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6];
+            double fl = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6] / (q.s2d_c ? 4.0 : 1.0);
             ScopedTimer tmh(1, fl, (hipStream_t)stream);
             int rc = stylex_launch_halo(q, (hipStream_t)stream);
             if (rc != STYLEX_NOT_APPLICABLE) return rc;
@@ -266,7 +270,7 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
 }
 
 int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
-                             const int64_t* sh, const float* x_scale, const float* dy_scale, int precision,
+                             const int64_t* sh, const float* x_scale, const float* dy_scale, int s2d_c, int precision,
                              void* stream) {
     if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
@@ -279,9 +283,21 @@ int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* wor
     p.a2_scale = dy_scale;
     p.act_bf16 = precision == STYLEX_BF16_ACT;
     if (p.act_bf16) precision = STYLEX_BF16;
-    double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW;
+    p.s2d_c = s2d_c;
+    if (s2d_c && (p.Ck != 4 * s2d_c || s2d_c % 64 || p.KH != 3 || p.stride != 1)) return STYLEX_EINVAL;
+    double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (s2d_c ? 4.0 : 1.0);
     ScopedTimer tm(2, flops, (hipStream_t)stream);
     return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream);
+}
+
+int stylex_pack_weight_s2d(const float* w, void* wf, void* wb, const int64_t* sh, void* stream) {
+    if (!w || sh[0] < 1 || sh[1] < 1 || sh[2] != 3 || sh[3] != 3) return STYLEX_EINVAL;
+    return stylex_launch_pack_s2d(w, wf, wb, (int)sh[0], (int)sh[1], (hipStream_t)stream);
+}
+
+int stylex_fold_weight_grad_s2d(const float* dw2, float* dw, const int64_t* sh, void* stream) {
+    if (!dw2 || !dw || sh[0] < 1 || sh[1] < 1 || sh[2] != 3 || sh[3] != 3) return STYLEX_EINVAL;
+    return stylex_launch_fold_s2d(dw2, dw, (int)sh[0], (int)sh[1], (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -27,6 +27,8 @@ struct ConvKParams {
     int transposed;   // 0: forward gather  ih = oh*s + kh - p ; 1: data-gradient gather ih = (oh + p - kh)/s
     int phase_major;  // rows ordered by (oh&1, ow&1) first (transposed stride-2 only)
     int act_bf16;     // activation tensors (a, a2, y, residual) are bf16 instead of fp32 (STYLEX_BF16_ACT)
+    int s2d_c;        // >0: the conv is a 3x3/s2 conv in space-to-depth form: source channels = 4 sub-positions x s2d_c,
+                      //     structurally-zero (tap, sub-position) pairs are skipped (conv_halo / conv_wgrad_halo)
     int flip_taps;    // halo kernel: read weight tap 8-t for compute tap t (data gradient of a 3x3/s1/p1 conv)
     int M;            // B*Ho*Wo
     int flags;
@@ -50,3 +52,17 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s);
 bool stylex_wgrad_halo_applicable(const ConvKParams& p);
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);
 int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out);
+
+// Weight taps (bit kh*3+kw of the 3x3 frame) that are structurally non-zero for sub-position s = sy*2+sx of a
+// stride-2 3x3/pad-1 convolution rewritten over the space-to-depth input (frame offset -1 -> kh2 = 0 needs
+// the odd sub-row/col, offset 0 -> kh2 = 1 takes both, offset +1 never contributes).
+__host__ __device__ inline unsigned stylex_s2d_tap_mask(int s) {
+    const int sy = s >> 1, sx = s & 1;
+    unsigned m = 0;
+    for (int kh = 0; kh < 2; ++kh)
+        for (int kw = 0; kw < 2; ++kw)
+            if ((kh == 1 || sy == 1) && (kw == 1 || sx == 1)) m |= 1u << (kh * 3 + kw);
+    return m;
+}
+int stylex_launch_pack_s2d(const float* w, void* wf, void* wb, int N, int C, hipStream_t s);
+int stylex_launch_fold_s2d(const float* dw2, float* dw, int N, int C, hipStream_t s);

@@ -31,6 +31,7 @@ class ConvEpilogue(ctypes.Structure):
         ("noise_b", ctypes.c_void_p),
         ("residual", ctypes.c_void_p),
         ("res_scale", ctypes.c_float),
+        ("s2d_c", ctypes.c_int32),
     ]
 
 
@@ -46,7 +47,11 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_conv2d_bwd_weight_workspace_bytes": (ctypes.c_int64, [_i64p]),
     "stylex_conv2d_bwd_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p, _c_f, _c_f,
-                                                ctypes.c_int, ctypes.c_void_p]),
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_s2d_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_s2d_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_pack_weight_s2d": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_fold_weight_grad_s2d": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_reflect_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -202,6 +207,38 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     return wf, wb
 
 
+def pack_weight_s2d(w):
+    """OIHW {N,C,3,3} parameter of a stride-2 conv -> bf16 operands of its space-to-depth form (cached)."""
+    lib = _ensure_device(w)
+    key = None
+    if isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32:
+        key = (w.data_ptr(), w._version, tuple(w.shape), "s2d")
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is w:
+            return hit[1], hit[2]
+    wc = w.contiguous().float()
+    n, c, kh, kw = wc.shape
+    assert kh == 3 and kw == 3
+    wf = torch.empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
+    wb = torch.empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
+    _check(lib.stylex_pack_weight_s2d(_ptr(wc), _ptr(wf), _ptr(wb), _shape(n, c, 3, 3), _stream()),
+           "stylex_pack_weight_s2d")
+    if key is not None:
+        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (weakref.ref(w), wf, wb)
+    return wf, wb
+
+
+def fold_weight_grad_s2d(dw2, w_shape):
+    lib = _ensure_device(dw2)
+    n, c = w_shape[0], w_shape[1]
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dw2.device)
+    _check(lib.stylex_fold_weight_grad_s2d(_ptr(dw2.contiguous()), _ptr(dw), _shape(n, c, 3, 3), _stream()),
+           "stylex_fold_weight_grad_s2d")
+    return dw
+
+
 def _split_workspace(lib, shp, which, precision, like):
     nbytes = lib.stylex_conv2d_workspace_bytes(shp, which, precision)
     if nbytes <= 0:
@@ -210,17 +247,18 @@ def _split_workspace(lib, shp, which, precision, like):
 
 
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
-               noise_w=None, noise_b=None, residual=None, res_scale=1.0):
+               noise_w=None, noise_b=None, residual=None, res_scale=1.0, packed=None, w_shape=None, s2d_c=0):
     """x: channels_last [B,C,H,W] in the precision's activation dtype; w: OIHW parameter.
     Returns channels_last [B,N,Ho,Wo] of the same dtype."""
     lib = _ensure_device(x)
     adt = act_dtype(precision)
     assert is_cl(x) and x.dtype == adt, (x.dtype, adt)
-    sh = conv_shape(x.shape, w.shape, stride, pad)
-    wf, _ = pack_weight(w, True, False, precision)
+    sh = conv_shape(x.shape, w_shape if packed is not None else w.shape, stride, pad)
+    wf = packed if packed is not None else pack_weight(w, True, False, precision)[0]
     y = empty_cl((sh[0], sh[4], sh[9], sh[10]), x, adt)
     flags = 0
     epi = ConvEpilogue()
+    epi.s2d_c = int(s2d_c)
     keep = []
     if in_scale is not None:
         in_scale = _f32(in_scale)
@@ -258,15 +296,17 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
     return y
 
 
-def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_scale=None):
+def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_scale=None, packed=None, w_shape=None,
+                    s2d_c=0):
     lib = _ensure_device(dy)
     adt = act_dtype(precision)
     assert is_cl(dy) and dy.dtype == adt, (dy.dtype, adt)
-    sh = conv_shape(x_shape, w.shape, stride, pad)
+    sh = conv_shape(x_shape, w_shape if packed is not None else w.shape, stride, pad)
     assert tuple(dy.shape) == (sh[0], sh[4], sh[9], sh[10]), (dy.shape, sh)
-    _, wb = pack_weight(w, False, True, precision)
+    wb = packed if packed is not None else pack_weight(w, False, True, precision)[1]
     dx = empty_cl(tuple(x_shape), dy, adt)
     epi = ConvEpilogue()
+    epi.s2d_c = int(s2d_c)
     flags = 0
     in_scale, out_scale = _f32(in_scale), _f32(out_scale)
     if in_scale is not None:
@@ -281,7 +321,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     return dx
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None):
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None, s2d_c=0):
     lib = _ensure_device(x)
     adt = act_dtype(precision)
     assert is_cl(x) and is_cl(dy) and x.dtype == adt and dy.dtype == adt, (x.dtype, dy.dtype, adt)
@@ -294,7 +334,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     x_scale, dy_scale = _f32(x_scale), _f32(dy_scale)
     _check(lib.stylex_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, _ptr(x_scale),
-                                        _ptr(dy_scale), precision, _stream()), "stylex_conv2d_bwd_weight")
+                                        _ptr(dy_scale), int(s2d_c), precision, _stream()), "stylex_conv2d_bwd_weight")
     return dw
 
 
@@ -323,6 +363,26 @@ def blur3x3_fwd(x):
 
 def blur3x3_bwd(dy):
     return _ew("stylex_blur3x3_reflect_bwd", dy, tuple(dy.shape), tuple(dy.shape))
+
+
+def blur3x3_s2d_fwd(x):
+    """blur, written as [B, 4C, H/2, W/2] (space-to-depth, channel = ((h&1)*2+(w&1))*C + c)."""
+    lib = _ensure_device(x)
+    assert is_cl(x)
+    b, c, h, w = x.shape
+    y = empty_cl((b, 4 * c, h // 2, w // 2), x)
+    _check(lib.stylex_blur3x3_s2d_fwd(_ptr(x), _ptr(y), _shape(b, h, w, c), _adt(x), _stream()), "stylex_blur3x3_s2d_fwd")
+    return y
+
+
+def blur3x3_s2d_bwd(dy2):
+    lib = _ensure_device(dy2)
+    assert is_cl(dy2)
+    b, c4, h2, w2 = dy2.shape
+    dx = empty_cl((b, c4 // 4, 2 * h2, 2 * w2), dy2)
+    _check(lib.stylex_blur3x3_s2d_bwd(_ptr(dy2), _ptr(dx), _shape(b, 2 * h2, 2 * w2, c4 // 4), _adt(dy2), _stream()),
+           "stylex_blur3x3_s2d_bwd")
+    return dx
 
 
 def bias_act_fwd(x, bias=None, noise=None, noise_w=None, noise_b=None):

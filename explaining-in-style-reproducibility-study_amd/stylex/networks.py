@@ -167,10 +167,10 @@ class DiscriminatorBlock(nn.Module):  # reference :721-744
         res = self.conv_res(x)
         x = self.net(x)
         if exists(self.downsample):
-            blur, down = self.downsample[0], self.downsample[1]
-            # (conv(blur(x)) + bias + res) / sqrt(2): the merge of :743 rides in the conv epilogue
-            return ops.conv2d(blur(x), down.weight, down.bias, stride=2, padding=1, residual=res,
-                              res_scale=1 / math.sqrt(2))
+            down = self.downsample[1]
+            # (conv_s2(blur(x)) + bias + res) / sqrt(2): blur -> space-to-depth -> halo conv with the merge of
+            # :743 in its epilogue
+            return ops.blur_down(x, down.weight, down.bias, res, 1 / math.sqrt(2))
         return ops.residual_merge(x, res)
 
 

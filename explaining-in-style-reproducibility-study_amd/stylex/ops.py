@@ -328,6 +328,68 @@ class _ModConvFast(torch.autograd.Function):
         return gx, gs1, gd, gw, None, gnw, gnb, None, None
 
 
+class _BlurS2D(torch.autograd.Function):
+    """blur3x3 whose output is stored space-to-depth ([B,4C,H/2,W/2]) for the stride-2 conv that follows."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return hb.blur3x3_s2d_fwd(_cl(x))
+
+    @staticmethod
+    def backward(ctx, gy2):
+        return _BlurS2DBwd.apply(gy2)
+
+
+class _BlurS2DBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy2):
+        return hb.blur3x3_s2d_bwd(_cl(gy2))
+
+    @staticmethod
+    def backward(ctx, ggx):
+        return _BlurS2D.apply(ggx)
+
+
+class _DownS2DFast(torch.autograd.Function):
+    """(conv3x3_s2(x) + bias + residual) * res_scale with x given space-to-depth: runs as a 3x3/s1 conv over
+    4C channels on the LDS-halo kernels, structurally-zero taps skipped (exactly the original 9*C work)."""
+
+    @staticmethod
+    def forward(ctx, x2, w, bias, residual, res_scale):
+        x2 = _cl(x2)
+        if residual is not None:
+            residual = _cl(residual)
+        n, c = w.shape[0], w.shape[1]
+        wf2, _ = hb.pack_weight_s2d(w)
+        y = hb.conv2d_fwd(x2, None, 1, 1, _PRECISION, bias=bias, residual=residual, res_scale=res_scale, packed=wf2,
+                          w_shape=(n, 4 * c, 3, 3), s2d_c=c)
+        ctx.save_for_backward(x2, w)
+        ctx.cfg = (float(res_scale) if residual is not None else 1.0, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        scale, has_bias, has_res = ctx.cfg
+        n, c = w.shape[0], w.shape[1]
+        gy = _cl(gy)
+        want_dx = scale != 1.0
+        gz, gsum = hb.act_bwd_reduce(gy, None, False, scale, want_dx=want_dx)
+        if not want_dx:
+            gz = gy
+        gx2 = gw = None
+        if ctx.needs_input_grad[0]:
+            _, wb2 = hb.pack_weight_s2d(w)
+            gx2 = hb.conv2d_bwd_data(gz, None, tuple(x2.shape), 1, 1, _PRECISION, packed=wb2, w_shape=(n, 4 * c, 3, 3),
+                                     s2d_c=c)
+        if ctx.needs_input_grad[1]:
+            dw2 = hb.conv2d_bwd_weight(x2, gz, (n, 4 * c, 3, 3), 1, 1, _PRECISION, s2d_c=c)
+            gw = hb.fold_weight_grad_s2d(dw2, tuple(w.shape))
+        gb = gsum if (has_bias and ctx.needs_input_grad[2]) else None
+        return gx2, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None
+
+
 # ------------------------------------------------------------------------------------------
 # the HIP implementation object
 # ------------------------------------------------------------------------------------------
@@ -436,6 +498,16 @@ class HipOps:
         return _Blur.apply(_act(x))
 
     @staticmethod
+    def blur_down(x, weight, bias, residual, res_scale):
+        """(conv3x3_s2(blur(x)) + bias + residual) * res_scale — the tail of DiscriminatorBlock (:733-743)."""
+        b, c, h, w = x.shape
+        if (fast_enabled() and _PRECISION != hb.F32 and c % 64 == 0 and weight.shape[0] % 4 == 0 and h % 2 == 0
+                and w % 2 == 0 and w // 2 >= 16 and h // 2 >= 16 and tuple(weight.shape[2:]) == (3, 3)):
+            return _DownS2DFast.apply(_BlurS2D.apply(_act(x)), weight, bias, _act(residual), res_scale)
+        return HipOps.conv2d(HipOps.blur3x3(x), weight, bias, stride=2, padding=1, residual=residual,
+                             res_scale=res_scale)
+
+    @staticmethod
     def residual_merge(x, res):
         return (x + res) * (1 / math.sqrt(2))
 
@@ -481,6 +553,10 @@ def upsample2x(x):
 
 def blur3x3(x):
     return _IMPL.blur3x3(x)
+
+
+def blur_down(*a, **k):
+    return _IMPL.blur_down(*a, **k)
 
 
 def residual_merge(x, res):

@@ -86,6 +86,9 @@ typedef struct {
     const float* noise_b;   /* [N] */
     const void* residual;   /* [B][Ho][Wo][N], activation dtype */
     float res_scale;
+    int32_t s2d_c;          /* >0: space-to-depth form of a 3x3/stride-2/pad-1 conv (see stylex_blur3x3_s2d_fwd):
+                             * `shape` describes the 3x3/s1/p1 conv over 4*s2d_c channels, the weights come from
+                             * stylex_pack_weight_s2d, structurally-zero taps are skipped.  s2d_c % 64 == 0. */
 } stylex_conv_epilogue;
 
 /* Optional split-K workspace for launches that cannot fill the chip (few output tiles, long K):
@@ -116,8 +119,8 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* shape);
 /* x_scale [B][C] / dy_scale [B][N] (either may be NULL) are the per-sample
  * modulation / demodulation factors of the modulated conv, applied while staging. */
 int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
-                             const int64_t* shape, const float* x_scale, const float* dy_scale, int precision,
-                             void* stream);
+                             const int64_t* shape, const float* x_scale, const float* dy_scale, int s2d_c,
+                             int precision, void* stream);
 
 /* Elementwise / resampling entry points take `act_dtype`: 0 = fp32 activations, 1 = bf16 activations
  * (the storage type of STYLEX_BF16_ACT); arithmetic is fp32 either way.
@@ -133,6 +136,18 @@ int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, const int64_t* shap
  * shape = {B, H, W, C}.  Index rule (exact): -1 -> 1, H -> H-2. */
 int stylex_blur3x3_reflect_fwd(const void* x, void* y, const int64_t* shape, int act_dtype, void* stream);
 int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
+
+/* Space-to-depth pipeline for the blur + stride-2 conv of DiscriminatorBlock (stylex_train.py:733-742):
+ * the blur writes its [B,H,W,C] result as [B,H/2,W/2,4C] (channel = ((h&1)*2+(w&1))*C + c), which turns the
+ * 3x3/s2/p1 conv into a 3x3/s1/p1 conv over 4C channels whose weights (stylex_pack_weight_s2d, bf16,
+ * from the OIHW parameter {N,C,3,3}) are zero for 27 of the 36 (tap, sub-position) pairs; the conv
+ * kernels skip those (epi.s2d_c / s2d_c argument), so exactly the 9*C products of the original conv are
+ * computed while every operand is read once.  stylex_fold_weight_grad_s2d maps the weight gradient of
+ * the s2d conv ([N][4C][3][3]) back to the parameter layout.  H, W even. */
+int stylex_blur3x3_s2d_fwd(const void* x, void* y_s2d, const int64_t* shape, int act_dtype, void* stream);
+int stylex_blur3x3_s2d_bwd(const void* dy_s2d, void* dx, const int64_t* shape, int act_dtype, void* stream);
+int stylex_pack_weight_s2d(const float* w_oihw, void* w_fwd, void* w_bwd, const int64_t* shape, void* stream);
+int stylex_fold_weight_grad_s2d(const float* dw_s2d, float* dw_oihw, const int64_t* shape, void* stream);
 
 /* y = leaky_relu(x + bias[c] (+ noise[b][w][h]*noise_w[c] + noise_b[c]), 0.2)
  * (nn.Conv2d bias + leaky_relu, stylex_train.py:340-341,726-731; noise add :696-714).

@@ -48,6 +48,11 @@ class CpuOracleOps:
         return so.blur3x3_reflect(x)
 
     @staticmethod
+    def blur_down(x, weight, bias, residual, res_scale):
+        return CpuOracleOps.conv2d(so.blur3x3_reflect(x), weight, bias, stride=2, padding=1, residual=residual,
+                                   res_scale=res_scale)
+
+    @staticmethod
     def residual_merge(x, res):
         return (x + res) * (1 / math.sqrt(2))
 

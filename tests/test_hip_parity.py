@@ -169,6 +169,38 @@ def test_fast_fused_path_matches_differentiable_path(prec):
         close(a, b_, tol * 5, "fast grad " + nm)
 
 
+def test_s2d_downsample_path_matches_strided_conv():
+    """blur -> space-to-depth -> 3x3/s1 halo conv with skipped zero taps == blur -> 3x3/s2 conv (+bias+res)*c,
+    outputs and all gradients (bf16 mode: this path only exists on the bf16 kernels)."""
+    ops.set_precision("bf16")
+    g = torch.Generator().manual_seed(8)
+    B, C, N, H = 2, 64, 128, 64
+    x0 = torch.randn(B, C, H, H, generator=g)
+    w0 = torch.randn(N, C, 3, 3, generator=g) / 24
+    b0 = torch.randn(N, generator=g)
+    r0 = torch.randn(B, N, H // 2, H // 2, generator=g)
+
+    def run(fast):
+        prev = ops.set_fast(fast)
+        try:
+            x, w, b, r = (t.clone().to(DEV).requires_grad_() for t in (x0, w0, b0, r0))
+            y = ops.blur_down(x.contiguous(memory_format=torch.channels_last), w, b, r, 0.7)
+            (y.float() ** 2).mean().backward()
+            return y, [t.grad for t in (x, w, b, r)]
+        finally:
+            ops.set_fast(prev)
+
+    # float64 CPU reference of the same op
+    xr, wr, br, rr = (t.clone().double().requires_grad_() for t in (x0, w0, b0, r0))
+    yr = (F.conv2d(so.blur3x3_reflect(xr), wr, br, stride=2, padding=1) + rr) * 0.7
+    (yr ** 2).mean().backward()
+    for fast in (False, True):
+        y, gs = run(fast)
+        close(yr, y, TOLBF, "y fast=%s" % fast)
+        for nm, a, b_ in zip(("x", "w", "bias", "res"), (xr.grad, wr.grad, br.grad, rr.grad), gs):
+            close(a, b_, TOLBF * 2, "grad %s fast=%s" % (nm, fast))
+
+
 def test_conv_bias_lrelu_and_second_order():
     """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
     g = torch.Generator().manual_seed(5)
