@@ -215,8 +215,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
         }
     }
 
-    // epilogue: D[i][j]: col j = lane&31 -> output channel, row -> tile pixel
+    // ---- epilogue.  D[i][j]: col j = lane&31 -> output channel, rows -> 16 tile pixels per lane, i.e. the
+    // natural store is one element per lane (2-4 B).  The tile is therefore transposed through LDS (the halo /
+    // weight space is dead after the last barrier) and written with 16-byte row stores: a wave covers 1 KiB
+    // of contiguous NHWC output when N == BN.
     const int lj = lane & 31, lh = lane >> 5;
+    constexpr int OUT_ES = ABF ? 2 : 4;                    // output element size
+    constexpr int OROW = BN * OUT_ES + 16;                 // LDS row pitch of the staged output tile (+16 B skew)
+    static_assert(256 * OROW <= NP * ROWB + BN * 9 * ROWB, "output tile must fit in the staging LDS");
+    const bool wide = (p.N % (16 / OUT_ES) == 0);          // 16-byte global stores need aligned rows
+    if (wide) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + j * 32 + lj;
+            const bool nok = n < p.N;
+            const float bias = (nok && (p.flags & STYLEX_EPI_BIAS)) ? p.bias[n] : 0.f;
+            const float osc = (nok && (p.flags & STYLEX_EPI_OSCALE)) ? p.out_scale[(long)b * p.N + n] : 1.f;
+            float nw = 0.f, nb = 0.f;
+            if (nok && (p.flags & STYLEX_EPI_NOISE)) {
+                nw = p.noise_w[n];
+                nb = p.noise_b[n];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[i][j][r] * osc + bias;
+                    if (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL)) {
+                        const int ph = pix / TW, pw = pix - ph * TW;
+                        const int y = min(y0 + ph, H - 1), x = min(x0 + pw, W - 1);
+                        if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
+                        if ((p.flags & STYLEX_EPI_RESIDUAL) && nok)
+                            v = (v + act_ld1(p.residual, ((long)(b * H + y) * W + x) * p.N + n, p.act_bf16)) * p.res_scale;
+                    }
+                    if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
+                    char* d = smem + pix * OROW + (j * 32 + lj) * OUT_ES;
+                    if (ABF) *reinterpret_cast<unsigned short*>(d) = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+                    else *reinterpret_cast<float*>(d) = v;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN * OUT_ES / 16;  // 16-byte chunks per pixel row
+#pragma unroll
+        for (int k = 0; k < CPR; ++k) {
+            const int id = tid + 256 * k;
+            const int pix = id / CPR, q = id - pix * CPR;
+            const int ph = pix / TW, pw = pix - ph * TW;
+            const int y = y0 + ph, x = x0 + pw;
+            const int n = n0 + q * (16 / OUT_ES);
+            if (y < H && x < W && n < p.N) {
+                uint4 v = *reinterpret_cast<const uint4*>(smem + pix * OROW + q * 16);
+                char* dst = reinterpret_cast<char*>(p.y) + (((long)(b * H + y) * W + x) * p.N + n) * OUT_ES;
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + lj;
