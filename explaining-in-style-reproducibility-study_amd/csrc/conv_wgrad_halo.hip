@@ -102,55 +102,69 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
         const int y0 = (tt / tiles_x) * TH, x0 = (tt % tiles_x) * TW;
 
         if (ABF) {
-            // bf16 activations: raw 16-byte slots (8 channels), 8 slots per 64-channel pixel row, no conversion
+            // bf16 activations: raw 16-byte slots (8 channels), 8 slots per 64-channel pixel row, no conversion.
+            // ALL global loads of the tile (8 dy + 11 halo per thread) are issued before the first LDS store so
+            // that one memory latency covers the whole tile.
             const int q = tid & 7;
-            {
-                const int nn = n0 + q * 8;
-                float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
-                if (p.a2_scale && nn < N) {
-                    s0 = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn);
-                    s1 = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn + 4);
-                }
-#pragma unroll 4
-                for (int it = 0; it < 8; ++it) {
-                    int px = (tid >> 3) + 32 * it;
-                    int y = y0 + px / TW, x = x0 + (px % TW);
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (nn < N && y < H && x < W)
-                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.a2) + ((long)(b * H + y) * W + x) * N + nn);
-                    if (p.a2_scale) {
-                        float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
-                        v.x = pack_bf16(f0.x * s0.x, f0.y * s0.y); v.y = pack_bf16(f0.z * s0.z, f0.w * s0.w);
-                        v.z = pack_bf16(f1.x * s1.x, f1.y * s1.y); v.w = pack_bf16(f1.z * s1.z, f1.w * s1.w);
-                    }
-                    *reinterpret_cast<uint4*>(smem + (q >> 2) * DY_PANEL + px * PIX_ROW + (q & 3) * 16) = v;
-                }
+            const int nn = n0 + q * 8, cc = c0 + q * 8;
+            constexpr int XS = (NP + 31) / 32;
+            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, t0 = s0, t1 = s0;
+            if (p.a2_scale && nn < N) {
+                s0 = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn);
+                s1 = *reinterpret_cast<const float4*>(p.a2_scale + (long)b * N + nn + 4);
             }
-            {
-                const int cc = c0 + q * 8;
-                float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
-                if (p.a_scale && cc < C) {
-                    s0 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
-                    s1 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc + 4);
-                }
-#pragma unroll 4
-                for (int it = 0; it < (NP + 31) / 32; ++it) {
-                    int hp = (tid >> 3) + 32 * it;
-                    if (hp < NP) {
-                        int hh = hp / HWD, ww = hp - hh * HWD;
-                        int y = y0 - 1 + hh, x = x0 - 1 + ww;
-                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                        if (cc < C && y >= 0 && y < H && x >= 0 && x < W)
-                            v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.a) + ((long)(b * H + y) * W + x) * C + cc);
-                        if (p.a_scale) {
-                            float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
-                            v.x = pack_bf16(f0.x * s0.x, f0.y * s0.y); v.y = pack_bf16(f0.z * s0.z, f0.w * s0.w);
-                            v.z = pack_bf16(f1.x * s1.x, f1.y * s1.y); v.w = pack_bf16(f1.z * s1.z, f1.w * s1.w);
-                        }
-                        *reinterpret_cast<uint4*>(smem + X_OFF + (q >> 2) * X_PANEL + hp * PIX_ROW + (q & 3) * 16) = v;
-                    }
-                }
+            if (p.a_scale && cc < C) {
+                t0 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc);
+                t1 = *reinterpret_cast<const float4*>(p.a_scale + (long)b * C + cc + 4);
             }
+            auto scaled = [&](uint4 v, const float4& a0, const float4& a1) -> uint4 {
+                float4 f0 = act_unpack4(make_uint2(v.x, v.y)), f1 = act_unpack4(make_uint2(v.z, v.w));
+                v.x = pack_bf16(f0.x * a0.x, f0.y * a0.y); v.y = pack_bf16(f0.z * a0.z, f0.w * a0.w);
+                v.z = pack_bf16(f1.x * a1.x, f1.y * a1.y); v.w = pack_bf16(f1.z * a1.z, f1.w * a1.w);
+                return v;
+            };
+            auto load_x = [&](int it) -> uint4 {
+                int hp = (tid >> 3) + 32 * it;
+                int hh = hp / HWD, ww = hp - hh * HWD;
+                int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                if (hp < NP && cc < C && y >= 0 && y < H && x >= 0 && x < W)
+                    return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.a) + ((long)(b * H + y) * W + x) * C + cc);
+                return make_uint4(0u, 0u, 0u, 0u);
+            };
+            auto store_x = [&](int it, uint4 v) {
+                int hp = (tid >> 3) + 32 * it;
+                if (hp < NP) {
+                    if (p.a_scale) v = scaled(v, t0, t1);
+                    *reinterpret_cast<uint4*>(smem + X_OFF + (q >> 2) * X_PANEL + hp * PIX_ROW + (q & 3) * 16) = v;
+                }
+            };
+            constexpr int XH = (XS + 1) / 2;
+            uint4 vd[8], vx[XH];
+            // batch 1 in flight: 8 dy + first half of the halo
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int px = (tid >> 3) + 32 * it;
+                int y = y0 + px / TW, x = x0 + (px % TW);
+                vd[it] = make_uint4(0u, 0u, 0u, 0u);
+                if (nn < N && y < H && x < W)
+                    vd[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.a2) + ((long)(b * H + y) * W + x) * N + nn);
+            }
+#pragma unroll
+            for (int it = 0; it < XH; ++it) vx[it] = load_x(it);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int px = (tid >> 3) + 32 * it;
+                uint4 v = vd[it];
+                if (p.a2_scale) v = scaled(v, s0, s1);
+                *reinterpret_cast<uint4*>(smem + (q >> 2) * DY_PANEL + px * PIX_ROW + (q & 3) * 16) = v;
+            }
+            // batch 2: second half of the halo is issued while the first is being stored
+#pragma unroll
+            for (int it = 0; it < XS - XH; ++it) vd[it] = load_x(XH + it);
+#pragma unroll
+            for (int it = 0; it < XH; ++it) store_x(it, vx[it]);
+#pragma unroll
+            for (int it = 0; it < XS - XH; ++it) store_x(XH + it, vd[it]);
         } else {
             // ---- stage dy tile: 256 px x 64 n (16 float4 per pixel), 16 float4 per thread
             {
