@@ -95,12 +95,13 @@ def cpu_baseline(args):
     tr = so.OracleTrainer(TinyClassifier(seed=99), LPIPSStandIn(seed=4242), cyc(), image_size=args.image_size,
                           network_capacity=16, fmap_max=512, batch_size=bs, gradient_accumulate_every=args.gae,
                           lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1)
-    tr.steps = 1  # a non-GP step
+    tr.steps = 1  # two non-GP steps (bounded sample: ~10-20 s of CPU work)
     t0 = time.time()
     tr.train()
+    tr.train()
     dt = time.time() - t0
-    return {"value": bs * args.gae / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "1 non-GP Trainer.train() of the CPU oracle at %dpx, batch %d, GAE %d (%.1f s); stand-in "
+    return {"value": 2 * bs * args.gae / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "2 non-GP Trainer.train() calls of the CPU oracle at %dpx, batch %d, GAE %d (%.1f s); stand-in "
                       "classifier/LPIPS" % (args.image_size, bs, args.gae, dt)}
 
 
@@ -116,7 +117,7 @@ def main():
     ap.add_argument("--classifier", default="resnet")
     ap.add_argument("--workdir", default="/tmp/stylex_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--roofline-steps", type=int, default=4)
     args = ap.parse_args()
@@ -173,8 +174,17 @@ def main():
         name, r = max(rep.items(), key=lambda kv: kv[1]["ms"])
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+        # HBM bytes per launch of that class from the PMC passes of tools/collect_traffic.py (committed under
+        # profiles/); null when no measurement exists for the class / precision
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if name in tj and args.precision in tj.get("command", ""):
+                traffic = round(tj[name]["bytes_per_launch"])
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": "conv_%s (implicit-GEMM MFMA)" % name, "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(1, r["launches"]), 4),
                 "classes": {k: {"tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "ms": round(v["ms"], 2),
                                 "launches": v["launches"]} for k, v in rep.items()}}
