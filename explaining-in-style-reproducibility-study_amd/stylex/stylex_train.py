@@ -526,7 +526,9 @@ class Trainer:
                     if self.alternating_training:
                         encoder_input = True
                 generated = m.G(w_styles, inoise)
+            ops.set_fast(True)  # the fake branch is only ever differentiated once
             fake_out = m.D_aug(generated, detach=True, **aug)
+            ops.set_fast(not apply_gp)  # the gradient penalty differentiates the real branch twice
             real_out = m.D_aug(real, **aug)
             divergence = hinge_loss(real_out, fake_out)
             disc_loss = divergence
