@@ -34,6 +34,27 @@ struct Vec<1> {
     static __device__ __forceinline__ void fma(T& a, float w, T x) { a = fmaf(w, x, a); }
 };
 
+struct F8 {
+    float4 a, b;
+};
+template <>
+struct Vec<8> {  // bf16 activations only: 8 channels = one 16-byte access per lane
+    typedef F8 T;
+    static __device__ __forceinline__ T zero() { return F8{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}; }
+    static __device__ __forceinline__ T ld(const void* p, long off, int) {
+        uint4 h = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + off);
+        return F8{act_unpack4(make_uint2(h.x, h.y)), act_unpack4(make_uint2(h.z, h.w))};
+    }
+    static __device__ __forceinline__ void st(void* p, long off, T v, int) {
+        uint2 lo = act_pack4(v.a), hi = act_pack4(v.b);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + off) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    static __device__ __forceinline__ void fma(T& acc, float w, T x) {
+        Vec<4>::fma(acc.a, w, x.a);
+        Vec<4>::fma(acc.b, w, x.b);
+    }
+};
+
 // ---- bilinear x2 index rule (exact integer arithmetic) -------------------------------------
 // out[2k]   = .25*in[max(k-1,0)] + .75*in[k]
 // out[2k+1] = .75*in[k]          + .25*in[min(k+1,n-1)]
@@ -276,7 +297,9 @@ inline bool vec_ok(int C, const void* a, const void* b) {
 
 #define LAUNCH_EW(kern, work, a, b, ...)                                                                    \
     do {                                                                                                    \
-        if (vec_ok(C, a, b))                                                                                \
+        if (bf && (C % 8 == 0) && vec_ok(C, a, b))                                                          \
+            hipLaunchKernelGGL(kern<8>, dim3(grid_for((work) / 8)), dim3(256), 0, s, __VA_ARGS__);          \
+        else if (vec_ok(C, a, b))                                                                           \
             hipLaunchKernelGGL(kern<4>, dim3(grid_for((work) / 4)), dim3(256), 0, s, __VA_ARGS__);          \
         else                                                                                                \
             hipLaunchKernelGGL(kern<1>, dim3(grid_for(work)), dim3(256), 0, s, __VA_ARGS__);                \
