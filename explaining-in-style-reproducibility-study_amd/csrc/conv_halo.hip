@@ -35,7 +35,9 @@ constexpr int ROWB = 80;  // LDS row pitch in bytes (32 bf16 + 16 B pad)
 
 // ABF: activations are bf16 in HBM -> the halo is staged with raw 16-byte (8-channel) loads and no
 // conversion; otherwise fp32 activations are converted to bf16 on the way into LDS.
-template <int TW, int TN, bool ABF>
+// S2D: space-to-depth form with per-chunk tap masks (kept out of the plain variant: the mask branches stop the
+// compiler from software-pipelining the LDS reads across taps).  EPIX: epilogue may carry noise / residual.
+template <int TW, int TN, bool ABF, bool S2D, bool EPIX>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p) {
     constexpr int TH = 256 / TW, HWD = TW + 2, NP = (TH + 2) * HWD;
     constexpr int BN = TN * 32;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     // sub-position of the source-channel chunk (forward) or of this block's output-channel tile (dgrad)
     const unsigned all_taps = 0x1ffu;
     auto wmask_of_chunk = [&](int c0) -> unsigned {
-        if (!p.s2d_c) return all_taps;
+        if (!S2D) return all_taps;
         return stylex_s2d_tap_mask(p.flip_taps ? n0 / p.s2d_c : c0 / p.s2d_c);
     };
     unsigned cur_wmask = all_taps;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             int ck = c0 + qq * 8;
             int gt = p.flip_taps ? 8 - tap : tap;
-            if (r < W_ROWS && n0 + nl < p.N && ck < C && ((wm_next >> gt) & 1)) {
+            if (r < W_ROWS && n0 + nl < p.N && ck < C && (!S2D || ((wm_next >> gt) & 1))) {
                 v = *reinterpret_cast<const uint4*>(wsrc + ((long)(n0 + nl) * 9 + gt) * C + ck);
             }
             wreg[it] = v;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     auto compute = [&]() {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (!((cur_wmask >> (p.flip_taps ? 8 - tap : tap)) & 1)) continue;  // block-uniform skip (s2d form)
+            if (S2D && !((cur_wmask >> (p.flip_taps ? 8 - tap : tap)) & 1)) continue;  // block-uniform skip
             const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 for (int r = 0; r < 16; ++r) {
                     const int pix = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float v = acc[i][j][r] * osc + bias;
-                    if (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL)) {
+                    if (EPIX && (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL))) {
                         const int ph = pix / TW, pw = pix - ph * TW;
                         const int y = min(y0 + ph, H - 1), x = min(x0 + pw, W - 1);
                         if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
@@ -304,11 +306,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     }
 }
 
-template <int TW, int TN, bool ABF>
+template <int TW, int TN, bool ABF, bool S2D, bool EPIX>
 int launch_halo(const ConvKParams& p, hipStream_t s) {
     constexpr int TH = 256 / TW, NP = (TH + 2) * (TW + 2), BN = TN * 32;
     constexpr size_t sm = (size_t)NP * ROWB + (size_t)BN * 9 * ROWB;
-    auto k = conv3x3_halo_bf16_kernel<TW, TN, ABF>;
+    auto k = conv3x3_halo_bf16_kernel<TW, TN, ABF, S2D, EPIX>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -331,10 +333,23 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return STYLEX_NOT_APPLICABLE;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return STYLEX_NOT_APPLICABLE;
     const bool wide = p.Wo >= 32;
+    const bool epix = (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL)) != 0;
     if (p.act_bf16) {
-        if (p.N > 32) return wide ? launch_halo<32, 2, true>(p, s) : launch_halo<16, 2, true>(p, s);
-        return wide ? launch_halo<32, 1, true>(p, s) : launch_halo<16, 1, true>(p, s);
+        if (p.s2d_c) {  // always N >= 64 here (s2d_c % 64 == 0)
+            if (p.N > 32) return wide ? launch_halo<32, 2, true, true, true>(p, s) : launch_halo<16, 2, true, true, true>(p, s);
+            return wide ? launch_halo<32, 1, true, true, true>(p, s) : launch_halo<16, 1, true, true, true>(p, s);
+        }
+        if (epix) {
+            if (p.N > 32) return wide ? launch_halo<32, 2, true, false, true>(p, s) : launch_halo<16, 2, true, false, true>(p, s);
+            return wide ? launch_halo<32, 1, true, false, true>(p, s) : launch_halo<16, 1, true, false, true>(p, s);
+        }
+        if (p.N > 32) return wide ? launch_halo<32, 2, true, false, false>(p, s) : launch_halo<16, 2, true, false, false>(p, s);
+        return wide ? launch_halo<32, 1, true, false, false>(p, s) : launch_halo<16, 1, true, false, false>(p, s);
     }
-    if (p.N > 32) return wide ? launch_halo<32, 2, false>(p, s) : launch_halo<16, 2, false>(p, s);
-    return wide ? launch_halo<32, 1, false>(p, s) : launch_halo<16, 1, false>(p, s);
+    if (p.s2d_c) {
+        if (p.N > 32) return wide ? launch_halo<32, 2, false, true, true>(p, s) : launch_halo<16, 2, false, true, true>(p, s);
+        return wide ? launch_halo<32, 1, false, true, true>(p, s) : launch_halo<16, 1, false, true, true>(p, s);
+    }
+    if (p.N > 32) return wide ? launch_halo<32, 2, false, false, true>(p, s) : launch_halo<16, 2, false, false, true>(p, s);
+    return wide ? launch_halo<32, 1, false, false, true>(p, s) : launch_halo<16, 1, false, false, true>(p, s);
 }
