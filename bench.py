@@ -60,7 +60,8 @@ def build_trainer(args, device, rank, world):
                     fmap_max=512, batch_size=args.batch * world, gradient_accumulate_every=args.gae, lr=2e-4,
                     ttur_mult=1.5, mixed_prob=0.9, rec_scaling=1, kl_scaling=1, aug_prob=0.,
                     alternating_training=True, classifier_name=args.classifier, classifier_path=None,
-                    evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None, is_ddp=world > 1, rank=rank,
+                    evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None,
+                    is_ddp=world > 1 or os.environ.get("STYLEX_FORCE_DDP") == "1", rank=rank,
                     world_size=world, device=device)
     tr.loader = st.cycle(ring)
     tr.dataset = list(range(10 ** 6))
@@ -129,8 +130,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda:%d" % local_rank)
-    if world > 1:
+    force_ddp = os.environ.get("STYLEX_FORCE_DDP") == "1"  # 1-rank RCCL smoke test of the N>1 code path
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import hip_backend as hb
@@ -213,7 +216,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

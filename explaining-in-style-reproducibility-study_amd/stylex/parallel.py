@@ -13,7 +13,9 @@ import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True inside an initialised process group (a 1-rank group still runs the collectives: used to smoke-test
+    the RCCL path on a single-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def broadcast_parameters(module, src=0):

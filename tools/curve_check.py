@@ -1,0 +1,53 @@
+"""Loss-curve parity over 100 steps (north_star): config-1 shape (64 px, B=4, GAE=2) on the HIP fp32 path vs the
+reference's own CPU trajectory (tests/golden/curve_64.npz).  Prints the per-step relative error and the horizon
+up to which |err| <= 1e-3 * max(1, |ref|)."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd", "stylex"), os.path.join(ROOT, "oracle")]
+import ops  # noqa: E402
+import stylex_train as st  # noqa: E402
+from lpips_standin import LPIPSStandIn  # noqa: E402
+from ref_shim import TinyClassifier  # noqa: E402
+
+
+def run(n=100, precision="fp32", fast=None):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "curve_64.npz"))
+    size, cap, fmax, bs, gae = (int(v) for v in g["config"])
+    dev = torch.device("cuda:0")
+    ops.set_precision(precision)
+    cls = TinyClassifier(seed=int(g["cls_seed"])).to(dev)
+    gd = torch.Generator().manual_seed(int(g["data_seed"]))
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    tr = st.Trainer(name="curve", base_dir="/tmp/stylex_curve", image_size=size, network_capacity=cap, fmap_max=fmax,
+                    batch_size=bs, gradient_accumulate_every=gae, lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1,
+                    classifier=cls, lpips_fn=LPIPSStandIn(seed=int(g["lpips_seed"])).to(dev), classifier_name="resnet",
+                    evaluate_every=10 ** 9, save_every=10 ** 9, device=dev)
+    tr.loader = st.cycle(batches)
+    tr.save = lambda *a, **k: None
+    tr.evaluate = lambda *a, **k: None
+    rows = []
+    for _ in range(n):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                     np.nan if tr.last_gp_loss is None else tr.last_gp_loss])
+    return np.array(rows), g["scalars"][:n]
+
+
+if __name__ == "__main__":
+    got, ref = run()
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    worst = np.nanmax(err, axis=1)
+    horizon = int(np.argmax(worst > 1e-3)) if (worst > 1e-3).any() else len(worst)
+    for i in range(0, len(worst), 5):
+        print("step %3d  max rel err %.2e   D %.4g vs %.4g   G %.4g vs %.4g" % (i, worst[i], got[i, 0], ref[i, 0], got[i, 1], ref[i, 1]))
+    print("horizon (all 5 scalars within 1e-3): %d steps of %d; finite: %s" % (horizon, len(worst), bool(np.isfinite(got[:, :4]).all())))
