@@ -526,10 +526,19 @@ class Trainer:
                     if self.alternating_training:
                         encoder_input = True
                 generated = m.G(w_styles, inoise)
-            ops.set_fast(True)  # the fake branch is only ever differentiated once
-            fake_out = m.D_aug(generated, detach=True, **aug)
-            ops.set_fast(not apply_gp)  # the gradient penalty differentiates the real branch twice
-            real_out = m.D_aug(real, **aug)
+            if not apply_gp and not self.aug_prob:
+                # D has no batch statistics: D(fake) and D(real) are one pass over the concatenated batch
+                # (same arithmetic per sample; half the launches of the launch-bound small layers).  The second
+                # random() keeps the draw count of the two AugWrapper calls of the reference (:1331-1333).
+                ops.set_fast(True)
+                both = m.D_aug(torch.cat((generated, real), dim=0), detach=True, **aug)
+                random()
+                fake_out, real_out = both[:generated.shape[0]], both[generated.shape[0]:]
+            else:
+                ops.set_fast(True)  # the fake branch is only ever differentiated once
+                fake_out = m.D_aug(generated, detach=True, **aug)
+                ops.set_fast(not apply_gp)  # the gradient penalty differentiates the real branch twice
+                real_out = m.D_aug(real, **aug)
             divergence = hinge_loss(real_out, fake_out)
             disc_loss = divergence
             if apply_gp:
