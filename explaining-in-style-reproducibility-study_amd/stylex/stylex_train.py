@@ -159,6 +159,13 @@ def gradient_penalty(images, output, weight=10):
     return weight * ((norms - 1) ** 2).mean()
 
 
+def gradient_norms(images, output):
+    """Per-sample ||dD/dx||_2 (the inner term of gradient_penalty), differentiable."""
+    (gradients,) = torch.autograd.grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
+                                       create_graph=True, retain_graph=True, only_inputs=True)
+    return ops.rowwise_sumsq(_flat_rows(gradients)).sqrt()
+
+
 def calc_pl_lengths(styles, images):
     """Path lengths (reference :306-316); pl_noise is drawn on the CPU generator for draw-order parity."""
     num_pixels = images.shape[2] * images.shape[3]
@@ -506,47 +513,76 @@ class Trainer:
         avg_pl_length = self.pl_mean
         latents_fn = None
 
+        # Micro-step batching: G, D and the encoder carry no batch statistics, so the `gae` micro-steps of a
+        # phase are evaluated as ONE pass over their concatenated batch (same per-sample arithmetic, the
+        # weight-gradient GEMMs sum over gae*B rows at once, half the launches of the launch-bound small
+        # layers).  Inputs are still DRAWN micro-step by micro-step in the reference's order (loader, Python
+        # random(), torch.randn), so every RNG stream is consumed identically.  With augmentation on
+        # (AugWrapper consumes RNG per call) every micro-step stays its own group.
+        fuse = not self.aug_prob
+        groups = [list(range(gae))] if fuse else [[i] for i in range(gae)]
+
+        def D_call(images, detach=False):
+            if fuse:  # AugWrapper at prob 0 is D itself; its random() draw is issued where the reference draws it
+                return m.D(images.detach() if detach else images)
+            return m.D_aug(images, detach=detach, **aug)
+
+        def cat(ts):
+            return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+
         # ---------------- discriminator phase ----------------
-        # fused once-differentiable kernels unless this phase differentiates twice (gradient penalty)
-        ops.set_fast(not apply_gp)
         m.D_opt.zero_grad()
         encoder_input = False
-        for micro in range(gae):
-            real = self._next_batch()
+        for group in groups:
+            reals, ws, noises = [], [], []
+            with torch.no_grad():  # the generator/encoder graph is never used in this phase (:1330-1331)
+                for _ in group:
+                    reals.append(self._next_batch())
+                    if (not self.alternating_training) or encoder_input:
+                        _, _, w_styles = self._styles_from_encoder(self._next_batch())
+                        inoise = image_noise(batch_size, image_size, device=dev)
+                        encoder_input = False
+                    else:
+                        latents_fn = mixed_list if random() < self.mixed_prob else noise_list
+                        w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
+                        if self.alternating_training:
+                            encoder_input = True
+                    ws.append(w_styles)
+                    noises.append(inoise)
+                    if fuse:
+                        random(), random()  # the two AugWrapper draws of this micro-step (:1331-1333)
+                ops.set_fast(True)
+                generated = m.G(cat(ws), cat(noises))
+            real = cat(reals)
+            n_fake = generated.shape[0]
             if apply_gp:
                 real.requires_grad_()
-            with torch.no_grad():  # the generator/encoder graph is never used in this phase (:1330-1331)
-                if (not self.alternating_training) or encoder_input:
-                    _, _, w_styles = self._styles_from_encoder(self._next_batch())
-                    inoise = image_noise(batch_size, image_size, device=dev)
-                    encoder_input = False
-                else:
-                    latents_fn = mixed_list if random() < self.mixed_prob else noise_list
-                    w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
-                    if self.alternating_training:
-                        encoder_input = True
-                generated = m.G(w_styles, inoise)
-            if not apply_gp and not self.aug_prob:
-                # D has no batch statistics: D(fake) and D(real) are one pass over the concatenated batch
-                # (same arithmetic per sample; half the launches of the launch-bound small layers).  The second
-                # random() keeps the draw count of the two AugWrapper calls of the reference (:1331-1333).
-                ops.set_fast(True)
-                both = m.D_aug(torch.cat((generated, real), dim=0), detach=True, **aug)
-                random()
-                fake_out, real_out = both[:generated.shape[0]], both[generated.shape[0]:]
-            else:
                 ops.set_fast(True)  # the fake branch is only ever differentiated once
-                fake_out = m.D_aug(generated, detach=True, **aug)
-                ops.set_fast(not apply_gp)  # the gradient penalty differentiates the real branch twice
-                real_out = m.D_aug(real, **aug)
-            divergence = hinge_loss(real_out, fake_out)
-            disc_loss = divergence
-            if apply_gp:
-                gp = gradient_penalty(real, real_out)
-                gp_val = gp.detach()
-                disc_loss = disc_loss + gp
+                fake_out = D_call(generated, detach=True)
+                ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
+                real_out = D_call(real)
+                grad_norms = gradient_norms(real, real_out)
+            else:
+                # D(fake) and D(real) are one pass over the concatenated batch
+                ops.set_fast(True)
+                if fuse:
+                    both = D_call(torch.cat((generated, real), dim=0), detach=True)
+                    fake_out, real_out = both[:n_fake], both[n_fake:]
+                else:
+                    fake_out = D_call(generated, detach=True)
+                    real_out = D_call(real)
+            disc_loss, lo = 0, 0
+            for r in reals:
+                sl = slice(lo, lo + r.shape[0])
+                lo += r.shape[0]
+                divergence = hinge_loss(real_out[sl], fake_out[sl])
+                disc_loss = disc_loss + divergence
+                if apply_gp:
+                    gp = 10 * ((grad_norms[sl] - 1) ** 2).mean()
+                    gp_val = gp.detach()
+                    disc_loss = disc_loss + gp
+                tot_d += divergence.detach() / gae
             (disc_loss / gae).backward()
-            tot_d += divergence.detach() / gae
         if self.is_ddp:
             self._d_sync.all_reduce()
         self.d_loss = float(tot_d)  # the one host sync of this phase
@@ -559,43 +595,59 @@ class Trainer:
         # ---------------- generator phase ----------------
         if self.alternating_training:
             encoder_input = False
+        if apply_pl:  # path-length regularisation draws torch RNG between micro-steps: no batching
+            groups = [[i] for i in range(gae)]
         ops.set_fast(not apply_pl)  # path-length regularisation is the only double backward of this phase
         m.G_opt.zero_grad()
         set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
         try:
-            for micro in range(gae):
-                batch = self._next_batch()
-                enc_step = (not self.alternating_training) or encoder_input
-                if enc_step:
-                    enc_out, real_logits, w_styles = self._styles_from_encoder(batch)
-                    inoise = image_noise(batch_size, image_size, device=dev)
-                else:
-                    w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
-                generated = m.G(w_styles, inoise)
-                fake_out = m.D_aug(generated, **aug)
-                loss = gen_hinge_loss(fake_out, None)
-                total = loss
-                if enc_step:
-                    gen_logits = self.classifier.classify_images(generated)
-                    rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, m.encoder(generated), enc_out,
-                                                                     self.lpips_fn) / gae
-                    kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
-                if apply_pl:
-                    pl_lengths = calc_pl_lengths(w_styles, generated)
-                    avg_pl_length = np.mean(pl_lengths.detach().cpu().numpy())
-                    if not is_empty(self.pl_mean):
-                        pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
-                        if not torch.isnan(pl_loss):
-                            total = total + pl_loss
-                total = total / gae
-                if enc_step:
-                    (total + rec + kl).backward()  # == the three backward calls of :1436-1438
-                    tot_rec += rec.detach()
-                    tot_kl += kl.detach()
-                else:
-                    total.backward()
-                tot_g += loss.detach() / gae
-                encoder_input = not encoder_input
+            for group in groups:
+                ws, noises, micro = [], [], []
+                for _ in group:
+                    batch = self._next_batch()
+                    enc_step = (not self.alternating_training) or encoder_input
+                    if enc_step:
+                        enc_out, real_logits, w_styles = self._styles_from_encoder(batch)
+                        inoise = image_noise(batch_size, image_size, device=dev)
+                        micro.append((batch, enc_out, real_logits))
+                    else:
+                        w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
+                        micro.append(None)
+                    ws.append(w_styles)
+                    noises.append(inoise)
+                    if fuse:
+                        random()  # the AugWrapper draw of this micro-step (:1417)
+                    encoder_input = not encoder_input
+                w_all = cat(ws)
+                generated_all = m.G(w_all, cat(noises))
+                fake_all = D_call(generated_all)
+                total_all, lo = 0, 0
+                for w_styles, enc in zip(ws, micro):
+                    sl = slice(lo, lo + w_styles.shape[0])
+                    lo += w_styles.shape[0]
+                    generated = generated_all[sl]
+                    loss = gen_hinge_loss(fake_all[sl], None)
+                    total = loss
+                    if apply_pl:
+                        pl_lengths = calc_pl_lengths(w_all, generated)
+                        avg_pl_length = np.mean(pl_lengths.detach().cpu().numpy())
+                        if not is_empty(self.pl_mean):
+                            pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
+                            if not torch.isnan(pl_loss):
+                                total = total + pl_loss
+                    total = total / gae
+                    if enc is not None:
+                        batch, enc_out, real_logits = enc
+                        gen_logits = self.classifier.classify_images(generated)
+                        rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, m.encoder(generated),
+                                                                         enc_out, self.lpips_fn) / gae
+                        kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
+                        total = total + rec + kl  # one backward == the three backward calls of :1436-1438
+                        tot_rec += rec.detach()
+                        tot_kl += kl.detach()
+                    total_all = total_all + total
+                    tot_g += loss.detach() / gae
+                total_all.backward()
         finally:
             set_requires_grad(m.D, True)
             ops.set_fast(False)
