@@ -585,12 +585,7 @@ class Trainer:
             (disc_loss / gae).backward()
         if self.is_ddp:
             self._d_sync.all_reduce()
-        self.d_loss = float(tot_d)  # the one host sync of this phase
-        if gp_val is not None:
-            self.last_gp_loss = float(gp_val)
-        if math.isnan(self.d_loss):
-            raise NanException  # reference: raise_if_nan hook on the loss (:1352) — before the step
-        m.D_opt.step()
+        m.D_opt.step()  # no host sync here: the NaN check of the reference sits at the end of the step (:1483)
 
         # ---------------- generator phase ----------------
         if self.alternating_training:
@@ -653,16 +648,19 @@ class Trainer:
             ops.set_fast(False)
         if self.is_ddp:
             self._g_sync.all_reduce()
-        self.g_loss, rec_f, kl_f = (float(v) for v in torch.stack((tot_g, tot_rec, tot_kl)).tolist())
+        m.G_opt.step()
+
+        # the one host sync of the step: all loss scalars in one transfer
+        vals = torch.stack((tot_d, tot_g, tot_rec, tot_kl, gp_val if gp_val is not None else tot_d)).tolist()
+        self.d_loss, self.g_loss, rec_f, kl_f = vals[:4]
+        if gp_val is not None:
+            self.last_gp_loss = vals[4]
         if (not self.alternating_training) or gae > 1:
             self.total_rec_loss, self.total_kl_loss = rec_f, kl_f
-        if math.isnan(self.g_loss):
-            raise NanException
         if exists(self.tb_writer):
             for k, v in (("G", self.g_loss), ("D", self.d_loss), ("rec", self.total_rec_loss),
                          ("kl", self.total_kl_loss)):
                 self.tb_writer.add_scalar("loss/" + k, v, self.steps)
-        m.G_opt.step()
 
         if apply_pl and not np.isnan(avg_pl_length):  # EMA(0.99), reference :1128, :1471-1473
             self.pl_mean = avg_pl_length if self.pl_mean is None else self.pl_mean * 0.99 + 0.01 * avg_pl_length
@@ -670,6 +668,10 @@ class Trainer:
             m.EMA()
         if self.is_main and self.steps <= 25000 and self.steps % 1000 == 2:
             m.reset_parameter_averaging()
+        if math.isnan(self.g_loss) or math.isnan(self.d_loss):  # save from NaN errors (reference :1483-1486)
+            print(f"NaN detected for generator or discriminator. Loading from checkpoint #{self.checkpoint_num}")
+            self.load(self.checkpoint_num)
+            raise NanException
         if self.is_main:
             if self.steps % self.save_every == 0:
                 self.save(self.checkpoint_num)

@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     prec = {"bf16": hb.BF16_ACT, "bf16_f32act": hb.BF16, "fp32": hb.F32}[a.precision]
@@ -62,14 +62,30 @@ def main():
     for (name, c, n, res, k, s, p) in layers(a.size):
         if a.only and a.only not in name:
             continue
-        x = torch.randn(a.batch, c, res, res, device=dev).to(adt).contiguous(memory_format=torch.channels_last)
-        w = torch.randn(n, c, k, k, device=dev) * 0.05
-        y = hb.conv2d_fwd(x, w, s, p, prec)
-        dy = torch.randn_like(y)
-        t_f = timeit(lambda: hb.conv2d_fwd(x, w, s, p, prec), a.iters)
-        t_d = timeit(lambda: hb.conv2d_bwd_data(dy, w, tuple(x.shape), s, p, prec), a.iters)
-        t_w = timeit(lambda: hb.conv2d_bwd_weight(x, dy, tuple(w.shape), s, p, prec), a.iters)
-        fl = 2.0 * y.numel() * c * k * k
+        cp = c
+        if c == 3:  # the product pads RGB to one 16-byte slot (ops._pad_rgb)
+            cp = 8 if adt == torch.bfloat16 else 4
+        npad = 4 if n == 3 else n
+        w = torch.randn(npad, cp, k, k, device=dev) * 0.05
+        if k == 3 and s == 2 and prec == hb.BF16_ACT:
+            # the product's down-sampling conv: space-to-depth input, 3x3/s1 over 4C channels, masked taps
+            x = torch.randn(a.batch, 4 * c, res // 2, res // 2, device=dev).to(adt).contiguous(memory_format=torch.channels_last)
+            wf2, wb2 = hb.pack_weight_s2d(w)
+            ws = (n, 4 * c, 3, 3)
+            fwd = lambda: hb.conv2d_fwd(x, None, 1, 1, prec, packed=wf2, w_shape=ws, s2d_c=c)
+            y = fwd()
+            dy = torch.randn_like(y)
+            bwd = lambda: hb.conv2d_bwd_data(dy, None, tuple(x.shape), 1, 1, prec, packed=wb2, w_shape=ws, s2d_c=c)
+            wgr = lambda: hb.conv2d_bwd_weight(x, dy, ws, 1, 1, prec, s2d_c=c)
+        else:
+            x = torch.randn(a.batch, cp, res, res, device=dev).to(adt).contiguous(memory_format=torch.channels_last)
+            fwd = lambda: hb.conv2d_fwd(x, w, s, p, prec)
+            y = fwd()
+            dy = torch.randn_like(y)
+            bwd = lambda: hb.conv2d_bwd_data(dy, w, tuple(x.shape), s, p, prec)
+            wgr = lambda: hb.conv2d_bwd_weight(x, dy, tuple(w.shape), s, p, prec)
+        t_f, t_d, t_w = timeit(fwd, a.iters), timeit(bwd, a.iters), timeit(wgr, a.iters)
+        fl = 2.0 * a.batch * n * (y.shape[2] * y.shape[3]) * c * k * k
         byts = float(x.element_size()) * (x.numel() + y.numel()) + 4.0 * w.numel()
         print("%-10s %5d %5d %4d %d %d | %9.3f %9.3f %9.3f | %6.1f %6.1f %6.1f | %7.0f" % (
             name, c, n, res, k, s, t_f, t_d, t_w, fl / t_f / 1e9, fl / t_d / 1e9, fl / t_w / 1e9, byts / t_f / 1e6))
