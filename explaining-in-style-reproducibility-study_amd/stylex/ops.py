@@ -64,65 +64,110 @@ def _act(t):
 # ------------------------------------------------------------------------------------------
 
 
+_INPUTS_ONLY = False
+
+
+class inputs_only:
+    """Context for `torch.autograd.grad(..., inputs=<activations>)` calls (gradient penalty, path length):
+    autograd asks every Function for ALL its input gradients even when only the data path is wanted, so the
+    weight/bias gradients of that first backward would be computed and thrown away.  Inside this context the
+    conv Functions skip them."""
+
+    def __enter__(self):
+        global _INPUTS_ONLY
+        self.prev, _INPUTS_ONLY = _INPUTS_ONLY, True
+
+    def __exit__(self, *exc):
+        global _INPUTS_ONLY
+        _INPUTS_ONLY = self.prev
+
+
+def _want_param_grad(ctx, i):
+    return ctx.needs_input_grad[i] and not _INPUTS_ONLY
+
+
+def _fwd(x, w, stride, pad, s2d, **epi):
+    """conv forward; s2d = C of the original stride-2 conv when x is its space-to-depth image."""
+    if s2d:
+        wf2, _ = hb.pack_weight_s2d(w)
+        return hb.conv2d_fwd(x, None, 1, 1, _PRECISION, packed=wf2, w_shape=(w.shape[0], 4 * s2d, 3, 3), s2d_c=s2d, **epi)
+    return hb.conv2d_fwd(x, w, stride, pad, _PRECISION, **epi)
+
+
+def _bwd_data(gy, w, x_shape, stride, pad, s2d):
+    if s2d:
+        _, wb2 = hb.pack_weight_s2d(w)
+        return hb.conv2d_bwd_data(gy, None, x_shape, 1, 1, _PRECISION, packed=wb2, w_shape=(w.shape[0], 4 * s2d, 3, 3),
+                                  s2d_c=s2d)
+    return hb.conv2d_bwd_data(gy, w, x_shape, stride, pad, _PRECISION)
+
+
+def _bwd_weight(x, gy, w_shape, stride, pad, s2d):
+    if s2d:
+        dw2 = hb.conv2d_bwd_weight(x, gy, (w_shape[0], 4 * s2d, 3, 3), 1, 1, _PRECISION, s2d_c=s2d)
+        return hb.fold_weight_grad_s2d(dw2, tuple(w_shape))
+    return hb.conv2d_bwd_weight(x, gy, w_shape, stride, pad, _PRECISION)
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
+    def forward(ctx, x, w, stride, pad, s2d=0):
         x = _cl(x)
         ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, _PRECISION)
-        return hb.conv2d_fwd(x, w, stride, pad, _PRECISION)
+        ctx.cfg = (stride, pad, s2d)
+        return _fwd(x, w, stride, pad, s2d)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        stride, pad, _ = ctx.cfg
+        stride, pad, s2d = ctx.cfg
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _Dgrad.apply(gy, w, tuple(x.shape), stride, pad)
-        if ctx.needs_input_grad[1]:
-            gw = _Wgrad.apply(x, gy, tuple(w.shape), stride, pad)
-        return gx, gw, None, None
+            gx = _Dgrad.apply(gy, w, tuple(x.shape), stride, pad, s2d)
+        if _want_param_grad(ctx, 1):
+            gw = _Wgrad.apply(x, gy, tuple(w.shape), stride, pad, s2d)
+        return gx, gw, None, None, None
 
 
 class _Dgrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gy, w, x_shape, stride, pad):
+    def forward(ctx, gy, w, x_shape, stride, pad, s2d=0):
         gy = _cl(gy)
         ctx.save_for_backward(gy, w)
-        ctx.cfg = (x_shape, stride, pad)
-        return hb.conv2d_bwd_data(gy, w, x_shape, stride, pad, _PRECISION)
+        ctx.cfg = (x_shape, stride, pad, s2d)
+        return _bwd_data(gy, w, x_shape, stride, pad, s2d)
 
     @staticmethod
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
-        x_shape, stride, pad = ctx.cfg
+        x_shape, stride, pad, s2d = ctx.cfg
         d_gy = d_w = None
         if ctx.needs_input_grad[0]:
-            d_gy = _Conv.apply(ggx, w, stride, pad)
-        if ctx.needs_input_grad[1]:
-            d_w = _Wgrad.apply(ggx, gy, tuple(w.shape), stride, pad)
-        return d_gy, d_w, None, None, None
+            d_gy = _Conv.apply(ggx, w, stride, pad, s2d)
+        if _want_param_grad(ctx, 1):
+            d_w = _Wgrad.apply(ggx, gy, tuple(w.shape), stride, pad, s2d)
+        return d_gy, d_w, None, None, None, None
 
 
 class _Wgrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gy, w_shape, stride, pad):
+    def forward(ctx, x, gy, w_shape, stride, pad, s2d=0):
         x, gy = _cl(x), _cl(gy)
         ctx.save_for_backward(x, gy)
-        ctx.cfg = (w_shape, stride, pad)
-        return hb.conv2d_bwd_weight(x, gy, w_shape, stride, pad, _PRECISION)
+        ctx.cfg = (w_shape, stride, pad, s2d)
+        return _bwd_weight(x, gy, w_shape, stride, pad, s2d)
 
     @staticmethod
     def backward(ctx, ggw):
         x, gy = ctx.saved_tensors
-        w_shape, stride, pad = ctx.cfg
+        w_shape, stride, pad, s2d = ctx.cfg
         d_x = d_gy = None
         ggw = ggw.contiguous()
         if ctx.needs_input_grad[0]:
-            d_x = _Dgrad.apply(gy, ggw, tuple(x.shape), stride, pad)
+            d_x = _Dgrad.apply(gy, ggw, tuple(x.shape), stride, pad, s2d)
         if ctx.needs_input_grad[1]:
-            d_gy = _Conv.apply(x, ggw, stride, pad)
-        return d_x, d_gy, None, None, None
+            d_gy = _Conv.apply(x, ggw, stride, pad, s2d)
+        return d_x, d_gy, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -143,7 +188,7 @@ class _BiasAct(torch.autograd.Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         gx = _BiasActBwd.apply(gy, y)
-        gb = gx.sum(dim=(0, 2, 3), dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        gb = gx.sum(dim=(0, 2, 3), dtype=torch.float32) if (ctx.has_bias and _want_param_grad(ctx, 1)) else None
         return gx, gb
 
 
@@ -286,6 +331,40 @@ class _ConvBiasActFast(torch.autograd.Function):
         return gx, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None, None, None, None
 
 
+class _ConvBiasActDD(torch.autograd.Function):
+    """Same fused forward kernel as _ConvBiasActFast; the backward is composed of differentiable Functions
+    (activation-derivative kernel, the conv triad), so it can be differentiated again: this is what the
+    real branch of a gradient-penalty step runs.  `s2d` = C when x is the space-to-depth image of a stride-2
+    conv's input (see _DownS2DFast)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, stride, pad, lrelu, res_scale, s2d=0):
+        x = _cl(x)
+        if residual is not None:
+            residual = _cl(residual)
+        y = _fwd(x, w, stride, pad, s2d, bias=bias, lrelu=lrelu, residual=residual, res_scale=res_scale)
+        ctx.save_for_backward(x, w, y if lrelu else None)
+        ctx.cfg = (stride, pad, lrelu, float(res_scale) if residual is not None else 1.0, bias is not None,
+                   residual is not None, s2d)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, lrelu, scale, has_bias, has_res, s2d = ctx.cfg
+        gz = _BiasActBwd.apply(gy, y.detach()) if lrelu else gy
+        if scale != 1.0:
+            gz = gz * scale
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _Dgrad.apply(gz, w, tuple(x.shape), stride, pad, s2d)
+        if _want_param_grad(ctx, 1):
+            gw = _Wgrad.apply(x, gz, tuple(w.shape), stride, pad, s2d)
+        if has_bias and _want_param_grad(ctx, 2):
+            gb = gz.sum(dim=(0, 2, 3), dtype=torch.float32)
+        return gx, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None
+
+
 class _ModConvFast(torch.autograd.Function):
     """y = lrelu?( d[b,o] * conv(x * s1[b,i], w) + noise[b,w,h]*nw[o] + nb[o] )   (Conv2DMod + noise + act)"""
 
@@ -420,9 +499,9 @@ class HipOps:
         x, weight, n_out = _pad_rgb(_act(x), weight)
         residual = _act(residual)
         padded_out = n_out != weight.shape[0]
-        if fast_enabled() and not padded_out:
-            y = _ConvBiasActFast.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)
-            return y
+        if not padded_out:
+            fn = _ConvBiasActFast if fast_enabled() else _ConvBiasActDD
+            return fn.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)
         y = _Conv.apply(x, weight, stride, padding)
         if padded_out:
             y = y[:, :n_out]
@@ -501,9 +580,12 @@ class HipOps:
     def blur_down(x, weight, bias, residual, res_scale):
         """(conv3x3_s2(blur(x)) + bias + residual) * res_scale — the tail of DiscriminatorBlock (:733-743)."""
         b, c, h, w = x.shape
-        if (fast_enabled() and _PRECISION != hb.F32 and c % 64 == 0 and weight.shape[0] % 4 == 0 and h % 2 == 0
+        if (_PRECISION != hb.F32 and c % 64 == 0 and weight.shape[0] % 4 == 0 and h % 2 == 0
                 and w % 2 == 0 and w // 2 >= 16 and h // 2 >= 16 and tuple(weight.shape[2:]) == (3, 3)):
-            return _DownS2DFast.apply(_BlurS2D.apply(_act(x)), weight, bias, _act(residual), res_scale)
+            x2 = _BlurS2D.apply(_act(x))
+            if fast_enabled():
+                return _DownS2DFast.apply(x2, weight, bias, _act(residual), res_scale)
+            return _ConvBiasActDD.apply(x2, weight, bias, _act(residual), 1, 1, False, res_scale, c)
         return HipOps.conv2d(HipOps.blur3x3(x), weight, bias, stride=2, padding=1, residual=residual,
                              res_scale=res_scale)
 

@@ -153,16 +153,14 @@ def _flat_rows(t):
 def gradient_penalty(images, output, weight=10):
     """10 * mean((||dD/dx||_2 - 1)^2) on reals (reference :296-303); the per-sample norm is the
     wavefront-shuffle reduction kernel."""
-    (gradients,) = torch.autograd.grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
-                                       create_graph=True, retain_graph=True, only_inputs=True)
-    norms = ops.rowwise_sumsq(_flat_rows(gradients)).sqrt()
-    return weight * ((norms - 1) ** 2).mean()
+    return weight * ((gradient_norms(images, output) - 1) ** 2).mean()
 
 
 def gradient_norms(images, output):
     """Per-sample ||dD/dx||_2 (the inner term of gradient_penalty), differentiable."""
-    (gradients,) = torch.autograd.grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
-                                       create_graph=True, retain_graph=True, only_inputs=True)
+    with ops.inputs_only():  # parameter gradients of this first backward would be discarded
+        (gradients,) = torch.autograd.grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
+                                           create_graph=True, retain_graph=True, only_inputs=True)
     return ops.rowwise_sumsq(_flat_rows(gradients)).sqrt()
 
 
@@ -171,8 +169,9 @@ def calc_pl_lengths(styles, images):
     num_pixels = images.shape[2] * images.shape[3]
     pl_noise = (torch.randn(images.shape) / math.sqrt(num_pixels)).to(images.device)
     outputs = (images * pl_noise).sum()
-    (pl_grads,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones_like(outputs),
-                                      create_graph=True, retain_graph=True, only_inputs=True)
+    with ops.inputs_only():
+        (pl_grads,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones_like(outputs),
+                                          create_graph=True, retain_graph=True, only_inputs=True)
     return (pl_grads ** 2).sum(dim=2).mean(dim=1).sqrt()
 
 

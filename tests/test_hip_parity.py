@@ -232,8 +232,9 @@ def test_conv_bias_lrelu_and_second_order():
     close(g0, g1, what="gx")
     close(p0, p1, 1e-4, "penalty")
     for a, b, nm in zip(gr0, gr1, ("w1", "b1", "w2", "b2")):
-        if a is None:
-            assert b is None or float(b.abs().max()) == 0.0
+        if a is None or b is None:  # None == structurally zero gradient
+            other = b if a is None else a
+            assert other is None or float(other.abs().max()) == 0.0, nm
             continue
         close(a, b, 2e-4, "second-order grad " + nm)
 
@@ -336,7 +337,8 @@ def test_gp_and_pl_double_backward_vs_reference_golden():
     gp.backward()
     grads = dict(m.D.named_parameters())
     for n, gs in zip(g["gp/grad_names"], g["gp/grad_stats"]):
-        close_stats(gs, grads[str(n)].grad.cpu(), 5e-4)
+        pr = grads[str(n)]  # a structurally-zero gradient (conv biases under a pure GP loss) may come back as None
+        close_stats(gs, (torch.zeros_like(pr) if pr.grad is None else pr.grad).cpu(), 5e-4)
     close(g["gp/grad_fc_w"], m.D.fc.weight.grad, 2e-4, "gp grad fc")
     close(g["gp/grad_b0_res_w"], m.D.blocks[0].conv_res.weight.grad, 2e-4, "gp grad conv_res")
     w = torch.from_numpy(g["pl/w"]).to(DEV).requires_grad_()
