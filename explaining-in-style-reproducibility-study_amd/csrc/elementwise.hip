@@ -212,6 +212,82 @@ __global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict
     }
 }
 
+// ---- bf16 column-strip blur (forward and adjoint) ---------------------------------------------
+// One lane owns 8 channels of one column and walks ROWS output rows with a 3-row sliding window of
+// horizontally filtered values, so every input row is fetched once per strip (+2 halo rows) instead of three
+// times; the x+-1 neighbours are the lines the adjacent lanes fetch anyway.  Used for bf16 tensors only (the
+// fp32 parity mode keeps the direct 9-tap kernel and its summation order).
+template <bool ADJ>
+__device__ __forceinline__ void blur_tap(int pos, int d, int n, int& idx, float& coef) {
+    if (!ADJ) {
+        idx = reflect1(pos + d, n);
+        coef = d == 0 ? 2.f : 1.f;
+    } else {
+        idx = pos + d;
+        if (idx < 0 || idx >= n) {
+            idx = pos;
+            coef = 0.f;
+        } else {
+            coef = blur_coef(idx, pos, n);
+        }
+    }
+}
+
+template <bool ADJ, int ROWS>
+__global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short* __restrict__ in,
+                                                            unsigned short* __restrict__ out, int B, int H, int W, int C,
+                                                            int s2d) {
+    const int cv = C >> 3;
+    const int strips = (H + ROWS - 1) / ROWS;
+    const long total = (long)B * strips * W * cv;
+    const bool in_s2d = ADJ && s2d, out_s2d = !ADJ && s2d;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8;
+        long t = i / cv;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h0 = (int)(t % strips) * ROWS;
+        const int b = (int)(t / strips);
+        int iw[3];
+        float cw[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) blur_tap<ADJ>(w, e - 1, W, iw[e], cw[e]);
+        auto addr = [&](int hh, int ww) -> long {
+            return in_s2d ? s2d_off(b, hh, ww, c, H, W, C) : (((long)b * H + hh) * W + ww) * C + c;
+        };
+        auto hrow = [&](int hh) -> F8 {  // horizontally filtered row hh (already a valid row index)
+            F8 acc = Vec<8>::zero();
+#pragma unroll
+            for (int e = 0; e < 3; ++e) Vec<8>::fma(acc, cw[e], Vec<8>::ld(in, addr(hh, iw[e]), 1));
+            return acc;
+        };
+        int ih;
+        float ch;
+        F8 win[3];
+        blur_tap<ADJ>(h0, -1, H, ih, ch);
+        win[0] = hrow(ih);
+        win[1] = hrow(h0);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int h = h0 + r;
+            if (h >= H) break;
+            float cv3[3];
+            int dummy;
+            blur_tap<ADJ>(h, 1, H, ih, cv3[2]);
+            win[2] = hrow(ih);
+            blur_tap<ADJ>(h, -1, H, dummy, cv3[0]);
+            cv3[1] = ADJ ? blur_coef(h, h, H) : 2.f;
+            F8 acc = Vec<8>::zero();
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Vec<8>::fma(acc, cv3[a] * (1.f / 16.f), win[a]);
+            const long o = out_s2d ? s2d_off(b, h, w, c, H, W, C) : (((long)b * H + h) * W + w) * C + c;
+            Vec<8>::st(out, o, acc, 1);
+            win[0] = win[1];
+            win[1] = win[2];
+        }
+    }
+}
+
 // ---- bias (+ transposed noise) + LeakyReLU(0.2) ----------------------------------------------
 template <int V>
 __global__ void bias_act_fwd_kernel(const void* __restrict__ x, const float* __restrict__ bias,
@@ -306,6 +382,21 @@ inline bool vec_ok(int C, const void* a, const void* b) {
         return (int)hipGetLastError();                                                                      \
     } while (0)
 
+static bool blur_strip_ok(int bf, int H, int C, const void* a, const void* b) {
+    return bf && (C % 8 == 0) && H >= 8 && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
+           ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+}
+template <bool ADJ>
+static int launch_blur_strip(const void* in, void* out, int B, int H, int W, int C, int s2d, hipStream_t s) {
+    constexpr int ROWS = 8;
+    long work = (long)B * ((H + ROWS - 1) / ROWS) * W * (C / 8);
+    long blocks = (work + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((blur3x3_strip_kernel<ADJ, ROWS>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const unsigned short*)in, (unsigned short*)out, B, H, W, C, s2d);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 #define EW_ARGS const int64_t* sh, int act_dtype, void* stream
@@ -328,21 +419,25 @@ int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, EW_ARGS) {
 int stylex_blur3x3_reflect_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
+    if (blur_strip_ok(bf, H, C, x, y)) return launch_blur_strip<false>(x, y, B, H, W, C, 0, s);
     LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 0);
 }
 int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
+    if (blur_strip_ok(bf, H, C, dy, dx)) return launch_blur_strip<true>(dy, dx, B, H, W, C, 0, s);
     LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 0);
 }
 int stylex_blur3x3_s2d_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
+    if (blur_strip_ok(bf, H, C, x, y)) return launch_blur_strip<false>(x, y, B, H, W, C, 1, s);
     LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 1);
 }
 int stylex_blur3x3_s2d_bwd(const void* dy, void* dx, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
+    if (blur_strip_ok(bf, H, C, dy, dx)) return launch_blur_strip<true>(dy, dx, B, H, W, C, 1, s);
     LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 1);
 }
 int stylex_bias_act_fwd(const void* x, const float* bias, const float* noise, int64_t noise_stride,

@@ -239,6 +239,36 @@ def test_conv_bias_lrelu_and_second_order():
         close(a, b, 2e-4, "second-order grad " + nm)
 
 
+def test_bf16_strip_blur_vs_oracle():
+    """bf16 tensors take the column-strip blur kernels (forward and adjoint, plain and space-to-depth output):
+    compare with the oracle on the bf16-rounded input; sizes exercise a partial last strip and both borders."""
+    ops.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(11)
+        for (B, C, H, W) in ((2, 8, 10, 12), (1, 16, 8, 8), (2, 64, 36, 20)):
+            x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+            r = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+            xr = x.clone().double().requires_grad_()
+            yr = so.blur3x3_reflect(xr)
+            (yr * r.double()).sum().backward()
+            xd = x.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+            y = ops.blur3x3(xd)
+            assert y.dtype == torch.bfloat16
+            (y.float() * r.to(DEV)).sum().backward()
+            close(yr, y, 1e-2, "strip blur fwd %s" % ((B, C, H, W),))
+            close(xr.grad, xd.grad, 1e-2, "strip blur adjoint %s" % ((B, C, H, W),))
+            # space-to-depth output form and its adjoint
+            y2 = hb.blur3x3_s2d_fwd(xd.detach())
+            want = F.pixel_unshuffle(yr.detach().float(), 2).view(B, C, 4, H // 2, W // 2).transpose(1, 2).reshape(
+                B, 4 * C, H // 2, W // 2)
+            close(want, y2, 1e-2, "strip blur s2d fwd")
+            r2 = F.pixel_unshuffle(r, 2).view(B, C, 4, H // 2, W // 2).transpose(1, 2).reshape(B, 4 * C, H // 2, W // 2)
+            gx2 = hb.blur3x3_s2d_bwd(r2.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last))
+            close(xr.grad, gx2, 1e-2, "strip blur s2d adjoint")
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_resampling_exact_index_rules():
     g = load_golden("ops")
     x = torch.from_numpy(g["up/x"])
