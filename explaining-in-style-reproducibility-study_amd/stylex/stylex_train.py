@@ -89,8 +89,43 @@ def _dev(device):
     return torch.device("cuda:%d" % int(device))
 
 
+class _Staging:
+    """Reusable pinned host buffers for the per-step RNG uploads (latents, image noise).  A pageable
+    .to(device) blocks the host until the stream drains (the copy is stream-ordered), serialising host and GPU
+    at the top of every phase; drawing straight into a pinned buffer and copying with non_blocking=True does
+    not.  Each (shape) has a small ring of buffers; a slot is reused only after the event recorded behind its
+    last copy has completed."""
+    RING = 8
+    _slots = {}
+
+    @classmethod
+    def take(cls, shape):
+        ring = cls._slots.setdefault(tuple(shape), {"i": 0, "bufs": []})
+        if len(ring["bufs"]) < cls.RING:
+            ring["bufs"].append([torch.empty(shape, pin_memory=True), None])
+            slot = ring["bufs"][-1]
+        else:
+            slot = ring["bufs"][ring["i"] % cls.RING]
+            ring["i"] += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+        return slot
+
+    @classmethod
+    def upload(cls, shape, fill, device):
+        """fill(buf) draws in place on the CPU generator (same stream consumption as torch.randn/empty+fill)."""
+        device = _dev(device)
+        if device.type != "cuda":
+            return fill(torch.empty(shape)).to(device)
+        slot = cls.take(shape)
+        out = fill(slot[0]).to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
+
+
 def noise(n, latent_dim, device):  # reference :319-320 — CPU RNG, then copy (keeps the draw order)
-    return torch.randn(n, latent_dim).to(_dev(device))
+    return _Staging.upload((n, latent_dim), lambda t: t.normal_(), device)
 
 
 def noise_list(n, layers, latent_dim, device):
@@ -107,7 +142,7 @@ def latent_to_w(style_vectorizer, latent_descr):
 
 
 def image_noise(n, im_size, device):  # reference :336-337
-    return torch.empty(n, im_size, im_size, 1).uniform_(0., 1.).to(_dev(device))
+    return _Staging.upload((n, im_size, im_size, 1), lambda t: t.uniform_(0., 1.), device)
 
 
 def evaluate_in_chunks(max_batch_size, model, *args):
@@ -167,7 +202,7 @@ def gradient_norms(images, output):
 def calc_pl_lengths(styles, images):
     """Path lengths (reference :306-316); pl_noise is drawn on the CPU generator for draw-order parity."""
     num_pixels = images.shape[2] * images.shape[3]
-    pl_noise = (torch.randn(images.shape) / math.sqrt(num_pixels)).to(images.device)
+    pl_noise = _Staging.upload(tuple(images.shape), lambda t: t.normal_().div_(math.sqrt(num_pixels)), images.device)
     outputs = (images * pl_noise).sum()
     with ops.inputs_only():
         (pl_grads,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones_like(outputs),
@@ -331,7 +366,28 @@ class StylEx(nn.Module):
 # ------------------------------------------------------------------------------------------
 
 
+def _lazy_loss(name):
+    """Loss scalar attribute that resolves the step's pending device->host copy on first read."""
+    def get(self):
+        self._resolve_losses(raise_nan=False)
+        return self.__dict__.get("_" + name)
+
+    def put(self, v):
+        self.__dict__["_" + name] = v
+
+    return property(get, put)
+
+
 class Trainer:
+    # Same attribute names as the reference (:1108-1116), backed by ONE asynchronous device->host copy per
+    # step: train() does not wait for the GPU, so the host prepares the next step's inputs while the GPU
+    # still runs this one.  Reading any of them (print_log, tests) waits for the copy and nothing else.
+    d_loss = _lazy_loss("d_loss")
+    g_loss = _lazy_loss("g_loss")
+    total_rec_loss = _lazy_loss("total_rec_loss")
+    total_kl_loss = _lazy_loss("total_kl_loss")
+    last_gp_loss = _lazy_loss("last_gp_loss")
+    _pending = None
     def __init__(self, name="default", results_dir="results", models_dir="models", base_dir="./", image_size=128,
                  network_capacity=16, fmap_max=512, transparent=False, batch_size=4, mixed_prob=0.9,
                  gradient_accumulate_every=1, lr=2e-4, lr_mlp=0.1, ttur_mult=2, rel_disc_loss=False, num_workers=None,
@@ -480,6 +536,28 @@ class Trainer:
     def _next_batch(self):
         return next(self.loader).to(self.device, non_blocking=True)
 
+    def _resolve_losses(self, raise_nan=True):
+        """Wait for the pending loss copy of the last step (only that copy, not the stream) and publish the
+        scalars.  NaN handling as the reference (:1483-1486): reload the last checkpoint and raise; train()
+        calls this for the previous step once the next discriminator phase is enqueued, and before saving."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            host, done, has_gp, keep_rec = pend
+            if done is not None:
+                done.synchronize()
+            vals = host.tolist()
+            self.d_loss, self.g_loss = vals[0], vals[1]
+            if has_gp:
+                self.last_gp_loss = vals[4]
+            if keep_rec:
+                self.total_rec_loss, self.total_kl_loss = vals[2], vals[3]
+            self._nan = math.isnan(vals[0]) or math.isnan(vals[1])
+        if raise_nan and getattr(self, "_nan", False):
+            self._nan = False
+            print(f"NaN detected for generator or discriminator. Loading from checkpoint #{self.checkpoint_num}")
+            self.load(self.checkpoint_num)
+            raise NanException
+
     def _styles_from_encoder(self, batch):
         m = self.StylEx
         enc = m.encoder(batch)
@@ -584,7 +662,8 @@ class Trainer:
             (disc_loss / gae).backward()
         if self.is_ddp:
             self._d_sync.all_reduce()
-        m.D_opt.step()  # no host sync here: the NaN check of the reference sits at the end of the step (:1483)
+        self._resolve_losses()  # previous step's scalars: its copy finished long ago, the GPU keeps running
+        m.D_opt.step()
 
         # ---------------- generator phase ----------------
         if self.alternating_training:
@@ -649,13 +728,17 @@ class Trainer:
             self._g_sync.all_reduce()
         m.G_opt.step()
 
-        # the one host sync of the step: all loss scalars in one transfer
-        vals = torch.stack((tot_d, tot_g, tot_rec, tot_kl, gp_val if gp_val is not None else tot_d)).tolist()
-        self.d_loss, self.g_loss, rec_f, kl_f = vals[:4]
-        if gp_val is not None:
-            self.last_gp_loss = vals[4]
-        if (not self.alternating_training) or gae > 1:
-            self.total_rec_loss, self.total_kl_loss = rec_f, kl_f
+        # all loss scalars of the step leave in one asynchronous copy (resolved lazily, see _resolve_losses)
+        stack = torch.stack((tot_d, tot_g, tot_rec, tot_kl, gp_val if gp_val is not None else tot_d))
+        keep_rec = (not self.alternating_training) or gae > 1
+        if stack.is_cuda:
+            host = torch.empty(stack.shape, dtype=stack.dtype, pin_memory=True)
+            host.copy_(stack, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        else:
+            host, done = stack, None
+        self._pending = (host, done, gp_val is not None, keep_rec)
         if exists(self.tb_writer):
             for k, v in (("G", self.g_loss), ("D", self.d_loss), ("rec", self.total_rec_loss),
                          ("kl", self.total_kl_loss)):
@@ -667,10 +750,8 @@ class Trainer:
             m.EMA()
         if self.is_main and self.steps <= 25000 and self.steps % 1000 == 2:
             m.reset_parameter_averaging()
-        if math.isnan(self.g_loss) or math.isnan(self.d_loss):  # save from NaN errors (reference :1483-1486)
-            print(f"NaN detected for generator or discriminator. Loading from checkpoint #{self.checkpoint_num}")
-            self.load(self.checkpoint_num)
-            raise NanException
+        if self.is_main and (self.steps % self.save_every == 0 or self.steps % self.evaluate_every == 0):
+            self._resolve_losses()  # never checkpoint a NaN state (reference :1483-1486 precedes the save)
         if self.is_main:
             if self.steps % self.save_every == 0:
                 self.save(self.checkpoint_num)

@@ -1,0 +1,16 @@
+"""Pack a rocprofv3 kernel_trace.csv into name-id/start/end rows (small enough to bring back from the GPU box).
+usage: trace_pack.py kernel_trace.csv out.csv.gz"""
+import csv
+import gzip
+import sys
+
+names = {}
+with open(sys.argv[1]) as f, gzip.open(sys.argv[2], "wt") as g:
+    rows = []
+    for r in csv.DictReader(f):
+        k = names.setdefault(r["Kernel_Name"], len(names))
+        rows.append("%d,%s,%s\n" % (k, r["Start_Timestamp"], r["End_Timestamp"]))
+    g.write("%d\n" % len(names))
+    for n, k in names.items():
+        g.write("%d\t%s\n" % (k, n))
+    g.writelines(rows)
