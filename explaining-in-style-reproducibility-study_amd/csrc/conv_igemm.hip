@@ -949,6 +949,16 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, 9, hs);
         return (int)hipGetLastError();
     }
+    if (precision == STYLEX_BF16 && stylex_wgrad_tr_applicable(p)) {
+        int ts = 0;
+        int rc = stylex_launch_wgrad_tr(p, partial, s, &ts);
+        if (rc) return rc;
+        long total = (long)p.N * p.Ck;
+        int rb = (int)((total + 255) / 256);
+        if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, p.KH * p.KW, ts);
+        return (int)hipGetLastError();
+    }
     int tn, tc, splits;
     long split_len;
     stylex_wgrad_plan(p, &tn, &tc, &splits, &split_len);

@@ -255,6 +255,7 @@ bool stylex_wgrad_halo_applicable(const ConvKParams& p) {
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
     if (p.Hi != p.Ho || p.Wi != p.Wo) return false;
     if (p.Ck % 4 != 0 || p.N % 4 != 0 || p.Wo < 16 || p.Ho < 8 || (long)p.Ho * p.Wo < 256) return false;
+    if (p.Ck == 8 && p.act_bf16 && p.N % 8 == 0) return false;  // RGB input: the flattened-tap kernel (conv_wgrad_tr.hip)
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.a2) & 15)) return false;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return false;
     if (p.a2_scale && (reinterpret_cast<uintptr_t>(p.a2_scale) & 15)) return false;

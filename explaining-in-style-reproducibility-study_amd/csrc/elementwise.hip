@@ -212,6 +212,40 @@ __global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict
     }
 }
 
+// ---- stride-2 pixel subsampling and its adjoint (zero insertion) --------------------------------
+// A 1x1 / stride-2 convolution (DiscriminatorBlock.conv_res) is a 1x1 / stride-1 convolution of the even
+// pixels: gathering them once turns its three GEMMs into contiguous ones, and the data gradient no longer runs
+// a full-resolution implicit GEMM whose rows are 3/4 structural zeros.  shape = the FULL-resolution [B,H,W,C].
+template <int V>
+__global__ void subsample2_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int C, int bf) {
+    const int cv = C / V, Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+    const long total = (long)B * Ho * Wo * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        int ow = (int)(pix % Wo);
+        int oh = (int)((pix / Wo) % Ho);
+        int b = (int)(pix / ((long)Ho * Wo));
+        Vec<V>::st(y, pix * C + c, Vec<V>::ld(x, (((long)b * H + 2 * oh) * W + 2 * ow) * C + c, bf), bf);
+    }
+}
+
+template <int V>
+__global__ void subsample2_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C, int bf) {
+    const int cv = C / V, Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+    const long total = (long)B * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * V;
+        long pix = i / cv;
+        int w = (int)(pix % W);
+        int h = (int)((pix / W) % H);
+        int b = (int)(pix / ((long)H * W));
+        typename Vec<V>::T v = Vec<V>::zero();
+        if (!((h | w) & 1)) v = Vec<V>::ld(dy, (((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c, bf);
+        Vec<V>::st(dx, pix * C + c, v, bf);
+    }
+}
+
 // ---- bf16 column-strip blur (forward and adjoint) ---------------------------------------------
 // One lane owns 8 channels of one column and walks ROWS output rows with a 3-row sliding window of
 // horizontally filtered values, so every input row is fetched once per strip (+2 halo rows) instead of three
@@ -439,6 +473,16 @@ int stylex_blur3x3_s2d_bwd(const void* dy, void* dx, EW_ARGS) {
     if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
     if (blur_strip_ok(bf, H, C, dy, dx)) return launch_blur_strip<true>(dy, dx, B, H, W, C, 1, s);
     LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 1);
+}
+int stylex_subsample2_fwd(const void* x, void* y, EW_ARGS) {
+    EW_UNPACK
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(subsample2_fwd_kernel, (long)B * ((H + 1) / 2) * ((W + 1) / 2) * C, x, y, x, y, B, H, W, C, bf);
+}
+int stylex_subsample2_bwd(const void* dy, void* dx, EW_ARGS) {
+    EW_UNPACK
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(subsample2_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
 }
 int stylex_bias_act_fwd(const void* x, const float* bias, const float* noise, int64_t noise_stride,
                         const float* noise_w, const float* noise_b, void* y, EW_ARGS) {

@@ -266,6 +266,12 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
         stylex_wgrad_halo_plan(p, &hs, &tps);
         if (hs > splits) splits = hs;
     }
+    if (p.Ck % 8 == 0 && p.N % 8 == 0) {  // bf16-activation tr kernel plan
+        int mode, ts;
+        long tl;
+        stylex_wgrad_tr_plan(p, &mode, &ts, &tl);
+        if (ts > splits) splits = ts;
+    }
     return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float);
 }
 

@@ -53,6 +53,11 @@ bool stylex_wgrad_halo_applicable(const ConvKParams& p);
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);
 int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out);
 
+// general bf16 weight gradient with LDS transpose reads (conv_wgrad_tr.hip)
+bool stylex_wgrad_tr_applicable(const ConvKParams& p);
+void stylex_wgrad_tr_plan(const ConvKParams& p, int* mode, int* splits, long* split_len);
+int stylex_launch_wgrad_tr(ConvKParams p, float* partial, hipStream_t s, int* splits_out);
+
 // Weight taps (bit kh*3+kw of the 3x3 frame) that are structurally non-zero for sub-position s = sy*2+sx of a
 // stride-2 3x3/pad-1 convolution rewritten over the space-to-depth input (frame offset -1 -> kh2 = 0 needs
 // the odd sub-row/col, offset 0 -> kh2 = 1 takes both, offset +1 never contributes).

@@ -50,6 +50,8 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_subsample2_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_subsample2_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_pack_weight_s2d": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_fold_weight_grad_s2d": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -383,6 +385,20 @@ def blur3x3_s2d_bwd(dy2):
     _check(lib.stylex_blur3x3_s2d_bwd(_ptr(dy2), _ptr(dx), _shape(b, 2 * h2, 2 * w2, c4 // 4), _adt(dy2), _stream()),
            "stylex_blur3x3_s2d_bwd")
     return dx
+
+
+def subsample2_fwd(x):
+    """x[:, :, ::2, ::2] as a dense channels_last tensor."""
+    b, c, h, w = x.shape
+    return _ew("stylex_subsample2_fwd", x, (b, c, (h + 1) // 2, (w + 1) // 2), (b, c, h, w))
+
+
+def subsample2_bwd(dy, full_hw):
+    """adjoint of subsample2_fwd: zeros with dy at the even pixels of a [*, *, H, W] tensor."""
+    b, c = dy.shape[:2]
+    h, w = full_hw
+    assert dy.shape[2] == (h + 1) // 2 and dy.shape[3] == (w + 1) // 2
+    return _ew("stylex_subsample2_bwd", dy, (b, c, h, w), (b, c, h, w))
 
 
 def bias_act_fwd(x, bias=None, noise=None, noise_w=None, noise_b=None):

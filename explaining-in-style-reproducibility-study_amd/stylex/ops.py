@@ -250,6 +250,29 @@ class _BlurBwd(torch.autograd.Function):
         return _Blur.apply(ggx)
 
 
+class _Subsample2(torch.autograd.Function):
+    """x[:, :, ::2, ::2] (dense); adjoint = zero insertion; the pair is closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = tuple(x.shape[2:])
+        return hb.subsample2_fwd(_cl(x))
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _ZeroInsert2.apply(gy, ctx.hw)
+
+
+class _ZeroInsert2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, hw):
+        return hb.subsample2_bwd(_cl(gy), hw)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        return _Subsample2.apply(ggx), None
+
+
 class _RowSumSq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d):
@@ -499,6 +522,9 @@ class HipOps:
         x, weight, n_out = _pad_rgb(_act(x), weight)
         residual = _act(residual)
         padded_out = n_out != weight.shape[0]
+        if stride == 2 and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and x.shape[1] % 4 == 0:
+            # 1x1 / stride 2 (conv_res): contiguous 1x1 / stride-1 GEMMs over the gathered even pixels
+            x, stride = _Subsample2.apply(x), 1
         if not padded_out:
             fn = _ConvBiasActFast if fast_enabled() else _ConvBiasActDD
             return fn.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)

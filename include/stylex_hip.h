@@ -146,6 +146,13 @@ int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, const int64_t* shape, i
  * the s2d conv ([N][4C][3][3]) back to the parameter layout.  H, W even. */
 int stylex_blur3x3_s2d_fwd(const void* x, void* y_s2d, const int64_t* shape, int act_dtype, void* stream);
 int stylex_blur3x3_s2d_bwd(const void* dy_s2d, void* dx, const int64_t* shape, int act_dtype, void* stream);
+
+/* Even-pixel gather y[b,i,j,:] = x[b,2i,2j,:] and its adjoint (zero insertion).  shape = the FULL-resolution
+ * {B,H,W,C}; the low-resolution tensor is [B,(H+1)/2,(W+1)/2,C].  With these the reference's 1x1 / stride-2
+ * residual convolution (DiscriminatorBlock.conv_res, stylex_train.py:724) runs as a contiguous 1x1 / stride-1
+ * convolution of the gathered pixels. */
+int stylex_subsample2_fwd(const void* x, void* y, const int64_t* shape, int act_dtype, void* stream);
+int stylex_subsample2_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
 int stylex_pack_weight_s2d(const float* w_oihw, void* w_fwd, void* w_bwd, const int64_t* shape, void* stream);
 int stylex_fold_weight_grad_s2d(const float* dw_s2d, float* dw_oihw, const int64_t* shape, void* stream);
 

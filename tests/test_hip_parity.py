@@ -65,6 +65,10 @@ CONV_CASES = [
     (2, 32, 32, 16, 16, 3, 1, 1),     # bf16: LDS-halo kernel, 16x16 tiles, N=32 variant
     (1, 40, 96, 40, 48, 3, 1, 1),     # halo kernel with partial tiles and a ragged channel chunk
     (3, 128, 24, 24, 40, 3, 1, 1),    # halo kernel: N < tile, H not a multiple of the tile
+    (2, 3, 64, 16, 16, 1, 2, 0),      # first conv_res: RGB padded to one 16-byte slot, 1x1 stride 2
+    (4, 256, 136, 8, 8, 3, 1, 1),     # bf16: transpose-read wgrad, 128x128 tiles, ragged N, several pixel splits
+    (2, 64, 128, 16, 16, 1, 2, 0),    # conv_res at a real channel ratio
+    (3, 72, 64, 5, 7, 3, 2, 1),       # stride 2 with odd sizes, ragged 64x64 channel tiles
 ]
 
 
