@@ -174,7 +174,11 @@ def main():
         torch.cuda.synchronize()
         rep = hb.timing_report()
         hb.timing_enable(0)
-        name, r = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        # forward and data-gradient launches run the SAME kernels (LDS-halo / implicit-GEMM conv with swapped
+        # roles), so they form one kernel class; the weight gradient has its own kernels
+        merged = {"fwd_bwd_data": {k: rep["fwd"][k] + rep["bwd_data"][k] for k in ("ms", "flops", "launches")},
+                  "bwd_weight": rep["bwd_weight"]}
+        name, r = max(merged.items(), key=lambda kv: kv[1]["ms"])
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         # HBM bytes per launch of that class from the PMC passes of tools/collect_traffic.py (committed under

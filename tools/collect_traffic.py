@@ -18,8 +18,10 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WGRAD = ("conv3x3_wgrad_halo_kernel", "conv_wgrad_kernel")
+WGRAD = ("conv3x3_wgrad_halo_kernel", "conv_wgrad_tr_kernel", "conv_wgrad_kernel")
 WGRAD_AUX = ("wgrad_reduce_kernel", "fold_weight_s2d_kernel")
+FWD = ("conv3x3_halo_bf16_kernel", "conv_igemm_kernel")  # forward and data gradient share these kernels
+FWD_AUX = ("splitk_epilogue_kernel", "pack_weight_kernel", "pack_weight_s2d_kernel")
 
 
 def run_pass(counter, bench_args):
@@ -55,13 +57,17 @@ def main():
                                "bytes_corrected": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0}
     main_disp = sum(v["dispatches"] for k, v in per_kernel.items() if any(w in k for w in WGRAD))
     fam_bytes = sum(v["bytes_corrected"] for k, v in per_kernel.items() if any(w in k for w in WGRAD + WGRAD_AUX))
+    fwd_disp = sum(v["dispatches"] for k, v in per_kernel.items() if any(w in k for w in FWD))
+    fwd_bytes = sum(v["bytes_corrected"] for k, v in per_kernel.items() if any(w in k for w in FWD + FWD_AUX))
     out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py " + " ".join(bench_args),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
            "bwd_weight": {"launches": main_disp, "bytes_total": fam_bytes,
                           "bytes_per_launch": fam_bytes / max(1, main_disp)},
+           "fwd_bwd_data": {"launches": fwd_disp, "bytes_total": fwd_bytes,
+                            "bytes_per_launch": fwd_bytes / max(1, fwd_disp)},
            "kernels": per_kernel}
     json.dump(out, open(a.out, "w"), indent=1)
-    print(json.dumps(out["bwd_weight"]))
+    print(json.dumps({k: out[k] for k in ("bwd_weight", "fwd_bwd_data")}))
 
 
 if __name__ == "__main__":

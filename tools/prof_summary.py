@@ -10,6 +10,9 @@ def family(n):
     if "wgrad_halo" in n: return "halo wgrad"
     if "conv_igemm" in n: return "igemm v1 fwd/dgrad"
     if "conv_wgrad_kernel" in n: return "wgrad v1"
+    if "conv_wgrad_tr" in n: return "wgrad tr (general)"
+    if "act_bwd_reduce" in n: return "fused act-bwd + bias-grad"
+    if "subsample2" in n: return "subsample"
     if "wgrad_reduce" in n or "splitk_epilogue" in n: return "split reduce"
     if "pack_weight" in n: return "pack_weight"
     if "bias_act" in n: return "bias_act"
