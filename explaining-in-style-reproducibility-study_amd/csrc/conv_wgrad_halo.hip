@@ -62,11 +62,27 @@ struct Geom {
     static constexpr int SMEM_BYTES = 2 * DY_PANEL + 2 * X_PANEL;  // ~75 KiB -> 2 blocks / CU
 };
 
-template <int TW, bool ABF>
+template <int TW, unsigned MASK>
+__device__ __forceinline__ void compute_tile(f32x16 (&acc)[9], const char* a_base, const char* b_base) {
+    constexpr int HWD = Geom<TW>::HWD, KS_PER_ROW = TW / 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int r = ks / KS_PER_ROW, pw0 = (ks % KS_PER_ROW) * 16;
+        bf16x8 av = tr_read8(a_base, (r * TW + pw0) * PIX_ROW, PIX_ROW);
+        bf16x8 bv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if ((MASK >> t) & 1u) bv[t] = tr_read8(b_base, ((r + t / 3) * HWD + pw0 + t % 3) * PIX_ROW, PIX_ROW);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if ((MASK >> t) & 1u) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[t], acc[t], 0, 0, 0);
+    }
+}
+
+template <int TW, bool ABF, bool S2D>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams p) {
     constexpr int TH = Geom<TW>::TH, HWD = Geom<TW>::HWD, NP = Geom<TW>::NP;
     constexpr int DY_PANEL = Geom<TW>::DY_PANEL, X_PANEL = Geom<TW>::X_PANEL, X_OFF = Geom<TW>::X_OFF;
-    constexpr int KS_PER_ROW = TW / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     // space-to-depth form of a stride-2 conv: taps that are structurally zero for this c-tile's sub-position
-    const unsigned tapmask = p.s2d_c ? stylex_s2d_tap_mask((c0 + wc * 32) / p.s2d_c) : 0x1ffu;
+    const unsigned tapmask = S2D ? stylex_s2d_tap_mask((c0 + wc * 32) / p.s2d_c) : 0x1ffu;
 
     // tr-read lane addressing (see header): group g = lane>>4 -> channel block (g&1)*16, k half (g>>1)*8
     const int i16 = lane & 15, g = lane >> 4;
@@ -216,21 +232,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
         }
         __syncthreads();
 
-        // ---- 16 k-steps of 16 pixels (half a tile row each); 9 taps share the A operand
+        // ---- 16 k-steps of 16 pixels (half a tile row each); 9 taps share the A operand.  The tap set is a
+        // compile-time mask (space-to-depth tiles dispatch on their 4 possible masks) so that a k-step is
+        // straight-line code: all its LDS transpose reads are issued first and the MFMAs start as operands
+        // arrive (a per-tap runtime branch made every MFMA wait for its own read: ~160 cycles per 32-cycle MFMA).
         const char* a_base = smem + wn * DY_PANEL + lane_off;
         const char* b_base = smem + X_OFF + wc * X_PANEL + lane_off;
-#pragma unroll 2
-        for (int ks = 0; ks < 16; ++ks) {
-            const int r = ks / KS_PER_ROW, pw0 = (ks % KS_PER_ROW) * 16;
-            bf16x8 av = tr_read8(a_base, (r * TW + pw0) * PIX_ROW, PIX_ROW);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (!((tapmask >> t) & 1)) continue;
-                const int kh = t / 3, kw = t - kh * 3;
-                bf16x8 bv = tr_read8(b_base, ((r + kh) * HWD + pw0 + kw) * PIX_ROW, PIX_ROW);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
-            }
-        }
+        if (!S2D) compute_tile<TW, 0x1ffu>(acc, a_base, b_base);
+        else if (tapmask == 0x010u) compute_tile<TW, 0x010u>(acc, a_base, b_base);
+        else if (tapmask == 0x018u) compute_tile<TW, 0x018u>(acc, a_base, b_base);
+        else if (tapmask == 0x012u) compute_tile<TW, 0x012u>(acc, a_base, b_base);
+        else compute_tile<TW, 0x01bu>(acc, a_base, b_base);
         __syncthreads();
     }
 
@@ -282,9 +294,9 @@ void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_sp
     *splits = (int)((tiles + tps - 1) / tps);
 }
 
-template <int TW, bool ABF>
+template <int TW, bool ABF, bool S2D>
 static int launch_wgrad_halo(const ConvKParams& p, int blocks, hipStream_t s) {
-    auto k = conv3x3_wgrad_halo_kernel<TW, ABF>;
+    auto k = conv3x3_wgrad_halo_kernel<TW, ABF, S2D>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -303,7 +315,11 @@ int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* 
     p.y = partial;
     int blocks = ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * splits;
     *splits_out = splits;
-    if (p.act_bf16 && p.Ck % 8 == 0 && p.N % 8 == 0)
-        return p.Wo >= 32 ? launch_wgrad_halo<32, true>(p, blocks, s) : launch_wgrad_halo<16, true>(p, blocks, s);
-    return p.Wo >= 32 ? launch_wgrad_halo<32, false>(p, blocks, s) : launch_wgrad_halo<16, false>(p, blocks, s);
+    const bool abf = p.act_bf16 && p.Ck % 8 == 0 && p.N % 8 == 0;
+    if (p.s2d_c) {
+        if (abf) return p.Wo >= 32 ? launch_wgrad_halo<32, true, true>(p, blocks, s) : launch_wgrad_halo<16, true, true>(p, blocks, s);
+        return p.Wo >= 32 ? launch_wgrad_halo<32, false, true>(p, blocks, s) : launch_wgrad_halo<16, false, true>(p, blocks, s);
+    }
+    if (abf) return p.Wo >= 32 ? launch_wgrad_halo<32, true, false>(p, blocks, s) : launch_wgrad_halo<16, true, false>(p, blocks, s);
+    return p.Wo >= 32 ? launch_wgrad_halo<32, false, false>(p, blocks, s) : launch_wgrad_halo<16, false, false>(p, blocks, s);
 }
