@@ -665,33 +665,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
 
 // dw_oihw[n][c][t] = sum_split partial[split][n][t][c]   (fixed order => deterministic)
 // One thread owns one (n, c): for each tap it reads the slices with lanes running along c (coalesced
-// 256-byte rows) and finally writes its T consecutive output floats (a wave covers one contiguous span).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int C, int T,
-                                    int splits) {
+// 256-byte rows), four slices in flight per tap.  The T results of a thread are consecutive in OIHW, so a block's
+// 256 pairs form one contiguous span of 256*T floats: it is transposed through LDS and written with coalesced
+// rows (the direct form wrote 4 bytes at a 36-byte lane stride).  Fixed summation order -> deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int N, int C, int T, int splits) {
+    __shared__ float tile[256 * 9];
     const long total = (long)N * C * T;
     const long pairs = (long)N * C;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long n = i / C;
-        const float* src = partial + (n * T) * C + c;
-        float* dst = dw + i * T;
-        if (T == 9) {
-            float acc[9];
+    const long i0 = (long)blockIdx.x * 256;
+    const long i = i0 + threadIdx.x;
+    if (T == 9) {
+        float acc[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-            for (int k = 0; k < splits; ++k) {
+        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+        if (i < pairs) {
+            const int c = (int)(i % C);
+            const long n = i / C;
+            const float* src = partial + (n * 9) * C + c;
+            int k = 0;
+            for (; k + 4 <= splits; k += 4) {
+                float v[4][9];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[u][t] = src[(long)(k + u) * total + (long)t * C];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[t] += v[u][t];
+            }
+            for (; k < splits; ++k) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc[t] += src[(long)k * total + (long)t * C];
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) dst[t] = acc[t];
-        } else {
-            for (int t = 0; t < T; ++t) {
-                float a = 0.f;
-                for (int k = 0; k < splits; ++k) a += src[(long)k * total + (long)t * C];
-                dst[t] = a;
-            }
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tile[threadIdx.x * 9 + t] = acc[t];
+        __syncthreads();
+        const long span = min((long)256, pairs - i0) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int o = j * 256 + threadIdx.x;
+            if (o < span) dw[i0 * 9 + o] = tile[o];
+        }
+        return;
+    }
+    if (i >= pairs) return;
+    const int c = (int)(i % C);
+    const long n = i / C;
+    const float* src = partial + (n * T) * C + c;
+    float* dst = dw + i * T;
+    for (int t = 0; t < T; ++t) {
+        float a = 0.f;
+        for (int k = 0; k < splits; ++k) a += src[(long)k * total + (long)t * C];
+        dst[t] = a;
     }
 }
 
@@ -945,7 +973,6 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         if (rc) return rc;
         long total = (long)p.N * p.Ck;
         int rb = (int)((total + 255) / 256);
-        if (rb > 4096) rb = 4096;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, 9, hs);
         return (int)hipGetLastError();
     }
@@ -955,7 +982,6 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         if (rc) return rc;
         long total = (long)p.N * p.Ck;
         int rb = (int)((total + 255) / 256);
-        if (rb > 4096) rb = 4096;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, p.KH * p.KW, ts);
         return (int)hipGetLastError();
     }
@@ -983,7 +1009,6 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
     if (rc) return rc;
     long total = (long)p.N * p.Ck;
     int rb = (int)((total + 255) / 256);
-    if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, T, splits);
     return (int)hipGetLastError();
 }
