@@ -179,6 +179,29 @@ def pack_cache_clear():
     _PACK_CACHE.clear()
 
 
+def _cache_hit(key, w):
+    """Cached packs may have been produced on another HIP stream (the Trainer forks independent branches over
+    side streams): make the consumer stream wait for the producing kernel and keep the block alive for it."""
+    hit = _PACK_CACHE.get(key)
+    if hit is None or hit[0]() is not w:  # same live Parameter object (its address cannot be recycled)
+        return None
+    cur = torch.cuda.current_stream()
+    if hit[4] != cur.cuda_stream:
+        cur.wait_event(hit[3])
+        for t in (hit[1], hit[2]):
+            if t is not None:
+                t.record_stream(cur)
+    return hit[1], hit[2]
+
+
+def _cache_put(key, w_param, wf, wb):
+    if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+        _PACK_CACHE.clear()
+    ev = torch.cuda.Event()
+    ev.record()
+    _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream)
+
+
 def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     """OIHW fp32 parameter -> K-contiguous operand layouts, fp32 or bf16 according to `precision`.
     Packs of nn.Parameters are cached until the parameter is modified in place (optimizer step):
@@ -188,9 +211,9 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     key = None
     if cacheable:
         key = (w.data_ptr(), w._version, tuple(w.shape), precision)
-        hit = _PACK_CACHE.get(key)
-        if hit is not None and hit[0]() is w:  # same live Parameter object (its address cannot be recycled)
-            return hit[1], hit[2]
+        hit = _cache_hit(key, w)
+        if hit is not None:
+            return hit
         want_fwd = want_bwd = True
     w_param = w
     w = w.contiguous()
@@ -203,9 +226,7 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
            "stylex_pack_weight")
     if key is not None:
-        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb)
+        _cache_put(key, w_param, wf, wb)
     return wf, wb
 
 
@@ -215,9 +236,9 @@ def pack_weight_s2d(w):
     key = None
     if isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32:
         key = (w.data_ptr(), w._version, tuple(w.shape), "s2d")
-        hit = _PACK_CACHE.get(key)
-        if hit is not None and hit[0]() is w:
-            return hit[1], hit[2]
+        hit = _cache_hit(key, w)
+        if hit is not None:
+            return hit
     wc = w.contiguous().float()
     n, c, kh, kw = wc.shape
     assert kh == 3 and kw == 3
@@ -226,9 +247,7 @@ def pack_weight_s2d(w):
     _check(lib.stylex_pack_weight_s2d(_ptr(wc), _ptr(wf), _ptr(wb), _shape(n, c, 3, 3), _stream()),
            "stylex_pack_weight_s2d")
     if key is not None:
-        if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (weakref.ref(w), wf, wb)
+        _cache_put(key, w, wf, wb)
     return wf, wb
 
 

@@ -248,10 +248,17 @@ def _frozen_layout(images):
     return images
 
 
-def reconstruction_loss(encoder_batch, generated_images, generated_images_w, encoder_w, lpips_fn=None):
+def perceptual_loss(encoder_batch, generated_images, lpips_fn=None):
     lpips_fn = lpips_fn or get_lpips(encoder_batch.device)
-    perceptual = lpips_fn(_frozen_layout(lpips_normalize(encoder_batch)),
-                          _frozen_layout(lpips_normalize(generated_images))).mean()
+    return lpips_fn(_frozen_layout(lpips_normalize(encoder_batch)),
+                    _frozen_layout(lpips_normalize(generated_images))).mean()
+
+
+def reconstruction_loss(encoder_batch, generated_images, generated_images_w, encoder_w, lpips_fn=None, perceptual=None):
+    """Reference :426-438.  `perceptual` may be passed in when the caller evaluated the LPIPS branch itself
+    (the Trainer runs it on a side stream)."""
+    if perceptual is None:
+        perceptual = perceptual_loss(encoder_batch, generated_images, lpips_fn)
     return 0.1 * perceptual + 0.1 * F.l1_loss(encoder_w, generated_images_w) + 1 * F.l1_loss(encoder_batch,
                                                                                              generated_images)
 
@@ -571,10 +578,38 @@ class Trainer:
             self.load(self.checkpoint_num)
             raise NanException
 
+    def _fork(self, fns):
+        """Evaluate independent sub-graphs concurrently: fns[0] on the current HIP stream, the others on side
+        streams, joined before returning.  The small layers of D / encoder / classifier / LPIPS each fill a
+        fraction of the 256 CUs; issued from separate streams they overlap, forward and — because autograd
+        replays every node on its forward stream — backward.  Results are identical (no shared mutable state)."""
+        if self.device.type != "cuda" or len(fns) < 2 or os.environ.get("STYLEX_STREAMS", "1") == "0":
+            return [f() for f in fns]
+        if getattr(self, "_side_streams", None) is None:
+            self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        main = torch.cuda.current_stream()
+        outs, used = [None] * len(fns), []
+        for i in range(1, len(fns)):
+            side = self._side_streams[(i - 1) % len(self._side_streams)]
+            if side not in used:
+                side.wait_stream(main)  # everything the branch reads was enqueued on `main` before the fork
+                used.append(side)
+            with torch.cuda.stream(side):
+                outs[i] = fns[i]()
+            for t in (outs[i] if isinstance(outs[i], (tuple, list)) else (outs[i],)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)  # produced on a side stream, consumed (and freed) on `main`
+        outs[0] = fns[0]()
+        for side in used:
+            main.wait_stream(side)
+        return outs
+
+    def _classify(self, images):
+        return self.classifier.classify_images(_frozen_layout(images))
+
     def _styles_from_encoder(self, batch):
         m = self.StylEx
-        enc = m.encoder(batch)
-        logits = self.classifier.classify_images(_frozen_layout(batch))
+        enc, logits = self._fork([lambda: m.encoder(batch), lambda: self._classify(batch)])
         w = styles_def_to_tensor([(torch.cat((enc, logits), dim=1), m.G.num_layers)])
         return enc, logits, w
 
@@ -706,11 +741,25 @@ class Trainer:
                     encoder_input = not encoder_input
                 w_all = cat(ws)
                 generated_all = m.G(w_all, cat(noises))
-                fake_all = D_call(generated_all)
-                total_all, lo = 0, 0
-                for w_styles, enc in zip(ws, micro):
-                    sl = slice(lo, lo + w_styles.shape[0])
+                # four independent consumers of the generated batch: D, and per encoder micro-step the classifier,
+                # the encoder and LPIPS — forked over HIP streams (see _fork)
+                spans, lo = [], 0
+                for w_styles in ws:
+                    spans.append(slice(lo, lo + w_styles.shape[0]))
                     lo += w_styles.shape[0]
+                branches, where = [lambda: D_call(generated_all)], []
+                for sl, enc in zip(spans, micro):
+                    if enc is not None:
+                        gen_i, batch_i = generated_all[sl], enc[0]
+                        where.append(len(branches))
+                        branches += [lambda g=gen_i: self._classify(g), lambda g=gen_i: m.encoder(g),
+                                     lambda g=gen_i, b=batch_i: perceptual_loss(b, g, self.lpips_fn)]
+                    else:
+                        where.append(None)
+                outs = self._fork(branches)
+                fake_all = outs[0]
+                total_all = 0
+                for sl, enc, at in zip(spans, micro, where):
                     generated = generated_all[sl]
                     loss = gen_hinge_loss(fake_all[sl], None)
                     total = loss
@@ -724,9 +773,9 @@ class Trainer:
                     total = total / gae
                     if enc is not None:
                         batch, enc_out, real_logits = enc
-                        gen_logits = self.classifier.classify_images(_frozen_layout(generated))
-                        rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, m.encoder(generated),
-                                                                         enc_out, self.lpips_fn) / gae
+                        gen_logits, gen_w, perceptual = outs[at:at + 3]
+                        rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, gen_w, enc_out,
+                                                                         self.lpips_fn, perceptual=perceptual) / gae
                         kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
                         total = total + rec + kl  # one backward == the three backward calls of :1436-1438
                         tot_rec += rec.detach()
