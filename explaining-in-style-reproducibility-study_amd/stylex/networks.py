@@ -25,6 +25,23 @@ def exists(v):
     return v is not None
 
 
+_SIDE = {}
+
+
+def _side_stream(t):
+    """The companion HIP stream of the current stream, for branch-level concurrency inside a network (None on
+    CPU or with STYLEX_STREAMS=0).  Keyed by the current stream so that networks the Trainer itself runs
+    concurrently on different streams do not meet on one shared side stream."""
+    import os
+
+    if not t.is_cuda or os.environ.get("STYLEX_STREAMS", "1") == "0":
+        return None
+    key = (t.device, torch.cuda.current_stream().cuda_stream)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=t.device)
+    return _SIDE[key]
+
+
 def leaky_relu(p=0.2):
     return nn.LeakyReLU(p, inplace=True)
 
@@ -142,7 +159,8 @@ class GeneratorBlock(nn.Module):  # reference :670-718
         self.activation = leaky_relu()
         self.to_rgb = RGBBlock(latent_dim, filters, upsample_rgb, rgba)
 
-    def forward(self, x, prev_rgb, istyle, inoise):
+    def forward_main(self, x, istyle, inoise):
+        """The feature path of the block (everything except the toRGB branch)."""
         if exists(self.upsample):
             x = self.upsample(x)
         style1 = self.to_style1(istyle)
@@ -151,8 +169,12 @@ class GeneratorBlock(nn.Module):  # reference :670-718
         style2 = self.to_style2(istyle)
         x = ops.modconv_noise_act(x, style2, self.conv2.weight, inoise, self.to_noise2.weight[:, 0],
                                   self.to_noise2.bias, demod=self.conv2.demod, eps=self.conv2.eps)
+        return x, torch.cat([style1, style2], dim=-1)
+
+    def forward(self, x, prev_rgb, istyle, inoise):
+        x, coords = self.forward_main(x, istyle, inoise)
         rgb = self.to_rgb(x, prev_rgb, istyle)
-        return x, rgb, torch.cat([style1, style2], dim=-1)
+        return x, rgb, coords
 
 
 class DiscriminatorBlock(nn.Module):  # reference :721-744
@@ -164,8 +186,20 @@ class DiscriminatorBlock(nn.Module):  # reference :721-744
         self.downsample = nn.Sequential(Blur(), HipConv2d(filters, filters, 3, padding=1, stride=2)) if downsample else None
 
     def forward(self, x):
-        res = self.conv_res(x)
-        x = self.net(x)
+        # the 1x1 residual conv is independent of the two 3x3 convs until the merge: side stream
+        side = _side_stream(x)
+        if side is None:
+            res = self.conv_res(x)
+            x = self.net(x)
+        else:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            x.record_stream(side)
+            with torch.cuda.stream(side):
+                res = self.conv_res(x)
+            x = self.net(x)
+            main.wait_stream(side)
+            res.record_stream(main)
         if exists(self.downsample):
             down = self.downsample[1]
             # (conv_s2(blur(x)) + bias + res) / sqrt(2): blur -> space-to-depth -> halo conv with the merge of
@@ -207,9 +241,24 @@ class Generator(nn.Module):  # reference :747-825
         batch = styles.shape[0]
         x = self.initial_conv(self.initial_block.expand(batch, -1, -1, -1))
         rgb, coords = None, []
+        # The toRGB chain (1x1 modulated conv to 3 channels, skip add, bilinear x2, blur: memory-bound kernels on
+        # 3-channel tensors) only feeds the NEXT toRGB, never the feature path, so it runs one block behind on a
+        # side HIP stream under the MFMA-bound convs of the next block; autograd replays it there in backward.
+        side = _side_stream(x)
+        main = torch.cuda.current_stream() if side is not None else None
         for li, block in enumerate(self.blocks):
-            x, rgb, sc = block(x, rgb, styles[:, li], input_noise)
+            x, sc = block.forward_main(x, styles[:, li], input_noise)
             coords.append(sc)
+            if side is None:
+                rgb = block.to_rgb(x, rgb, styles[:, li])
+                continue
+            side.wait_stream(main)  # x (and the style slice) are ready
+            x.record_stream(side)
+            with torch.cuda.stream(side):
+                rgb = block.to_rgb(x, rgb, styles[:, li])
+        if side is not None:
+            main.wait_stream(side)
+            rgb.record_stream(main)
         rgb = rgb.float()  # activations may be stored in bf16; the module API returns fp32 images
         if get_style_coords:
             return rgb, torch.cat(coords, dim=1)
