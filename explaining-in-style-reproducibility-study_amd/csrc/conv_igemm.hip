@@ -889,9 +889,11 @@ static void igemm_splitk_plan(const ConvKParams& p, bool vec, int precision, int
     int nk = vec ? ((p.Ck == 4 && !abf) ? (T + 7) / 8 : (abf && p.Ck == 8) ? (T + bk / 8 - 1) / (bk / 8) : T * ((p.Ck + bk - 1) / bk)) : (T * p.Ck + BK - 1) / BK;
     *ksplit = 1;
     *kt_per = nk;
-    if (blocks >= 192 || nk < 16) return;
+    // Small-spatial layers launch a handful of tiles whose K loop is pure latency (measured: 4-64 blocks, 35-45 us
+    // per launch whatever the size): slice K down to 2 K-tiles per block.
+    if (blocks >= 192 || nk < 4) return;
     long want = (512 + blocks - 1) / blocks;
-    long maxs = nk / 4;  // at least 4 K-tiles per slice
+    long maxs = nk / 2;  // at least 2 K-tiles per slice
     if (want > maxs) want = maxs;
     if (want > 36) want = 36;
     if (want < 2) return;

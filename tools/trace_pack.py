@@ -4,11 +4,13 @@ import csv
 import gzip
 import sys
 
+GRID = len(sys.argv) > 3 and sys.argv[3] == "grid"
 names = {}
 with open(sys.argv[1]) as f, gzip.open(sys.argv[2], "wt") as g:
     rows = []
     for r in csv.DictReader(f):
-        k = names.setdefault(r["Kernel_Name"], len(names))
+        # the grid size distinguishes the layer shapes a kernel template is launched with
+        k = names.setdefault(r["Kernel_Name"] + (" grid=%s" % r.get("Grid_Size_X", "?") if GRID else ""), len(names))
         rows.append("%d,%s,%s\n" % (k, r["Start_Timestamp"], r["End_Timestamp"]))
     g.write("%d\n" % len(names))
     for n, k in names.items():
