@@ -723,6 +723,54 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// Few outputs, many slices (first-layer wgrads: 64 x 8 x 9 outputs from several hundred pixel splits): the
+// kernel above would run 2 blocks with 768-long serial sums.  Here a block owns PP (n,c) pairs and G slice
+// groups: thread (g, p) sums slices g, g+G, ... of its pair, the G partial sums are combined through LDS in
+// fixed order (deterministic), T outputs per pair.
+template <int PP, int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                 int N, int C, int T, int splits) {
+    static_assert(PP * G == 256, "one thread per (pair, slice group)");
+    __shared__ float red[G][PP];
+    const long total = (long)N * C * T;
+    const long pairs = (long)N * C;
+    const int p = threadIdx.x % PP, g = threadIdx.x / PP;
+    const long i = (long)blockIdx.x * PP + p;
+    const bool ok = i < pairs;
+    const int c = ok ? (int)(i % C) : 0;
+    const long n = ok ? i / C : 0;
+    for (int t = 0; t < T; ++t) {
+        float a = 0.f;
+        if (ok) {
+            const float* src = partial + (n * T + t) * C + c;
+            for (int k = g; k < splits; k += G) a += src[(long)k * total];
+        }
+        red[g][p] = a;
+        __syncthreads();
+        if (g == 0 && ok) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < G; ++q) sum += red[q][p];
+            dw[i * T + t] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+static void launch_wgrad_reduce(const float* partial, float* dw, int N, int C, int T, int splits, hipStream_t s) {
+    const long pairs = (long)N * C;
+    if (splits >= 32 && pairs <= 2048) {
+        hipLaunchKernelGGL((wgrad_reduce_small_kernel<8, 32>), dim3((unsigned)((pairs + 7) / 8)), dim3(256), 0, s, partial, dw,
+                           N, C, T, splits);
+    } else if (splits >= 16 && pairs <= 16384) {
+        hipLaunchKernelGGL((wgrad_reduce_small_kernel<32, 8>), dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, partial,
+                           dw, N, C, T, splits);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, partial, dw, N, C, T,
+                           splits);
+    }
+}
+
 template <typename OUT>
 __device__ __forceinline__ OUT cvt_out(float v);
 template <>
@@ -973,18 +1021,14 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         int hs = 0;
         int rc = stylex_launch_wgrad_halo(p, partial, s, &hs);
         if (rc) return rc;
-        long total = (long)p.N * p.Ck;
-        int rb = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, 9, hs);
+        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s);
         return (int)hipGetLastError();
     }
     if (precision == STYLEX_BF16 && stylex_wgrad_tr_applicable(p)) {
         int ts = 0;
         int rc = stylex_launch_wgrad_tr(p, partial, s, &ts);
         if (rc) return rc;
-        long total = (long)p.N * p.Ck;
-        int rb = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, p.KH * p.KW, ts);
+        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, p.KH * p.KW, ts, s);
         return (int)hipGetLastError();
     }
     int tn, tc, splits;
@@ -1009,9 +1053,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
                 : (vec ? launch_wgrad<1, 1, true, false>(p, blocks, s) : launch_wgrad<1, 1, false, false>(p, blocks, s));
     }
     if (rc) return rc;
-    long total = (long)p.N * p.Ck;
-    int rb = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, dw_oihw, p.N, p.Ck, T, splits);
+    launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, T, splits, s);
     return (int)hipGetLastError();
 }
 
