@@ -731,38 +731,44 @@ template <int PP, int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                  int N, int C, int T, int splits) {
     static_assert(PP * G == 256, "one thread per (pair, slice group)");
-    __shared__ float red[G][PP];
+    __shared__ float red[G][PP][9];
     const long total = (long)N * C * T;
     const long pairs = (long)N * C;
     const int p = threadIdx.x % PP, g = threadIdx.x / PP;
     const long i = (long)blockIdx.x * PP + p;
     const bool ok = i < pairs;
-    const int c = ok ? (int)(i % C) : 0;
-    const long n = ok ? i / C : 0;
-    for (int t = 0; t < T; ++t) {
-        float a = 0.f;
-        if (ok) {
-            const float* src = partial + (n * T + t) * C + c;
-            for (int k = g; k < splits; k += G) a += src[(long)k * total];
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (ok) {
+        const float* src = partial + ((i / C) * T) * C + (int)(i % C);
+        for (int k = g; k < splits; k += G) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (t < T) acc[t] += src[(long)k * total + (long)t * C];
         }
-        red[g][p] = a;
-        __syncthreads();
-        if (g == 0 && ok) {
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[g][p][t] = acc[t];
+    __syncthreads();
+    // PP*T outputs of the block are contiguous in OIHW: thread o sums its G slice-group partials in fixed order
+    for (int o = threadIdx.x; o < PP * T; o += 256) {
+        const int pp = o / T, t = o - pp * T;
+        if ((long)blockIdx.x * PP + pp < pairs) {
             float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < G; ++q) sum += red[q][p];
-            dw[i * T + t] = sum;
+            for (int q = 0; q < G; ++q) sum += red[q][pp][t];
+            dw[(long)blockIdx.x * PP * T + o] = sum;
         }
-        __syncthreads();
     }
 }
 
 static void launch_wgrad_reduce(const float* partial, float* dw, int N, int C, int T, int splits, hipStream_t s) {
     const long pairs = (long)N * C;
-    if (splits >= 32 && pairs <= 2048) {
+    if (T <= 9 && splits >= 32 && pairs <= 2048) {
         hipLaunchKernelGGL((wgrad_reduce_small_kernel<8, 32>), dim3((unsigned)((pairs + 7) / 8)), dim3(256), 0, s, partial, dw,
                            N, C, T, splits);
-    } else if (splits >= 16 && pairs <= 16384) {
+    } else if (T <= 9 && splits >= 16 && pairs <= 16384) {
         hipLaunchKernelGGL((wgrad_reduce_small_kernel<32, 8>), dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, partial,
                            dw, N, C, T, splits);
     } else {
