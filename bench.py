@@ -130,6 +130,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda:%d" % local_rank)
+    # host side of a rank = kernel launches + the CPU RNG draws: a few threads per rank, not one pool per core per rank
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, world))))
     force_ddp = os.environ.get("STYLEX_FORCE_DDP") == "1"  # 1-rank RCCL smoke test of the N>1 code path
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -58,15 +58,18 @@ class GradSync:
         for bucket, flat, work in zip(self.buckets, flats, works):
             work.wait()
             flat.div_(world)
-            off = 0
+            off, dst, src = 0, [], []
             for p in bucket:
                 n = p.numel()
                 g = flat[off:off + n].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
-                    p.grad.copy_(g)
+                    dst.append(p.grad)
+                    src.append(g)
                 off += n
+            if dst:
+                torch._foreach_copy_(dst, src)  # one multi-tensor launch per bucket instead of one per parameter
 
 
 def all_reduce_scalar_flag(flag, device):
