@@ -945,9 +945,13 @@ static void igemm_splitk_plan(const ConvKParams& p, bool vec, int precision, int
     *kt_per = nk;
     // Small-spatial layers launch a handful of tiles whose K loop is pure latency (measured: 4-64 blocks, 35-45 us
     // per launch whatever the size): slice K down to 2 K-tiles per block.
-    if (blocks >= 192 || nk < 4) return;
+    // The fp32 parity mode keeps the coarser plan (>= 4 K-tiles per slice, K loops of >= 16 tiles only): the
+    // multi-step loss goldens were pinned with that summation order, and the untrained GAN amplifies a 1e-7
+    // reordering to a few 1e-3 within five steps.
+    const bool exact = precision == STYLEX_F32;
+    if (blocks >= 192 || nk < (exact ? 16 : 4)) return;
     long want = (512 + blocks - 1) / blocks;
-    long maxs = nk / 2;  // at least 2 K-tiles per slice
+    long maxs = nk / (exact ? 4 : 2);  // K-tiles per slice: >= 4 (fp32) / >= 2 (bf16)
     if (want > maxs) want = maxs;
     if (want > 36) want = 36;
     if (want < 2) return;

@@ -541,11 +541,12 @@ class HipOps:
         return y
 
     @staticmethod
-    def modulated_conv2d(x, style, weight, demod=True, eps=1e-8):
+    def modulated_conv2d(x, style, weight, demod=True, eps=1e-8, coeffs=None):
         """Conv2DMod.forward (:647-667) without materialising per-sample weights:
-        y = d[b,o] * conv(x * (style+1)[b,i], W),  d = rsqrt(((style+1)^2) @ sum_k W^2 + eps)."""
+        y = d[b,o] * conv(x * (style+1)[b,i], W),  d = rsqrt(((style+1)^2) @ sum_k W^2 + eps).
+        `coeffs` = mod_coeffs(style, weight, demod, eps) when the caller computed them ahead (side stream)."""
         x = _act(x)
-        s1 = style + 1
+        s1, d_pre = coeffs if coeffs is not None else mod_coeffs(style, weight, demod, eps)
         k = weight.shape[2]
         pad = (k - 1) // 2  # _get_same_padding for stride 1, dilation 1 (:644-645)
         n_out = weight.shape[0]
@@ -553,37 +554,29 @@ class HipOps:
         if n_out == 3:
             w_run = torch.cat([weight, weight.new_zeros(1, *weight.shape[1:])], dim=0)
         if fast_enabled() and w_run.shape[0] % 4 == 0:
-            d = None
-            if demod:
-                wsq = weight.pow(2).sum(dim=(2, 3))
-                d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)
-                if n_out == 3:
-                    d = torch.cat([d, d.new_ones(d.shape[0], 1)], dim=1)
+            d = d_pre
+            if demod and n_out == 3:
+                d = torch.cat([d, d.new_ones(d.shape[0], 1)], dim=1)
             y = _ModConvFast.apply(x, s1, d, w_run, None, None, None, pad, False)
             return y[:, :3] if n_out == 3 else y
         y = _Conv.apply(x * s1[:, :, None, None], w_run, 1, pad)
         if n_out == 3:
             y = y[:, :3]
         if demod:
-            wsq = weight.pow(2).sum(dim=(2, 3))  # [O, I]
-            d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)  # [B, O]
-            y = y * d[:, :, None, None]
+            y = y * d_pre[:, :, None, None]
         return y
 
     @staticmethod
-    def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8):
+    def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8, coeffs=None):
         """lrelu(Conv2DMod(x, style) + noise) of GeneratorBlock (:696-714) as one fused kernel when no
         double backward can be requested, else the differentiable composition."""
         x = _act(x)
         if fast_enabled() and weight.shape[0] % 4 == 0:
-            s1 = style + 1
-            d = None
-            if demod:
-                wsq = weight.pow(2).sum(dim=(2, 3))
-                d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)
+            s1, d = coeffs if coeffs is not None else mod_coeffs(style, weight, demod, eps)
             plane = inoise[:, :, :, 0]
             return _ModConvFast.apply(x, s1, d, weight, plane, noise_w, noise_b, (weight.shape[2] - 1) // 2, True)
-        return HipOps.noise_act(HipOps.modulated_conv2d(x, style, weight, demod, eps), inoise, noise_w, noise_b)
+        return HipOps.noise_act(HipOps.modulated_conv2d(x, style, weight, demod, eps, coeffs=coeffs), inoise, noise_w,
+                                noise_b)
 
     @staticmethod
     def noise_act(x, inoise, noise_w, noise_b):
@@ -637,6 +630,18 @@ def use_impl(impl):
 
 def impl():
     return _IMPL
+
+
+def mod_coeffs(style, weight, demod=True, eps=1e-8):
+    """(s+1, demodulation coefficient) of a modulated conv (:650-656 in the batched form): small dense math on
+    [B,C] / [O,I] tensors, independent of the activations — the Generator evaluates it for all layers ahead of
+    the conv chain on a companion stream."""
+    s1 = style + 1
+    d = None
+    if demod:
+        wsq = weight.pow(2).sum(dim=(2, 3))  # [O, I]
+        d = torch.rsqrt((s1 * s1) @ wsq.t() + eps)  # [B, O]
+    return s1, d
 
 
 def conv2d(*a, **k):

@@ -25,11 +25,11 @@ class CpuOracleOps:
         return so.lrelu(y) if lrelu else y
 
     @staticmethod
-    def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8):
+    def modconv_noise_act(x, style, weight, inoise, noise_w, noise_b, demod=True, eps=1e-8, coeffs=None):
         return CpuOracleOps.noise_act(so.modulated_conv2d(x, style, weight, demod, eps), inoise, noise_w, noise_b)
 
     @staticmethod
-    def modulated_conv2d(x, style, weight, demod=True, eps=1e-8):
+    def modulated_conv2d(x, style, weight, demod=True, eps=1e-8, coeffs=None):
         return so.modulated_conv2d(x, style, weight, demod, eps)
 
     @staticmethod
