@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     constexpr int W_ROWS = BN * 9;
     constexpr int W_SLOTS = (W_ROWS * 4 + 255) / 256;    // 16-byte global loads per thread per chunk
     constexpr int W_OFF = NP * ROWB;
+    // tap planes are skewed by 64 B: the staging store puts 4 consecutive taps of one output channel in 16
+    // neighbouring lanes, and BN*ROWB is a multiple of the 256-byte bank period
+    constexpr int W_TAP = BN * ROWB + 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
             int r = idx >> 2, qq = idx & 3;
             if (r < W_ROWS) {
                 int nl = r / 9, tap = r - nl * 9;
-                *reinterpret_cast<uint4*>(smem + W_OFF + (tap * BN + nl) * ROWB + qq * 16) = wreg[it];
+                *reinterpret_cast<uint4*>(smem + W_OFF + tap * W_TAP + nl * ROWB + qq * 16) = wreg[it];
             }
         }
     };
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                     av[i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + (kh * HWD + kw) * ROWB + ks * 32);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bv[j] = *reinterpret_cast<const bf16x8*>(smem + bbase + (tap * BN + j * 32) * ROWB + ks * 32);
+                    bv[j] = *reinterpret_cast<const bf16x8*>(smem + bbase + tap * W_TAP + j * 32 * ROWB + ks * 32);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     const int lj = lane & 31, lh = lane >> 5;
     constexpr int OUT_ES = ABF ? 2 : 4;                    // output element size
     constexpr int OROW = BN * OUT_ES + 16;                 // LDS row pitch of the staged output tile (+16 B skew)
-    static_assert(256 * OROW <= NP * ROWB + BN * 9 * ROWB, "output tile must fit in the staging LDS");
+    static_assert(256 * OROW <= NP * ROWB + 9 * W_TAP, "output tile must fit in the staging LDS");
     const bool wide = (p.N % (16 / OUT_ES) == 0);          // 16-byte global stores need aligned rows
     if (wide) {
 #pragma unroll
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
 template <int TW, int TN, bool ABF, bool S2D, bool EPIX>
 int launch_halo(const ConvKParams& p, hipStream_t s) {
     constexpr int TH = 256 / TW, NP = (TH + 2) * (TW + 2), BN = TN * 32;
-    constexpr size_t sm = (size_t)NP * ROWB + (size_t)BN * 9 * ROWB;
+    constexpr size_t sm = (size_t)NP * ROWB + 9 * ((size_t)BN * ROWB + 64);
     auto k = conv3x3_halo_bf16_kernel<TW, TN, ABF, S2D, EPIX>;
     static bool attr_done = false;
     if (!attr_done) {
