@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                         if ((p.flags & STYLEX_EPI_RESIDUAL) && nok)
                             v = (v + act_ld1(p.residual, ((long)(b * H + y) * W + x) * p.N + n, p.act_bf16)) * p.res_scale;
                     }
-                    if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
+                    if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
                     char* d = smem + pix * OROW + (j * 32 + lj) * OUT_ES;
                     if (ABF) *reinterpret_cast<unsigned short*>(d) = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
                     else *reinterpret_cast<float*>(d) = v;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 if (p.flags & STYLEX_EPI_BIAS) v += bias;
                 if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
                 if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
-                if (p.flags & STYLEX_EPI_LRELU) v = v > 0.f ? v : 0.2f * v;
+                if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
                 act_st1(p.y, o, v, p.act_bf16);
             }
         }

@@ -101,11 +101,12 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const void* __restri
             float4 gv = ld4(dy, o, bf);
             gv.x *= scale; gv.y *= scale; gv.z *= scale; gv.w *= scale;
             if (lrelu) {
+                const float slope = lrelu == 2 ? 0.f : 0.2f;  // 2 = ReLU
                 float4 yv = ld4(y, o, bf);
-                gv.x = yv.x > 0.f ? gv.x : 0.2f * gv.x;
-                gv.y = yv.y > 0.f ? gv.y : 0.2f * gv.y;
-                gv.z = yv.z > 0.f ? gv.z : 0.2f * gv.z;
-                gv.w = yv.w > 0.f ? gv.w : 0.2f * gv.w;
+                gv.x = yv.x > 0.f ? gv.x : slope * gv.x;
+                gv.y = yv.y > 0.f ? gv.y : slope * gv.y;
+                gv.z = yv.z > 0.f ? gv.z : slope * gv.z;
+                gv.w = yv.w > 0.f ? gv.w : slope * gv.w;
             }
             if (dx) st4(dx, o, gv, bf);
             a.v[0].x += gv.x; a.v[0].y += gv.y; a.v[0].z += gv.z; a.v[0].w += gv.w;

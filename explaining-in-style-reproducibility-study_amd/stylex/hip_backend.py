@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylex_hip.so")
 
 F32, BF16, BF16_ACT = 0, 1, 2  # BF16_ACT: bf16 MFMA + bf16 activation tensors in HBM
-EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL, EPI_RELU = 1, 2, 4, 8, 16, 32
 
 _c_f = ctypes.c_void_p  # device pointers travel as void*
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -290,8 +290,8 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
         keep.append(bias)
         flags |= EPI_BIAS
         epi.bias = bias.data_ptr()
-    if lrelu:
-        flags |= EPI_LRELU
+    if lrelu:  # True = LeakyReLU(0.2), "relu" = ReLU
+        flags |= EPI_RELU if lrelu == "relu" else EPI_LRELU
     if out_scale is not None:
         out_scale = _f32(out_scale)
         keep.append(out_scale)
@@ -462,7 +462,7 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True):
     nch = lib.stylex_reduce_chunks(shp)
     partial = torch.empty((b, nch, c), dtype=torch.float32, device=dy.device)
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
-    _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, int(bool(lrelu)),
+    _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)),
                                      float(scale), _adt(dy), _stream()), "stylex_act_bwd_reduce")
     return dx, partial.sum(dim=(0, 1))
 
@@ -481,7 +481,7 @@ def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu):
     if noise is not None:
         ns = noise.shape[1]
     _check(lib.stylex_modconv_bwd_prep(_ptr(gy), _ptr(y), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(gz),
-                                       _ptr(partial), shp, nch, int(bool(lrelu)), _adt(gy), _stream()),
+                                       _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)), _adt(gy), _stream()),
            "stylex_modconv_bwd_prep")
     return gz, partial.sum(dim=1)  # [B, 3, C]
 

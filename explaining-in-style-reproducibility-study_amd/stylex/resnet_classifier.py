@@ -48,4 +48,18 @@ class ResNet:
         x = F.interpolate(images, size=[self.resnet_dim, self.resnet_dim], mode="bilinear", align_corners=False)
         if self.normalize:
             x = (x - self._mean) / self._std
-        return self.model(x)
+        return self._net(x)(x)
+
+    def _net(self, x):
+        """Stock PyTorch fp32 module by default (north_star: the frozen classifier stays on stock PyTorch).
+        STYLEX_FROZEN_HIP=1 runs the BasicBlocks on the HIP conv kernels with BatchNorm folded
+        (frozen_resnet.py; exact in 'fp32' mode, +2.8 % step throughput in 'bf16' mode — but a bf16 ReLU network's
+        INPUT GRADIENT was measured 20 % off in the L2 sense (D's own LeakyReLU chain: 1.5 %), too noisy a
+        classifier signal to be the default)."""
+        if not x.is_cuda or os.environ.get("STYLEX_FROZEN_HIP", "0") != "1":
+            return self.model
+        if getattr(self, "_hip", None) is None:
+            from frozen_resnet import HipFrozenResNet
+
+            self._hip = HipFrozenResNet(self.model) if HipFrozenResNet.supports(self.model) else self.model
+        return self._hip

@@ -53,6 +53,7 @@ extern "C" {
 #define STYLEX_EPI_OSCALE 4    /* * out_scale[b][n]  (demodulation coefficient)      */
 #define STYLEX_EPI_NOISE 8     /* + noise[b][w][h] * noise_w[n] + noise_b[n] (sic: transposed) */
 #define STYLEX_EPI_RESIDUAL 16 /* (acc + residual[m][n]) * res_scale                 */
+#define STYLEX_EPI_RELU 32     /* max(v, 0) last (instead of LRELU; frozen ResNet blocks) */
 
 /* One-time per-process/per-device initialisation (kernel attributes). */
 int stylex_init(int device);
@@ -175,7 +176,8 @@ int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void*
  * Each launch writes partial[b][chunk][k][C] with nchunks = stylex_reduce_chunks(shape); the caller
  * sums over chunks (and over b where the parameter is per channel).  Deterministic.
  *
- * stylex_act_bwd_reduce:   dx = dy * scale * (lrelu ? (y>0 ? 1 : .2) : 1);  partial = sum_pixels dx
+ * stylex_act_bwd_reduce:   dx = dy * scale * (lrelu ? (y>0 ? 1 : slope) : 1), slope = .2 (lrelu==1) or 0 (lrelu==2, ReLU);
+ *                          partial = sum_pixels dx
  *   -> backward of lrelu(conv + bias) (stylex_train.py:726-731) and of (x+res)/sqrt(2) (:743);
  *      dx may be NULL (reduction only).
  * stylex_modconv_bwd_prep: for y = lrelu(d*z + noise[b,w,h]*nw[c] + nb[c]) (:700-714):
