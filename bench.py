@@ -169,6 +169,13 @@ def main():
     # ---- roofline of the dominant conv kernel class, hipEvent-timed on the launch stream
     roof = None
     if rank == 0 and args.roofline_steps > 0:
+        # kernel quality is measured with the branch-level stream concurrency of the Trainer switched off, so that an
+        # event pair brackets one kernel class running alone (the timed region above runs with it on)
+        prev_streams = os.environ.get("STYLEX_STREAMS")
+        os.environ["STYLEX_STREAMS"] = "0"
+        for _ in range(2):
+            tr.train()
+        torch.cuda.synchronize()
         hb.timing_enable(1)
         tr.steps = 0
         for _ in range(args.roofline_steps):
@@ -176,9 +183,13 @@ def main():
         torch.cuda.synchronize()
         rep = hb.timing_report()
         hb.timing_enable(0)
+        if prev_streams is None:
+            os.environ.pop("STYLEX_STREAMS", None)
+        else:
+            os.environ["STYLEX_STREAMS"] = prev_streams
         # forward and data-gradient launches run the SAME kernels (LDS-halo / implicit-GEMM conv with swapped
         # roles), so they form one kernel class; the weight gradient has its own kernels
-        merged = {"fwd_bwd_data": {k: rep["fwd"][k] + rep["bwd_data"][k] for k in ("ms", "flops", "launches")},
+        merged = {"fwd_bwd_data": {k: rep["fwd"][k] + rep["bwd_data"][k] for k in ("ms", "flops", "launches", "bytes")},
                   "bwd_weight": rep["bwd_weight"]}
         name, r = max(merged.items(), key=lambda kv: kv[1]["ms"])
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
@@ -195,6 +206,9 @@ def main():
         roof = {"bound": "mfma", "kernel": "conv_%s (implicit-GEMM MFMA)" % name, "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(1, r["launches"]), 4),
+                "algorithmic_bytes": round(r["bytes"] / max(1, r["launches"])),
+                "note": "per launch of the class over %d instrumented steps, stream concurrency off; traffic from "
+                        "profiles/r01_pmc_traffic.json" % args.roofline_steps,
                 "classes": {k: {"tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "ms": round(v["ms"], 2),
                                 "launches": v["launches"]} for k, v in rep.items()}}
     if world > 1:

@@ -15,6 +15,7 @@ struct TimedLaunch {
     hipEvent_t start, stop;
     int cls;
     double flops;
+    double bytes;  // algorithmic HBM bytes of the launch: operands in + result out, each once
 };
 std::mutex g_mu;
 bool g_timing = false;
@@ -22,15 +23,17 @@ std::vector<TimedLaunch> g_pending;
 int64_t g_launches[3] = {0, 0, 0};
 double g_ms[3] = {0, 0, 0};
 double g_flops[3] = {0, 0, 0};
+double g_bytes[3] = {0, 0, 0};
 
 struct ScopedTimer {
     bool on;
     TimedLaunch t;
     hipStream_t s;
-    ScopedTimer(int cls, double flops, hipStream_t stream) : on(g_timing), s(stream) {
+    ScopedTimer(int cls, double flops, double bytes, hipStream_t stream) : on(g_timing), s(stream) {
         if (!on) return;
         t.cls = cls;
         t.flops = flops;
+        t.bytes = bytes;
         (void)hipEventCreate(&t.start);
         (void)hipEventCreate(&t.stop);
         (void)hipEventRecord(t.start, s);
@@ -52,10 +55,20 @@ void drain_pending() {
         g_launches[t.cls] += 1;
         g_ms[t.cls] += ms;
         g_flops[t.cls] += t.flops;
+        g_bytes[t.cls] += t.bytes;
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
     g_pending.clear();
+}
+
+// algorithmic bytes of one conv launch: activation tensor in + out (each once, at the storage width of the
+// precision mode) + the weights once (fp32 master copy for the gradient, packed operand otherwise)
+double conv_bytes(const int64_t* sh, int precision, bool wgrad) {
+    const double es = precision == STYLEX_BF16_ACT ? 2.0 : 4.0;
+    const double in = (double)sh[0] * sh[1] * sh[2] * sh[3], out = (double)sh[0] * sh[9] * sh[10] * sh[4];
+    const double w = (double)sh[4] * sh[3] * sh[5] * sh[6];
+    return (in + out) * es + w * (wgrad ? 4.0 : (precision == STYLEX_F32 ? 4.0 : 2.0));
 }
 
 bool conv_shape_ok(const int64_t* sh) {
@@ -100,18 +113,20 @@ int stylex_timing_enable(int on) {
             g_launches[i] = 0;
             g_ms[i] = 0;
             g_flops[i] = 0;
+            g_bytes[i] = 0;
         }
     }
     return 0;
 }
 
-int stylex_timing_report(int cls, int64_t* launches, double* total_ms, double* total_flops) {
+int stylex_timing_report(int cls, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {
     if (cls < 0 || cls > 2) return STYLEX_EINVAL;
     drain_pending();
     std::lock_guard<std::mutex> lk(g_mu);
     if (launches) *launches = g_launches[cls];
     if (total_ms) *total_ms = g_ms[cls];
     if (total_flops) *total_flops = g_flops[cls];
+    if (total_bytes) *total_bytes = g_bytes[cls];
     return 0;
 }
 
@@ -189,7 +204,7 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
     if ((flags & STYLEX_EPI_RESIDUAL) && !p.residual) return STYLEX_EINVAL;
     if (p.s2d_c && (p.Ck != 4 * p.s2d_c || p.KH != 3 || p.stride != 1 || p.pad != 1 || p.s2d_c % 64)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (p.s2d_c ? 4.0 : 1.0);  // algorithmic: 9*C, not 36*C
-    ScopedTimer tm(0, flops, (hipStream_t)stream);
+    ScopedTimer tm(0, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream);
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -219,7 +234,7 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
         }
         if (!((flags & STYLEX_EPI_OSCALE) && !q.out_scale)) {
             double fl = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6] / (q.s2d_c ? 4.0 : 1.0);
-            ScopedTimer tmh(1, fl, (hipStream_t)stream);
+            ScopedTimer tmh(1, fl, conv_bytes(sh, q.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream);
             int rc = stylex_launch_halo(q, (hipStream_t)stream);
             if (rc != STYLEX_NOT_APPLICABLE) return rc;
             if (tmh.on) {  // not applicable: nothing was launched; fall through to the generic kernel
@@ -239,7 +254,7 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
     if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
     // algorithmic FLOPs of a data gradient = those of the forward conv
     double flops = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6];
-    ScopedTimer tm(1, flops, (hipStream_t)stream);
+    ScopedTimer tm(1, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream);
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -292,7 +307,7 @@ int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* wor
     p.s2d_c = s2d_c;
     if (s2d_c && (p.Ck != 4 * s2d_c || s2d_c % 64 || p.KH != 3 || p.stride != 1)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (s2d_c ? 4.0 : 1.0);
-    ScopedTimer tm(2, flops, (hipStream_t)stream);
+    ScopedTimer tm(2, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, true), (hipStream_t)stream);
     return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream);
 }
 

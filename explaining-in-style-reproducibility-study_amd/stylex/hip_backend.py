@@ -71,7 +71,7 @@ SIGNATURES = {
                                            ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
-                                            ctypes.POINTER(ctypes.c_double)]),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None
@@ -512,6 +512,7 @@ def timing_report():
         n = ctypes.c_int64()
         ms = ctypes.c_double()
         fl = ctypes.c_double()
-        lib.stylex_timing_report(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
-        out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value)
+        by = ctypes.c_double()
+        lib.stylex_timing_report(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+        out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
     return out

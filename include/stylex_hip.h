@@ -194,9 +194,11 @@ int stylex_scale_reduce(const void* x, const void* t, const float* s, void* gx, 
 
 /* Per-kernel timing hook: when enabled every conv launch is bracketed
  * by hipEvents on its stream; stylex_timing_report returns, per kernel class
- * (0=fwd,1=bwd_data,2=bwd_weight): launches, total ms, total algorithmic FLOPs. */
+ * (0=fwd,1=bwd_data,2=bwd_weight): launches, total ms, total algorithmic FLOPs and total algorithmic HBM
+ * bytes (activations in + out once at their storage width, weights once). */
 int stylex_timing_enable(int on);
-int stylex_timing_report(int kernel_class, int64_t* launches, double* total_ms, double* total_flops);
+int stylex_timing_report(int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
+                         double* total_bytes);
 
 #ifdef __cplusplus
 }

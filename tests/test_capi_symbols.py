@@ -49,4 +49,4 @@ def test_argument_validation_without_gpu():
     sh = (ctypes.c_int64 * 11)(1, 4, 4, 4, 4, 5, 5, 1, 2, 4, 4)  # 5x5 kernel: unsupported
     assert lib.stylex_conv2d_bwd_weight_workspace_bytes(sh) == -1
     assert lib.stylex_conv2d_fwd(None, None, None, sh, 0, None, 0, None, 0, None) == -1
-    assert lib.stylex_timing_report(7, None, None, None) == -1
+    assert lib.stylex_timing_report(7, None, None, None, None) == -1
