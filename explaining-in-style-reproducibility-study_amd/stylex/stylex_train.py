@@ -358,6 +358,11 @@ class StylEx(nn.Module):
         self._init_weights()
         self.reset_parameter_averaging()
         self.to(_dev(rank))
+        if _dev(rank).type == "cuda" and ops.get_precision() == "bf16":
+            # speed mode: one fused multi-tensor Adam launch per optimiser instead of ~23 foreach launches (same
+            # update rule; the fp32 parity mode keeps the default implementation the goldens were pinned with)
+            self.G_opt = Adam(generator_params, lr=self.lr, betas=(0.5, 0.9), fused=True)
+            self.D_opt = Adam(self.D.parameters(), lr=self.lr * ttur_mult, betas=(0.5, 0.9), fused=True)
 
     def _init_weights(self):
         for m in self.modules():  # the reference tests exact nn.Conv2d / nn.Linear types (:975-977)
