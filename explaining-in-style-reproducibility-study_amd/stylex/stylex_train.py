@@ -347,7 +347,8 @@ class StylEx(nn.Module):
                                 attn_layers=attn_layers, transparent=transparent, fmap_max=fmap_max)
         self.SE = StyleVectorizer(latent_dim, style_depth, lr_mul=lr_mlp)
         self.GE = Generator(image_size, latent_dim, network_capacity, transparent=transparent, attn_layers=attn_layers,
-                            no_const=no_const)  # (sic) the reference does not forward fmap_max here (:937-938)
+                            no_const=no_const, fmap_max=fmap_max)  # the reference omits fmap_max here (:937-938) and
+        # then crashes in reset_parameter_averaging for any fmap_max that actually caps a layer; identical at 512
         self.D_cl = None
         self.D_aug = AugWrapper(self.D, image_size)
         set_requires_grad(self.SE, False)
@@ -592,6 +593,11 @@ class Trainer:
             return [f() for f in fns]
         if getattr(self, "_side_streams", None) is None:
             self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            # parameters shared by branches on different streams (encoder, classifier input) accumulate across
+            # streams by design; the engine synchronises them — silence its advisory
+            warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if warn_off is not None:
+                warn_off(False)
         main = torch.cuda.current_stream()
         outs, used = [None] * len(fns), []
         for i in range(1, len(fns)):
