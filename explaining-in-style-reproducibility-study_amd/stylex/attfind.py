@@ -1,0 +1,131 @@
+"""Batched AttFind StyleSpace sweep — drop-in for ``attfind_extraction`` of the reference's
+``stylex/run_attfind_combined.ipynb`` (cell 5, :246-417; "old architecture" branch), producing the same datasets
+(``style_change, latents, base_prob, minima, maxima, style_coordinates, original_images, noise, discriminator``).
+
+The notebook perturbs ONE style coordinate at a time by mutating ``to_style{1,2}.bias`` in place and re-running
+the whole generator at batch 1: 2 x N_coords generator + classifier evaluations per image (2 x 2464 at 64 px).
+Here the same arithmetic is restructured for the GPU:
+
+* a perturbation is a per-sample additive offset on the block's style vector (``GeneratorBlock.forward_main(...,
+  styles=)``) — no parameter is mutated, so perturbations of different coordinates batch together;
+* a coordinate of block k only changes blocks k..L-1: the feature map and RGB entering block k are computed once
+  per image and shared by all perturbations of that block (prefix caching);
+* ``chunk`` perturbations (both directions of chunk/2 coordinates) run as one generator-suffix + classifier pass.
+"""
+import os
+
+import numpy as np
+import torch
+
+DATASETS = ("style_change", "latents", "base_prob", "minima", "maxima", "style_coordinates", "original_images",
+            "noise", "discriminator")
+
+
+def styles_def_to_tensor(styles_def):
+    return torch.cat([t[:, None, :].expand(-1, n, -1) for t, n in styles_def], dim=1)
+
+
+def _prefix_states(G, w_tensor, noise):
+    """Feature map / RGB entering every block for one image (batch 1), plus the unperturbed block styles."""
+    x = G.initial_conv(G.initial_block.expand(1, -1, -1, -1))
+    rgb, states = None, []
+    for li, block in enumerate(G.blocks):
+        istyle = w_tensor[:, li]
+        s1, s2 = block.to_style1(istyle), block.to_style2(istyle)
+        states.append((x, rgb, s1, s2))
+        x, _ = block.forward_main(x, istyle, noise, styles=(s1, s2))
+        rgb = block.to_rgb(x, rgb, istyle)
+    return states
+
+
+def _suffix(G, k, x, rgb, w_tensor, noise, styles_k):
+    """Blocks k..L-1 for a batch of perturbations of block k (styles_k = per-sample (style1, style2))."""
+    p = styles_k[0].shape[0]
+    w = w_tensor.expand(p, -1, -1)
+    nz = noise.expand(p, -1, -1, -1)
+    x = x.expand(p, -1, -1, -1)
+    rgb = None if rgb is None else rgb.expand(p, -1, -1, -1)
+    for li in range(k, len(G.blocks)):
+        block = G.blocks[li]
+        x, _ = block.forward_main(x, w[:, li], nz, styles=styles_k if li == k else None)
+        rgb = block.to_rgb(x, rgb, w[:, li])
+    return rgb.float()
+
+
+@torch.no_grad()
+def attfind_extraction(stylex, classifier, images, num_images, noise, shift_size=1.0, discriminator_threshold=None,
+                       use_discriminator=False, chunk=256, results_folder=None):
+    """images: iterable of [1,3,S,S] batches (the notebook's batch-size-1 loader).  Returns a dict of CPU tensors
+    with the notebook's dataset names; with `results_folder` also writes style_change_records.{hdf5|npz}."""
+    G = stylex.G
+    dev = next(G.parameters()).device
+    noise = noise.to(dev)
+    n_coords = sum(b.num_style_coords for b in G.blocks)
+    latents, base_logits, coords, disc, originals = [], [], [], [], []
+    for batch in images:
+        if len(latents) >= num_images:
+            break
+        batch = batch.to(dev)
+        enc = stylex.encoder(batch).reshape(1, -1)
+        w = torch.cat((enc, classifier.classify_images(batch)), dim=1)
+        generated, sc = G(styles_def_to_tensor([(w, G.num_layers)]), noise, get_style_coords=True)
+        d_out = stylex.D(generated).reshape(1)
+        if use_discriminator and discriminator_threshold is not None and float(d_out) < discriminator_threshold:
+            continue
+        originals.append(batch[0])
+        latents.append(w[0])
+        coords.append(sc[0])
+        disc.append(d_out)
+        base_logits.append(classifier.classify_images(generated)[0])
+    if not latents:
+        raise ValueError("No images pass the threshold check")
+    n = len(latents)
+    coords = torch.stack(coords)
+    minima, maxima = coords.min(dim=0)[0], coords.max(dim=0)[0]
+    effects = torch.zeros(n, 2, n_coords, 2, device=dev)
+    half = max(1, chunk // 2)
+    for i in range(n):
+        w_tensor = styles_def_to_tensor([(latents[i].unsqueeze(0), G.num_layers)])
+        states = _prefix_states(G, w_tensor, noise)
+        base = 0
+        for k, block in enumerate(G.blocks):
+            x_k, rgb_k, s1, s2 = states[k]
+            c1 = block.input_channels
+            for lo in range(0, block.num_style_coords, half):
+                idx = torch.arange(lo, min(lo + half, block.num_style_coords), device=dev)
+                sidx = base + idx
+                cur = coords[i, sidx]
+                # rows: [down for every coordinate of the chunk, then up]
+                delta = torch.cat(((minima[sidx] - cur) * shift_size, (maxima[sidx] - cur) * shift_size))
+                cols = torch.cat((idx, idx))
+                rows = torch.arange(cols.numel(), device=dev)
+                st1 = s1.expand(cols.numel(), -1).clone()
+                st2 = s2.expand(cols.numel(), -1).clone()
+                in1 = cols < c1
+                st1[rows[in1], cols[in1]] += delta[in1]
+                st2[rows[~in1], cols[~in1] - c1] += delta[~in1]
+                logits = classifier.classify_images(_suffix(G, k, x_k, rgb_k, w_tensor, noise, (st1, st2)))
+                diff = logits - base_logits[i][None]
+                m = idx.numel()
+                effects[i, 0, sidx] = diff[:m]
+                effects[i, 1, sidx] = diff[m:]
+            base += block.num_style_coords
+    out = {"style_change": effects, "latents": torch.stack(latents), "base_prob": torch.stack(base_logits),
+           "minima": minima[None], "maxima": maxima[None], "style_coordinates": coords,
+           "original_images": torch.stack(originals), "noise": noise, "discriminator": torch.stack(disc)}
+    out = {k: v.detach().float().cpu() for k, v in out.items()}
+    if results_folder is not None:
+        write_records(out, results_folder)
+    return out
+
+
+def write_records(out, results_folder):
+    """style_change_records.hdf5 with the notebook's dataset names (:392-416); .npz when h5py is not installed."""
+    try:
+        import h5py
+    except ImportError:
+        np.savez(os.path.join(results_folder, "style_change_records.npz"), **{k: v.numpy() for k, v in out.items()})
+        return
+    with h5py.File(os.path.join(results_folder, "style_change_records.hdf5"), "w") as f:
+        for k in DATASETS:
+            f.create_dataset(k, data=out[k].numpy(), dtype="f")

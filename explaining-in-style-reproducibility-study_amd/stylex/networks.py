@@ -123,8 +123,8 @@ class Conv2DMod(nn.Module):  # reference :632-667
         self.weight = nn.Parameter(torch.randn((out_chan, in_chan, kernel, kernel)))
         nn.init.kaiming_normal_(self.weight, a=0, mode="fan_in", nonlinearity="leaky_relu")
 
-    def forward(self, x, y, coeffs=None):
-        return ops.modulated_conv2d(x, y, self.weight, demod=self.demod, eps=self.eps, coeffs=coeffs)
+    def forward(self, x, y):
+        return ops.modulated_conv2d(x, y, self.weight, demod=self.demod, eps=self.eps)
 
 
 class RGBBlock(nn.Module):  # reference :604-629
@@ -135,9 +135,8 @@ class RGBBlock(nn.Module):  # reference :604-629
         self.conv = Conv2DMod(input_channel, 4 if rgba else 3, 1, demod=False)
         self.upsample = nn.Sequential(Upsample2x(), Blur()) if upsample else None
 
-    def forward(self, x, prev_rgb, istyle, pre=None):
-        style, coeffs = pre if pre is not None else (self.to_style(istyle), None)
-        x = self.conv(x, style, coeffs)
+    def forward(self, x, prev_rgb, istyle):
+        x = self.conv(x, self.to_style(istyle))
         if exists(prev_rgb):
             x = x + prev_rgb
         if exists(self.upsample):
@@ -160,25 +159,17 @@ class GeneratorBlock(nn.Module):  # reference :670-718
         self.activation = leaky_relu()
         self.to_rgb = RGBBlock(latent_dim, filters, upsample_rgb, rgba)
 
-    def modulation(self, istyle):
-        """Everything of the block that depends on the style vector only: the three affine style maps and the
-        (s+1, demod) coefficients of the three modulated convs."""
-        style1, style2, style_rgb = self.to_style1(istyle), self.to_style2(istyle), self.to_rgb.to_style(istyle)
-        return (style1, ops.mod_coeffs(style1, self.conv1.weight, self.conv1.demod, self.conv1.eps),
-                style2, ops.mod_coeffs(style2, self.conv2.weight, self.conv2.demod, self.conv2.eps),
-                style_rgb, ops.mod_coeffs(style_rgb, self.to_rgb.conv.weight, self.to_rgb.conv.demod, self.to_rgb.conv.eps))
-
-    def forward_main(self, x, istyle, inoise, mod=None):
-        """The feature path of the block (everything except the toRGB branch)."""
+    def forward_main(self, x, istyle, inoise, styles=None):
+        """The feature path of the block (everything except the toRGB branch).  `styles` = (style1, style2)
+        overrides the two affine style maps — the batched AttFind sweep (attfind.py) feeds per-sample offsets this
+        way instead of mutating `to_style*.bias` in place as the reference notebook does."""
         if exists(self.upsample):
             x = self.upsample(x)
-        style1, c1, style2, c2 = mod[:4] if mod is not None else (self.to_style1(istyle), None, None, None)
+        style1, style2 = styles if styles is not None else (self.to_style1(istyle), self.to_style2(istyle))
         x = ops.modconv_noise_act(x, style1, self.conv1.weight, inoise, self.to_noise1.weight[:, 0],
-                                  self.to_noise1.bias, demod=self.conv1.demod, eps=self.conv1.eps, coeffs=c1)
-        if mod is None:
-            style2 = self.to_style2(istyle)
+                                  self.to_noise1.bias, demod=self.conv1.demod, eps=self.conv1.eps)
         x = ops.modconv_noise_act(x, style2, self.conv2.weight, inoise, self.to_noise2.weight[:, 0],
-                                  self.to_noise2.bias, demod=self.conv2.demod, eps=self.conv2.eps, coeffs=c2)
+                                  self.to_noise2.bias, demod=self.conv2.demod, eps=self.conv2.eps)
         return x, torch.cat([style1, style2], dim=-1)
 
     def forward(self, x, prev_rgb, istyle, inoise):
@@ -263,7 +254,7 @@ class Generator(nn.Module):  # reference :747-825
         else:
             main = torch.cuda.current_stream()
             # (measured and dropped: evaluating all blocks' style affines / demod coefficients ahead on a second
-            # companion stream — GeneratorBlock.modulation() — changed nothing: 597 vs 600 images/s)
+            # companion stream changed nothing: 597 vs 600 images/s)
             for li, block in enumerate(self.blocks):
                 x, sc = block.forward_main(x, styles[:, li], input_noise)
                 coords.append(sc)

@@ -502,3 +502,16 @@ def test_full_size_resampling_roundtrip():
     lhs = float((ops.upsample2x(x).double() * r.double()).sum())
     rhs = float((x.double() * xr.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+
+
+def test_attfind_batched_engine_on_hip_vs_reference_notebook_golden():
+    """the batched AttFind sweep on the HIP kernels (fp32 mode) reproduces the datasets the
+    reference notebook's extraction cell writes (golden made by executing that cell on the reference StylEx)."""
+    import attfind
+    from test_attfind_cpu import build, check
+
+    g = load_golden("attfind_16")
+    m, clf, images, noise = build(g, device=DEV)
+    m = m.to(DEV)
+    out = attfind.attfind_extraction(m, clf, images, len(images), noise, shift_size=float(g["shift_size"]), chunk=64)
+    check(out, g, 2e-4)
