@@ -10,12 +10,16 @@ Here the same arithmetic is restructured for the GPU:
   styles=)``) — no parameter is mutated, so perturbations of different coordinates batch together;
 * a coordinate of block k only changes blocks k..L-1: the feature map and RGB entering block k are computed once
   per image and shared by all perturbations of that block (prefix caching);
-* ``chunk`` perturbations (both directions of chunk/2 coordinates) run as one generator-suffix + classifier pass.
+* ``chunk`` perturbations (both directions of chunk/2 coordinates) run as one generator-suffix + classifier pass;
+* under ``torch.distributed`` the sweep shards over images: every rank runs the cheap first pass on
+  all images (1 evaluation each, so minima / maxima need no collective), sweeps images ``rank::world`` and one
+  ``all_reduce(SUM)`` over the effect tensor (zero for foreign images) assembles the result on every rank.
 """
 import os
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 DATASETS = ("style_change", "latents", "base_prob", "minima", "maxima", "style_coordinates", "original_images",
             "noise", "discriminator")
@@ -84,7 +88,9 @@ def attfind_extraction(stylex, classifier, images, num_images, noise, shift_size
     minima, maxima = coords.min(dim=0)[0], coords.max(dim=0)[0]
     effects = torch.zeros(n, 2, n_coords, 2, device=dev)
     half = max(1, chunk // 2)
-    for i in range(n):
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if sharded else (0, 1)
+    for i in range(rank, n, world):
         w_tensor = styles_def_to_tensor([(latents[i].unsqueeze(0), G.num_layers)])
         states = _prefix_states(G, w_tensor, noise)
         base = 0
@@ -110,11 +116,13 @@ def attfind_extraction(stylex, classifier, images, num_images, noise, shift_size
                 effects[i, 0, sidx] = diff[:m]
                 effects[i, 1, sidx] = diff[m:]
             base += block.num_style_coords
+    if sharded:
+        dist.all_reduce(effects, op=dist.ReduceOp.SUM)
     out = {"style_change": effects, "latents": torch.stack(latents), "base_prob": torch.stack(base_logits),
            "minima": minima[None], "maxima": maxima[None], "style_coordinates": coords,
            "original_images": torch.stack(originals), "noise": noise, "discriminator": torch.stack(disc)}
     out = {k: v.detach().float().cpu() for k, v in out.items()}
-    if results_folder is not None:
+    if results_folder is not None and rank == 0:
         write_records(out, results_folder)
     return out
 

@@ -69,3 +69,38 @@ def test_batched_engine_vs_reference_notebook_golden(cpu_double):
     for chunk in (256, 10):  # one pass per block / ragged chunks
         out = attfind.attfind_extraction(m, clf, images, len(images), noise, shift_size=float(g["shift_size"]), chunk=chunk)
         check(out, g, 2e-5)
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    ops.use_impl(CpuOracleOps)
+    g = np.load(GOLD)
+    m, clf, images, noise = build(g)
+    out = attfind.attfind_extraction(m, clf, images, len(images), noise, shift_size=float(g["shift_size"]), chunk=64)
+    try:
+        check(out, g, 2e-5)
+        q.put((rank, "ok"))
+    except AssertionError as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    dist.destroy_process_group()
+
+
+def test_sweep_sharded_over_two_ranks_gloo():
+    """SURVEY §8(e): images sharded rank::world, one all_reduce assembles the effect tensor on every rank."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, "ok"), (1, "ok")], res
