@@ -693,10 +693,22 @@ class Trainer:
             n_fake = generated.shape[0]
             if apply_gp:
                 real.requires_grad_()
-                ops.set_fast(True)  # the fake branch is only ever differentiated once
-                fake_out = D_call(generated, detach=True)
-                ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
-                real_out = D_call(real)
+
+                def fake_branch():
+                    ops.set_fast(True)  # the fake branch is only ever differentiated once
+                    return D_call(generated, detach=True)
+
+                def real_branch():
+                    ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
+                    return D_call(real)
+
+                # the two D passes of a penalty step are independent until the loss: two HIP streams when D_aug is
+                # a pass-through (`fuse`; with augmentation the reference's fake-then-real draw order is kept)
+                if fuse:
+                    real_out, fake_out = self._fork([real_branch, fake_branch])
+                else:
+                    fake_out, real_out = fake_branch(), real_branch()
+                ops.set_fast(False)
                 grad_norms = gradient_norms(real, real_out)
             else:
                 # D(fake) and D(real) are one pass over the concatenated batch
