@@ -168,7 +168,7 @@ def main():
 
     # ---- roofline of the dominant conv kernel class, hipEvent-timed on the launch stream
     roof = None
-    if rank == 0 and args.roofline_steps > 0:
+    if args.roofline_steps > 0:  # on EVERY rank: train() contains the gradient all-reduce collectives
         # kernel quality is measured with the branch-level stream concurrency of the Trainer switched off, so that an
         # event pair brackets one kernel class running alone (the timed region above runs with it on)
         prev_streams = os.environ.get("STYLEX_STREAMS")
@@ -189,6 +189,7 @@ def main():
             os.environ["STYLEX_STREAMS"] = prev_streams
         # forward and data-gradient launches run the SAME kernels (LDS-halo / implicit-GEMM conv with swapped
         # roles), so they form one kernel class; the weight gradient has its own kernels
+    if args.roofline_steps > 0 and rank == 0:
         merged = {"fwd_bwd_data": {k: rep["fwd"][k] + rep["bwd_data"][k] for k in ("ms", "flops", "launches", "bytes")},
                   "bwd_weight": rep["bwd_weight"]}
         name, r = max(merged.items(), key=lambda kv: kv[1]["ms"])

@@ -730,6 +730,8 @@ class Trainer:
                     gp_val = gp.detach()
                     disc_loss = disc_loss + gp
                 tot_d += divergence.detach() / gae
+            if self.is_ddp and group is groups[-1]:
+                self._d_sync.arm()  # the all-reduce of D's gradients starts inside this backward
             (disc_loss / gae).backward()
         if self.is_ddp:
             self._d_sync.all_reduce()
@@ -805,6 +807,8 @@ class Trainer:
                         tot_kl += kl.detach()
                     total_all = total_all + total
                     tot_g += loss.detach() / gae
+                if self.is_ddp and group is groups[-1]:
+                    self._g_sync.arm()
                 total_all.backward()
         finally:
             set_requires_grad(m.D, True)

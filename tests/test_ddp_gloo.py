@@ -100,3 +100,63 @@ def test_two_rank_gloo(tmp_path):
         assert ok_after, "replicas diverged after two all-reduced steps"
         assert moved > 0
         assert np.isfinite(d_loss) and np.isfinite(g_loss)
+
+
+def _gradsync_worker(rank, world, port, q):
+    import torch.nn as nn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import parallel
+
+        torch.manual_seed(0)
+        net = nn.Sequential(nn.Linear(40, 300), nn.ReLU(), nn.Linear(300, 300), nn.ReLU(), nn.Linear(300, 7))
+        unused = nn.Linear(5, 5)  # a parameter set that never receives a gradient (contributes zeros)
+        params = list(unused.parameters()) + list(net.parameters())  # unused lands in the LAST bucket
+        sync = parallel.GradSync(params, bucket_bytes=2 * 1024, overlap=True)  # several buckets
+        assert len(sync.buckets) >= 3, len(sync.buckets)
+        x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
+        # reference: local gradients, averaged by hand
+        net(x).square().mean().backward()
+        local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered) / world
+        results = {}
+        for mode in ("armed", "plain"):
+            for p in params:
+                p.grad = None
+            if mode == "armed":
+                sync.arm()
+                launched_before = 0
+            net(x).square().mean().backward()
+            if mode == "armed":
+                launched_before = sync._next  # buckets already in flight when the backward returned
+            sync.all_reduce()
+            got = torch.cat([p.grad.reshape(-1) for p in params])
+            results[mode] = (float((got - want).abs().max()), launched_before if mode == "armed" else None)
+        q.put((rank, results))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradsync_overlapped_matches_manual_average():
+    """GradSync launches buckets from inside the backward (hooks, strict index order) and yields exactly the
+    rank-average; a never-used parameter's bucket is flushed with zeros by all_reduce()."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gradsync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, results in res:
+        assert results["armed"][0] < 1e-6 and results["plain"][0] < 1e-6, results
+        assert results["armed"][1] >= 2, "no bucket was launched during the backward: %r" % (results,)
