@@ -109,8 +109,8 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--precision", default=os.environ.get("STYLEX_PRECISION", "bf16"), choices=["bf16", "bf16_f32act", "fp32"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per micro-batch")
     ap.add_argument("--image-size", type=int, default=256)
