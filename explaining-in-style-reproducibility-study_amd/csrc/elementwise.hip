@@ -1,7 +1,8 @@
 // elementwise.hip — HBM-bound kernels of the StylEx step on gfx950: bilinear x2 and its adjoint,
 // 3x3 reflect blur and its adjoint, bias(+noise)+LeakyReLU and its gradient mask, row-wise
-// squared norms.  All tensors NHWC fp32; one lane handles VEC (4 or 1) consecutive channels of a
-// pixel so that a wave reads/writes whole 128-byte lines.  Grid-stride loops, 2048-block cap.
+// squared norms, even-pixel gather.  Tensors NHWC, fp32 or bf16 (act_dtype); one lane handles VEC consecutive
+// channels of a pixel (4 fp32 / 8 bf16 = 16 bytes, or 1 for odd channel counts) so that a wave reads/writes whole
+// lines.  Grid-stride loops.  bf16 blurs take the column-strip kernel below (5 TB/s vs 2-3 for the direct form).
 //
 // Reference ops replaced (file stylex/stylex_train.py): nn.Upsample(scale_factor=2, bilinear,
 // align_corners=False) :614,679; Blur :144-153 (kornia filter2d, reflect); nn.Conv2d bias +

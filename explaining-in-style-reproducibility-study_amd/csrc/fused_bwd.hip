@@ -3,7 +3,7 @@
 // so conv + bias/noise + LeakyReLU (+ demodulation / residual merge) run as ONE forward kernel and
 // the gradient bookkeeping below replaces 5-8 separate full-tensor passes and reductions).
 //
-// All tensors NHWC fp32.  One block = one image b x one contiguous pixel range; a thread owns VEC
+// Activation tensors NHWC fp32 or bf16 (act_dtype), sums in fp32.  One block = one image b x one contiguous pixel range; a thread owns VEC
 // consecutive channels and walks pixels with stride rows-per-pass, accumulating up to 3 column sums
 // in registers; the block combines them through LDS in fixed order and writes
 // partial[b][chunk][k][C]; the (tiny) sum over chunks is done by the caller.  Deterministic.

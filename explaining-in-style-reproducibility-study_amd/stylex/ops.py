@@ -11,7 +11,10 @@ The three convolution roles are closed under differentiation:
     Wgrad(x,gy)  --bwd-->  Dgrad(gy,ggw), Conv(x,ggw)
 
 Tensors are logically NCHW (reference API) and physically NHWC
-(``torch.channels_last``), fp32.
+(``torch.channels_last``); activations are fp32 in the parity mode and bf16 in
+the speed mode (``set_precision``).  First-order-only passes take the fused
+once-differentiable Functions (``set_fast``); double-differentiable passes use
+the same fused forward kernels with a backward composed of the Functions above.
 
 The module-level functions (``conv2d`` …) dispatch to an *implementation
 object*.  The default and only product implementation is the HIP one below; it
