@@ -137,3 +137,21 @@ def write_records(out, results_folder):
     with h5py.File(os.path.join(results_folder, "style_change_records.hdf5"), "w") as f:
         for k in DATASETS:
             f.create_dataset(k, data=out[k].numpy(), dtype="f")
+
+
+def find_significant_styles(style_change_effect, num_indices, class_index, max_image_effect=0.2, sindex_offset=0):
+    """Greedy selection of the style coordinates that most raise `class_index` (notebook cell 15): repeatedly take the
+    coordinate/direction with the largest mean positive effect over the images not yet explained (accumulated effect
+    < max_image_effect).  style_change_effect: [images, 2 directions, coords, classes].  Returns
+    [(direction, coordinate + sindex_offset)].  (The notebook's generator / classifier / latent arguments are unused.)"""
+    effect = np.array(style_change_effect, copy=True)
+    n_img, _, n_coords, _ = effect.shape
+    direction = np.maximum(0, effect[:, :, :, class_index].reshape((n_img, -1)))
+    images_effect = np.zeros(n_img)
+    chosen = []
+    while len(chosen) < num_indices:
+        nxt = int(np.argmax(np.mean(direction[images_effect < max_image_effect], axis=0)))
+        chosen.append(nxt)
+        images_effect += direction[:, nxt]
+        direction[:, nxt] = 0
+    return [(x // n_coords, (x % n_coords) + sindex_offset) for x in chosen]

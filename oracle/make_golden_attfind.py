@@ -97,5 +97,28 @@ def main():
     print({k: v.shape for k, v in out.items()})
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def main_select():
+    """Golden for the greedy style selection (notebook cell 15, ``find_significant_styles``), fed with the
+    ``style_change`` array of attfind_16.npz.  python oracle/make_golden_attfind.py select"""
+    nb = json.load(open(NOTEBOOK))
+    src = "".join(nb["cells"][15]["source"])
+    assert "def find_significant_styles(" in src
+    ns = dict(np=np)
+    exec(compile(src, NOTEBOOK + "#cell15", "exec"), ns)
+    g = np.load(os.path.join(os.path.dirname(HERE), "tests", "golden", "attfind_16.npz"))
+    effect = g["out/style_change"]
+    out = {}
+    for cls in (0, 1):
+        for thr in (0.2, 0.05):
+            sel = ns["find_significant_styles"](effect.copy(), 6, cls, None, None, None, None, None,
+                                                max_image_effect=thr, sindex_offset=0)
+            out["sel/c%d_t%g" % (cls, thr)] = np.array(sel, dtype=np.int64)
+    save("attfind_select_16", **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "select":
+    main_select()

@@ -104,3 +104,12 @@ def test_sweep_sharded_over_two_ranks_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, "ok"), (1, "ok")], res
+
+
+def test_find_significant_styles_vs_notebook_golden():
+    g = np.load(GOLD)
+    sel = np.load(os.path.join(ROOT, "tests", "golden", "attfind_select_16.npz"))
+    for cls in (0, 1):
+        for thr in (0.2, 0.05):
+            got = attfind.find_significant_styles(g["out/style_change"], 6, cls, max_image_effect=thr)
+            assert np.array_equal(np.array(got, dtype=np.int64), sel["sel/c%d_t%g" % (cls, thr)]), (cls, thr, got)
