@@ -427,7 +427,7 @@ class Trainer:
                  classifier_name=None,
                  # --- extensions (defaults reproduce the reference) ---
                  classifier=None, lpips_fn=None, gp_every=4, pl_every=32, pl_after=5000, device=None,
-                 *args, **kwargs):
+                 save_training_state=False, *args, **kwargs):
         kwargs.pop("kl_rec_during_disc", None)  # cli.py forwards it; only the new architecture reads it
         self.model_params = [args, kwargs]
         self.StylEx = None
@@ -470,6 +470,7 @@ class Trainer:
         self.sample_from_encoder = sample_from_encoder
         self.logger = None
         self.gp_every, self.pl_every, self.pl_after = gp_every, pl_every, pl_after
+        self.save_training_state = save_training_state
         self.device = _dev(device if device is not None else rank)
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
@@ -955,7 +956,13 @@ class Trainer:
     def save(self, num):
         if not exists(self.StylEx):
             self.init_StylEx()
-        torch.save({"StylEx": self.StylEx.state_dict(), "version": __version__}, self.model_name(num))
+        data = {"StylEx": self.StylEx.state_dict(), "version": __version__}
+        if self.save_training_state:
+            # extension: the reference drops optimiser moments, step count and the path-length mean on
+            # every restart; extra keys are ignored by the reference's loader (:1707-1716)
+            data["training_state"] = {"G_opt": self.StylEx.G_opt.state_dict(), "D_opt": self.StylEx.D_opt.state_dict(),
+                                      "steps": self.steps, "pl_mean": self.pl_mean}
+        torch.save(data, self.model_name(num))
         self.write_config()
 
     def load(self, num=-1):
@@ -972,6 +979,11 @@ class Trainer:
         if "version" in load_data:
             print(f"loading from version {load_data['version']}")
         self.StylEx.load_state_dict(load_data["StylEx"])
+        extra = load_data.get("training_state")
+        if extra is not None and self.save_training_state:
+            self.StylEx.G_opt.load_state_dict(extra["G_opt"])
+            self.StylEx.D_opt.load_state_dict(extra["D_opt"])
+            self.steps, self.pl_mean = extra["steps"], extra["pl_mean"]
         if self.is_ddp:
             parallel.broadcast_parameters(self.StylEx)
 

@@ -146,6 +146,39 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(a, b), k
 
 
+def test_checkpoint_with_training_state(tmp_path):
+    """Extension: with save_training_state=True the checkpoint also carries the optimiser moments,
+    the step count and the path-length mean, and a new Trainer restores them; the file stays a valid reference
+    checkpoint (the reference's loader reads 'StylEx' and 'version' only)."""
+    g = load_golden("steps_gae1_alt")
+    tr, _ = make_trainer(g, tmp_path)
+    del tr.save
+    tr.save_training_state = True
+    tr.save_every = 10 ** 9
+    for _ in range(2):
+        tr.train()
+    tr.pl_mean = 0.25
+    st.Trainer.save(tr, 7)
+    ck = torch.load(tr.model_name(7), weights_only=False)
+    assert {"StylEx", "version", "training_state"} == set(ck.keys())
+    tr2, _ = make_trainer(g, tmp_path)
+    tr2.save_training_state = True
+    tr2.save_every = 10 ** 9
+    tr2.load(7)
+    assert tr2.steps == 2 and tr2.pl_mean == 0.25
+    for name in ("G_opt", "D_opt"):
+        a = getattr(tr.StylEx, name).state_dict()["state"]
+        b = getattr(tr2.StylEx, name).state_dict()["state"]
+        assert len(a) == len(b) > 0
+        for k in a:
+            assert torch.equal(a[k]["exp_avg"], b[k]["exp_avg"]) and torch.equal(a[k]["exp_avg_sq"], b[k]["exp_avg_sq"])
+            assert float(a[k]["step"]) == float(b[k]["step"]) == 2.0
+    # without the flag the same file loads as a plain reference checkpoint
+    tr3, _ = make_trainer(g, tmp_path)
+    tr3.load(7)
+    assert not tr3.StylEx.G_opt.state_dict()["state"]
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback in the product path: HIP ops refuse CPU tensors."""
     ops.use_impl(ops.HipOps)
