@@ -1,0 +1,62 @@
+"""Race detector for the multi-stream step at FULL size: two fresh Trainers from the same seeds run N steps of the
+bench workload (256 px, B=32, GAE=2, bf16, HIP streams on); every loss scalar and a parameter checksum must be
+bit-identical.  All our reductions are fixed-order, so a missing stream dependency shows up as run-to-run noise.
+The frozen classifier / LPIPS run on MIOpen, whose default algorithms are NOT run-to-run reproducible (measured:
+identical input, logits differing at 1e-7, amplified to 2e-3 in D's bf16 output) — the check pins them with
+torch.backends.cudnn.deterministic.      python tools/determinism_check.py [steps] [image_size]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def run(steps=5, image_size=256, batch=32):
+    import torch
+
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    sys.path[:0] = [os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd", "stylex")]
+    import hip_backend as hb
+    import ops
+
+    hb.load_library()
+    ops.set_precision("bf16")
+    prev_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    a = argparse.Namespace(batch=batch, image_size=image_size, gae=2, classifier="resnet", workdir="/tmp/sb_det",
+                           precision="bf16")
+    runs = []
+    try:
+        for _ in range(2):
+            bench.seed_all(42)
+            tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
+            rows = []
+            for _i in range(steps):
+                tr.train()
+                rows.append((tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss, tr.last_gp_loss))
+            chk = float(sum(p.detach().double().abs().sum() for p in tr.StylEx.parameters()))
+            runs.append((rows, chk))
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        torch.backends.cudnn.deterministic = prev_det
+        ops.set_precision("fp32")
+    return runs
+
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    os.chdir(ROOT)
+    r = run(steps, size)
+    for i, (x, y) in enumerate(zip(r[0][0], r[1][0])):
+        print(i, "OK  " if x == y else "DIFF", x, y if x != y else "")
+    print("parameter checksum", r[0][1], r[1][1])
+    print("bit-identical:", r[0] == r[1])
+    sys.exit(0 if r[0] == r[1] else 1)
