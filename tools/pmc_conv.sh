@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/pmc1
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d /tmp/pmc1 -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py --precision bf16 --only "$1" --iters 2 > /tmp/pmc1.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d /tmp/pmc1 -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py --precision bf16 --batch ${BATCH:-64} --only "$1" --iters 2 > /tmp/pmc1.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("/tmp/pmc1/*counter_collection.csv")[0]
