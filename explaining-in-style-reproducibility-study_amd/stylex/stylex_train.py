@@ -470,6 +470,11 @@ class Trainer:
         self.sample_from_encoder = sample_from_encoder
         self.logger = None
         self.gp_every, self.pl_every, self.pl_after = gp_every, pl_every, pl_after
+        if os.environ.get("STYLEX_DETERMINISTIC") == "1":
+            # The HIP path is bit-reproducible run to run (fixed-order reductions, also across its streams); the only
+            # noise source of a step is MIOpen's default algorithm choice for the frozen classifier / LPIPS.  Pinning
+            # it makes a whole training run reproducible for about 1 % of step throughput.
+            torch.backends.cudnn.deterministic = True
         self.save_training_state = save_training_state
         self.device = _dev(device if device is not None else rank)
         self.lpips_fn = lpips_fn
