@@ -199,10 +199,18 @@ def gradient_norms(images, output):
     return ops.rowwise_sumsq(_flat_rows(gradients)).sqrt()
 
 
-def calc_pl_lengths(styles, images):
-    """Path lengths (reference :306-316); pl_noise is drawn on the CPU generator for draw-order parity."""
-    num_pixels = images.shape[2] * images.shape[3]
-    pl_noise = _Staging.upload(tuple(images.shape), lambda t: t.normal_().div_(math.sqrt(num_pixels)), images.device)
+def draw_pl_noise(shape, device):
+    """N(0,1)/sqrt(H*W) image noise of calc_pl_lengths (:308-309), drawn on the CPU generator (draw-order parity)."""
+    num_pixels = shape[2] * shape[3]
+    return _Staging.upload(tuple(shape), lambda t: t.normal_().div_(math.sqrt(num_pixels)), device)
+
+
+def calc_pl_lengths(styles, images, pl_noise=None):
+    """Path lengths (reference :306-316).  `pl_noise` lets the caller draw the noise itself (the Trainer draws it
+    micro-step by micro-step in the reference's order and evaluates the batched micro-steps in one call: the
+    per-sample lengths are independent)."""
+    if pl_noise is None:
+        pl_noise = draw_pl_noise(images.shape, images.device)
     outputs = (images * pl_noise).sum()
     with ops.inputs_only():
         (pl_grads,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones_like(outputs),
@@ -747,14 +755,14 @@ class Trainer:
         # ---------------- generator phase ----------------
         if self.alternating_training:
             encoder_input = False
-        if apply_pl:  # path-length regularisation draws torch RNG between micro-steps: no batching
-            groups = [[i] for i in range(gae)]
+        # (path-length steps batch like the others: the pl noise of a micro-step is drawn right after its other draws,
+        # where the reference draws it, and its shape does not depend on the generated images)
         ops.set_fast(not apply_pl)  # path-length regularisation is the only double backward of this phase
         m.G_opt.zero_grad()
         set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
         try:
             for group in groups:
-                ws, noises, micro = [], [], []
+                ws, noises, micro, pl_noises = [], [], [], []
                 for _ in group:
                     batch = self._next_batch()
                     enc_step = (not self.alternating_training) or encoder_input
@@ -769,9 +777,13 @@ class Trainer:
                     noises.append(inoise)
                     if fuse:
                         random()  # the AugWrapper draw of this micro-step (:1417)
+                        if apply_pl:
+                            pl_noises.append(draw_pl_noise((w_styles.shape[0], 4 if self.transparent else 3, image_size,
+                                                            image_size), dev))
                     encoder_input = not encoder_input
                 w_all = cat(ws)
                 generated_all = m.G(w_all, cat(noises))
+                pl_all = calc_pl_lengths(w_all, generated_all, cat(pl_noises)) if (apply_pl and pl_noises) else None
                 # four independent consumers of the generated batch: D, and per encoder micro-step the classifier,
                 # the encoder and LPIPS — forked over HIP streams (see _fork)
                 spans, lo = [], 0
@@ -795,7 +807,7 @@ class Trainer:
                     loss = gen_hinge_loss(fake_all[sl], None)
                     total = loss
                     if apply_pl:
-                        pl_lengths = calc_pl_lengths(w_all, generated)
+                        pl_lengths = pl_all[sl] if pl_all is not None else calc_pl_lengths(w_all, generated)
                         avg_pl_length = np.mean(pl_lengths.detach().cpu().numpy())
                         if not is_empty(self.pl_mean):
                             pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
