@@ -20,6 +20,7 @@
 // are reduced in fixed order by wgrad_reduce_kernel (deterministic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "stylex_internal.h"
 
@@ -261,6 +262,128 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_halo_kernel(ConvKParams 
     }
 }
 
+// ---- LDS-DMA variant for the memory-latency-bound low-channel layers ---------------------------------------
+// PMC on the 64-channel 256 px layers: 54 % of the wave cycles of the kernel above are spent waiting for its
+// staging loads (144 accumulator VGPRs leave no room to prefetch the next tile in registers, 75 KB of LDS per
+// block none for a second buffer at 2 blocks/CU).  Here ONE block per CU owns both 75 KB buffers and stages with
+// global_load_lds_dwordx4 (global -> LDS, no VGPRs): tile t+1 is in flight while tile t is being multiplied, so a
+// CU always has 76 KB outstanding.  A wave instruction writes 1 KiB of LDS linearly (lane l -> +16 l bytes) =
+// 16 pixel rows x 64 B of one 32-channel panel — exactly the unpadded panel layout the transpose reads want —
+// while the per-lane GLOBAL address is free, so halo / image-border pixels point at a 16-byte zero page.
+// bf16 activations, no per-sample scales (discriminator / encoder layers), TW = 32.
+__device__ uint4 g_zero_page[4];
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(1))) const void* gl_void_ptr;
+
+struct GeomDma {
+    static constexpr int NPR = 352;                       // 340 halo pixels rounded up to 16-pixel DMA pieces
+    static constexpr int DY_PANEL = 256 * PIX_ROW + 64;
+    static constexpr int X_PANEL = NPR * PIX_ROW + 64;
+    static constexpr int X_OFF = 2 * DY_PANEL;
+    static constexpr int BUF = 2 * DY_PANEL + 2 * X_PANEL;
+    static constexpr int SMEM_BYTES = 2 * BUF;            // 152.5 KiB: one block per CU
+};
+
+template <bool S2D>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKParams p) {
+    constexpr int TW = 32, TH = 8, HWD = 34, NP = 340;
+    constexpr int DY_PANEL = GeomDma::DY_PANEL, X_PANEL = GeomDma::X_PANEL, X_OFF = GeomDma::X_OFF, BUF = GeomDma::BUF;
+    static_assert(DY_PANEL == Geom<32>::DY_PANEL, "compute_tile addresses the dy panels with Geom<32>'s pitch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int H = p.Ho, W = p.Wo, C = p.Ck, N = p.N;
+    const int n_tiles = (N + 63) / 64, c_tiles = (C + 63) / 64;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total_tiles = p.B * tiles_img;
+    int bid = blockIdx.x;
+    {
+        int nblk = gridDim.x, q = nblk >> 3, rr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int ot = bid % (n_tiles * c_tiles);
+    const int split = bid / (n_tiles * c_tiles);
+    const int n0 = (ot / c_tiles) * 64, c0 = (ot % c_tiles) * 64;
+    const int t_begin = split * (int)p.split_len;
+    const int t_end = min(total_tiles, t_begin + (int)p.split_len);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const unsigned tapmask = S2D ? stylex_s2d_tap_mask((c0 + wc * 32) / p.s2d_c) : 0x1ffu;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int lane_off = ((g >> 1) * 8 + (i16 >> 2)) * PIX_ROW + ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+
+    const unsigned short* dy = reinterpret_cast<const unsigned short*>(p.a2);
+    const unsigned short* xs = reinterpret_cast<const unsigned short*>(p.a);
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page);
+    const int lp = lane >> 2, slot = lane & 3;  // pixel row within a 16-pixel piece, 16-byte slot within its 64 B
+
+    auto issue = [&](int tile, int buf) {
+        const int b = tile / tiles_img;
+        const int tt = tile - b * tiles_img;
+        const int y0 = (tt / tiles_x) * TH, x0 = (tt % tiles_x) * TW;
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {  // dy: 2 panels x 16 pieces of 16 pixels
+            const int ch = wave + 4 * it, panel = ch >> 4, piece = ch & 15;
+            const int px = piece * 16 + lp;
+            const int y = y0 + (px >> 5), x = x0 + (px & 31);
+            const int nn = n0 + panel * 32 + slot * 8;
+            const unsigned short* src = (nn < N && y < H && x < W) ? dy + ((long)(b * H + y) * W + x) * N + nn : zero;
+            __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + panel * DY_PANEL + piece * 16 * PIX_ROW),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 11; ++it) {  // x halo: 2 panels x 22 pieces
+            const int ch = wave + 4 * it;
+            if (ch < 44) {
+                const int panel = ch >= 22 ? 1 : 0, piece = ch - panel * 22;
+                const int hp = piece * 16 + lp;
+                const int hh = hp / HWD, ww = hp - hh * HWD;
+                const int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                const int cc = c0 + panel * 32 + slot * 8;
+                const bool ok = hp < NP && cc < C && y >= 0 && y < H && x >= 0 && x < W;
+                const unsigned short* src = ok ? xs + ((long)(b * H + y) * W + x) * C + cc : zero;
+                __builtin_amdgcn_global_load_lds((gl_void_ptr)src,
+                                                 (lds_void_ptr)(base + X_OFF + panel * X_PANEL + piece * 16 * PIX_ROW), 16, 0, 0);
+            }
+        }
+    };
+
+    if (t_begin < t_end) issue(t_begin, 0);
+    int buf = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of `tile` have landed
+        __syncthreads();                                   // ... and everybody else's; compute(tile-1) is finished
+        if (tile + 1 < t_end) issue(tile + 1, buf ^ 1);
+        const char* a_base = smem + buf * BUF + wn * DY_PANEL + lane_off;
+        const char* b_base = smem + buf * BUF + X_OFF + wc * X_PANEL + lane_off;
+        if (!S2D) compute_tile<TW, 0x1ffu>(acc, a_base, b_base);
+        else if (tapmask == 0x010u) compute_tile<TW, 0x010u>(acc, a_base, b_base);
+        else if (tapmask == 0x018u) compute_tile<TW, 0x018u>(acc, a_base, b_base);
+        else if (tapmask == 0x012u) compute_tile<TW, 0x012u>(acc, a_base, b_base);
+        else compute_tile<TW, 0x01bu>(acc, a_base, b_base);
+    }
+
+    const int lj = lane & 31, lh = lane >> 5;
+    float* out = p.y + (long)split * N * 9 * C;
+    const int c = c0 + wc * 32 + lj;
+    if (c < C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n < N) out[((long)n * 9 + t) * C + c] = acc[t][r];
+            }
+    }
+}
+
 }  // namespace
 
 bool stylex_wgrad_halo_applicable(const ConvKParams& p) {
@@ -279,11 +402,32 @@ static void tile_dims(const ConvKParams& p, int* tw, int* th) {
     *th = 256 / *tw;
 }
 
+// the LDS-DMA variant: bf16, unscaled, 32-wide tiles, few output tiles (<= 128 channels on both sides: the layers
+// whose time is staging latency, not MFMA)
+static bool wgrad_dma_eligible(const ConvKParams& p) {
+    static const bool off = getenv("STYLEX_WGRAD_DMA") && getenv("STYLEX_WGRAD_DMA")[0] == '0';
+    if (off) return false;
+    if (!p.act_bf16 || p.Ck % 8 != 0 || p.N % 8 != 0 || p.Wo < 32 || p.a_scale || p.a2_scale) return false;
+    if (p.s2d_c) return false;  // space-to-depth tiles do 1-4 taps per staged tile: 2 blocks per CU hide that better
+    static const long max_otiles = getenv("STYLEX_WGRAD_DMA_OT") ? atol(getenv("STYLEX_WGRAD_DMA_OT")) : 8;
+    long otiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64);
+    return otiles <= max_otiles;
+}
+
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split) {
     int tw, th;
     tile_dims(p, &tw, &th);
     long tiles = (long)p.B * ((p.Wo + tw - 1) / tw) * ((p.Ho + th - 1) / th);
     long otiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64);
+    if (wgrad_dma_eligible(p)) {  // one resident block per CU
+        long want = (256 + otiles - 1) / otiles;
+        if (want > tiles) want = tiles;
+        if (want < 1) want = 1;
+        long tps = (tiles + want - 1) / want;
+        *tiles_per_split = (int)tps;
+        *splits = (int)((tiles + tps - 1) / tps);
+        return;
+    }
     // ~2 resident blocks per CU (measured: halving the splits of the 512x512 layers to save partial traffic
     // costs 40-60 % in kernel time — parallelism matters more)
     long want = (512 + otiles - 1) / otiles;
@@ -315,6 +459,18 @@ int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* 
     p.y = partial;
     int blocks = ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * splits;
     *splits_out = splits;
+    if (wgrad_dma_eligible(p)) {
+        auto k = p.s2d_c ? conv3x3_wgrad_halo_dma_kernel<true> : conv3x3_wgrad_halo_dma_kernel<false>;
+        static bool attr_done[2] = {false, false};
+        if (!attr_done[p.s2d_c ? 1 : 0]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               GeomDma::SMEM_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_done[p.s2d_c ? 1 : 0] = true;
+        }
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), GeomDma::SMEM_BYTES, s, p);
+        return (int)hipGetLastError();
+    }
     const bool abf = p.act_bf16 && p.Ck % 8 == 0 && p.N % 8 == 0;
     if (p.s2d_c) {
         if (abf) return p.Wo >= 32 ? launch_wgrad_halo<32, true, true>(p, blocks, s) : launch_wgrad_halo<16, true, true>(p, blocks, s);
