@@ -409,7 +409,7 @@ static bool wgrad_dma_eligible(const ConvKParams& p) {
     if (off) return false;
     if (!p.act_bf16 || p.Ck % 8 != 0 || p.N % 8 != 0 || p.Wo < 32 || p.a_scale || p.a2_scale) return false;
     if (p.s2d_c) return false;  // space-to-depth tiles do 1-4 taps per staged tile: 2 blocks per CU hide that better
-    static const long max_otiles = getenv("STYLEX_WGRAD_DMA_OT") ? atol(getenv("STYLEX_WGRAD_DMA_OT")) : 8;
+    static const long max_otiles = getenv("STYLEX_WGRAD_DMA_OT") ? atol(getenv("STYLEX_WGRAD_DMA_OT")) : 16;
     long otiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64);
     return otiles <= max_otiles;
 }
