@@ -335,6 +335,10 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
     if (p.Ck % 8 != 0 || p.Wo < 16 || p.Ho < 8 || (long)p.Ho * p.Wo < 256) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return STYLEX_NOT_APPLICABLE;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return STYLEX_NOT_APPLICABLE;
+    {
+        int rc = stylex_launch_halo_dma(p, s);
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+    }
     const bool wide = p.Wo >= 32;
     const bool epix = (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL)) != 0;
     if (p.act_bf16) {

@@ -1,0 +1,214 @@
+// conv_halo_dma.hip — 3x3 / stride-1 / pad-1 forward and data gradient for the >= 128-channel layers of the
+// discriminator / encoder (bf16 activations, no per-sample scales), staged with LDS-DMA.
+//
+// Why a second halo kernel.  conv_halo.hip stages through registers (60 VGPRs of prefetch + 64 of accumulators at 2
+// blocks per CU = the whole 256-register budget) and reads 1 KB of LDS per MFMA (64 px x 64 n wave tiles) — exactly
+// the LDS port limit, measured 42 % of the MFMA peak at best.  global_load_lds_dwordx4 needs no staging registers, so
+// one block per CU can afford a 16x32-pixel x 128-channel tile (wave tile 128 px x 128 n = 4x4 MFMA tiles, 256
+// accumulator registers): every operand read feeds four MFMAs (0.5 KB of LDS per MFMA), the weights of a chunk are
+// staged once per 512 pixels instead of once per 256, and the next 16-channel chunk streams into the second LDS
+// buffer while this one is multiplied.
+//
+// LDS image of a chunk (16 input channels = 32-byte rows, unpadded — 8 consecutive rows cover the 256-byte bank
+// period once): halo rows [18*34 -> 640][32 B], then weight rows [9 taps][128 n][32 B].  A DMA wave instruction writes
+// 1 KiB linearly (lane l -> +16 l bytes) = 32 rows; the per-lane global address is free, so padding pixels and
+// channel tails read a 16-byte zero page.
+//
+// Epilogue: bias + (Leaky)ReLU only (what those layers use); the data gradient passes flip_taps and no flags.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "stylex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ uint4 g_zero_page_fwd[4];
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(1))) const void* gl_void_ptr;
+
+__device__ __forceinline__ unsigned short to_bf16(float v) {
+    f32x2_t t = {v, 0.f};
+    bf16x2_t r = __builtin_convertvector(t, bf16x2_t);
+    return (unsigned short)(*reinterpret_cast<unsigned*>(&r) & 0xffffu);
+}
+
+constexpr int TW = 32, TH = 16, HWD = TW + 2, NP = (TH + 2) * HWD;  // 612 halo pixels
+constexpr int ROW = 32;                                              // bytes per LDS row (16 bf16)
+constexpr int HALO_PIECES = (NP + 31) / 32;                          // 20 DMA pieces of 32 rows
+constexpr int HALO_BYTES = HALO_PIECES * 1024;
+constexpr int BN = 128;
+constexpr int W_PIECES = 9 * BN / 32;                                // 36
+constexpr int W_BYTES = W_PIECES * 1024;
+constexpr int BUF = HALO_BYTES + W_BYTES;                            // 57344
+constexpr int SMEM_BYTES = 2 * BUF;                                  // 112 KiB -> one block per CU
+static_assert(HALO_PIECES + W_PIECES == 56, "the staging loop assumes 14 DMA pieces per wave");
+
+__global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.Ho, W = p.Wo, C = p.Ck, N = p.N;
+    const int n_tiles = (N + BN - 1) / BN;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+
+    int bid = blockIdx.x;
+    {  // XCD-aware order: the output-channel tiles of one pixel tile are neighbours on one XCD
+        int nblk = gridDim.x, q = nblk >> 3, rr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int n0 = (bid % n_tiles) * BN;
+    int pt = bid / n_tiles;
+    const int b = pt / (tiles_x * tiles_y);
+    pt -= b * tiles_x * tiles_y;
+    const int y0 = (pt / tiles_x) * TH, x0 = (pt % tiles_x) * TW;
+
+    const unsigned short* xs = reinterpret_cast<const unsigned short*>(p.a);
+    const unsigned short* ws = reinterpret_cast<const unsigned short*>(p.w);
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page_fwd);
+    const int lr = lane >> 1, slot = lane & 1;  // row within a 32-row piece, 16-byte half of the 32-byte row
+
+    // per-wave piece list (same for every chunk): pieces wave, wave+4, ...; global element offsets without the chunk term
+    long src_off[14];
+    bool src_ok[14];
+#pragma unroll
+    for (int it = 0; it < 14; ++it) {
+        const int piece = wave + 4 * it;
+        if (piece < HALO_PIECES) {
+            const int hp = piece * 32 + lr;
+            const int hh = hp / HWD, ww = hp - hh * HWD;
+            const int y = y0 - 1 + hh, x = x0 - 1 + ww;
+            src_ok[it] = hp < NP && y >= 0 && y < H && x >= 0 && x < W;
+            src_off[it] = ((long)(b * H + y) * W + x) * C + slot * 8;
+        } else {
+            const int r = (piece - HALO_PIECES) * 32 + lr;  // weight row = tap * 128 + n
+            const int tap = r >> 7, nl = r & 127;
+            const int gt = p.flip_taps ? 8 - tap : tap;
+            src_ok[it] = n0 + nl < N;
+            src_off[it] = ((long)(n0 + nl) * 9 + gt) * C + slot * 8;
+        }
+    }
+
+    auto issue = [&](int c0, int buf) {
+        char* base = smem + buf * BUF;
+        const bool cok = c0 + slot * 8 < C;
+#pragma unroll
+        for (int it = 0; it < 14; ++it) {
+            const int piece = wave + 4 * it;
+            const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + src_off[it] + c0;
+            const unsigned short* src = (src_ok[it] && cok) ? g : zero;
+            __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // operand addressing: MFMA row-tile i of this wave = tile row 4*wave + i (32 pixels); lane li <-> pixel / channel
+    const int li = lane & 31, lk = lane >> 5;
+    const int a_lane = ((4 * wave) * HWD + li) * ROW + lk * 16;  // + i*HWD*ROW + (kh*HWD + kw)*ROW
+    const int b_lane = HALO_BYTES + li * ROW + lk * 16;          // + (tap*128 + j*32)*ROW
+
+    const int nchunks = (C + 15) / 16;
+    issue(0, 0);
+    int buf = 0;
+    for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ch + 1 < nchunks) issue((ch + 1) * 16, buf ^ 1);
+        const char* base = smem + buf * BUF;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            bf16x8 av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                av[i] = *reinterpret_cast<const bf16x8*>(base + a_lane + ((i + kh) * HWD + kw) * ROW);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bv[j] = *reinterpret_cast<const bf16x8*>(base + b_lane + (tap * BN + j * 32) * ROW);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the staging buffers: they become per-wave transpose scratch
+
+    // ---- epilogue: per row-tile i the wave's 32 px x 128 n block goes through LDS (8 KiB per wave) and leaves as
+    // 16-byte row stores (a pixel's 128 channels = 256 contiguous bytes).  D[row = pixel][col = channel]:
+    // col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    char* scratch = smem + wave * 8192;
+    const int lj = lane & 31, lh = lane >> 5;
+    const bool act = (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) != 0;
+    const float slope = (p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f;
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 32 + lj;
+        bias[j] = ((p.flags & STYLEX_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
+    }
+    unsigned short* yout = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bias[j];
+                if (act) v = v > 0.f ? v : slope * v;
+                *reinterpret_cast<unsigned short*>(scratch + px * 256 + (j * 32 + lj) * 2) = to_bf16(v);
+            }
+        // wave-private scratch: LDS operations of one wave are ordered, no barrier needed
+        const int y = y0 + 4 * wave + i;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int id = lane + 64 * k;           // 512 slots of 16 B = 32 px x 16 slots
+            const int px = id >> 4, q = id & 15;
+            const int x = x0 + px, n = n0 + q * 8;
+            if (y < H && x < W && n < N) {
+                const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * 256 + q * 16);
+                *reinterpret_cast<uint4*>(yout + ((long)(b * H + y) * W + x) * N + n) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// STYLEX_NOT_APPLICABLE unless: bf16 activations, plain 3x3/s1/p1, no per-sample scales / noise / residual /
+// space-to-depth, >= 128 output and input channels (64 input channels = 4 chunks measured 7 % slower than the
+// register-staged kernel) in whole 8-channel slots, at least one 16x32 tile's worth of image.
+int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
+    static const bool on = !(getenv("STYLEX_HALO_DMA") && getenv("STYLEX_HALO_DMA")[0] == '0');
+    if (!on) return STYLEX_NOT_APPLICABLE;
+    if (!p.act_bf16 || p.s2d_c || p.a_scale) return STYLEX_NOT_APPLICABLE;
+    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) return STYLEX_NOT_APPLICABLE;
+    if (p.N < 128 || p.N % 8 != 0 || p.Ck % 8 != 0 || p.Ck < 128 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
+        (reinterpret_cast<uintptr_t>(p.y) & 15))
+        return STYLEX_NOT_APPLICABLE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_dma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    long blocks = tiles * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(conv3x3_halo_dma_kernel, dim3((unsigned)blocks), dim3(256), SMEM_BYTES, s, p);
+    return (int)hipGetLastError();
+}

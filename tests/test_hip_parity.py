@@ -69,6 +69,9 @@ CONV_CASES = [
     (4, 256, 136, 8, 8, 3, 1, 1),     # bf16: transpose-read wgrad, 128x128 tiles, ragged N, several pixel splits
     (2, 64, 128, 16, 16, 1, 2, 0),    # conv_res at a real channel ratio
     (3, 72, 64, 5, 7, 3, 2, 1),       # stride 2 with odd sizes, ragged 64x64 channel tiles
+    (2, 128, 128, 32, 32, 3, 1, 1),   # bf16: LDS-DMA halo kernel (16x32 px x 128 n tiles), whole tiles
+    (1, 136, 160, 20, 40, 3, 1, 1),   # bf16: LDS-DMA kernel, ragged: 8-channel tail, partial N tile, partial pixel tiles
+    (1, 128, 256, 16, 32, 3, 1, 1),   # bf16: LDS-DMA kernel, one pixel tile, two N tiles
 ]
 
 
@@ -241,6 +244,37 @@ def test_conv_bias_lrelu_and_second_order():
             assert other is None or float(other.abs().max()) == 0.0, nm
             continue
         close(a, b, 2e-4, "second-order grad " + nm)
+
+
+def test_dma_halo_kernel_bias_lrelu_epilogue():
+    """The LDS-DMA forward kernel's own epilogue (bias + LeakyReLU / ReLU) and its use as data gradient."""
+    ops.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(21)
+        B, C, N, H, W = 2, 128, 256, 24, 64
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(N, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        b = torch.randn(N, generator=g)
+        for act, ref_act in ((True, lambda t: F.leaky_relu(t, 0.2)), ("relu", F.relu), (False, lambda t: t)):
+            xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+            yr = ref_act(F.conv2d(xr, wr, br, 1, 1))
+            r = torch.randn(yr.shape, generator=g)
+            (yr * r).sum().backward()
+            xd, wd, bd = cl(x).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+            prev = ops.set_fast(True)
+            try:
+                y = ops.conv2d(xd, wd, bd, 1, 1, lrelu=act)
+                (y.float() * cl(r)).sum().backward()
+            finally:
+                ops.set_fast(prev)
+            close(yr, y, TOLBF, "dma fwd act=%s" % act)
+            # gradients: a bf16 pre-activation at the rounding threshold flips its (Leaky)ReLU mask, which moves single
+            # gradient entries by O(1) of their size — compared in the L2 sense (the no-activation case is tight)
+            for nm, a, b_ in (("dgrad", xr.grad, xd.grad), ("wgrad", wr.grad, wd.grad), ("bias", br.grad, bd.grad)):
+                rel = float((a.double() - b_.detach().double().cpu()).norm() / a.double().norm())
+                assert rel <= (6e-2 if act == "relu" else 3e-2 if act else 1e-2), "dma %s act=%s: relative L2 error %.3e" % (nm, act, rel)
+    finally:
+        ops.set_precision("fp32")
 
 
 def test_bf16_strip_blur_vs_oracle():
