@@ -69,6 +69,9 @@ SIGNATURES = {
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
+    "stylex_torgb_chunks": (ctypes.c_int, [_i64p]),
+    "stylex_torgb_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_torgb_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
@@ -499,6 +502,41 @@ def scale_reduce(x, t, s, want_gx=True):
     _check(lib.stylex_scale_reduce(_ptr(x), _ptr(t), _ptr(s), _ptr(gx), _ptr(partial), shp, nch, _adt(x), _stream()),
            "stylex_scale_reduce")
     return gx, partial.sum(dim=1)
+
+
+def torgb_ok(x):
+    """The streaming to-RGB kernels take bf16 NHWC inputs with a power-of-two channel count in [8, 512]."""
+    c = x.shape[1]
+    if os.environ.get("STYLEX_TORGB", "1") == "0":  # A/B switch: back to the generic conv path
+        return False
+    return x.is_cuda and x.dtype == torch.bfloat16 and 8 <= c <= 512 and (c & (c - 1)) == 0
+
+
+def torgb_fwd(x, s1, w):
+    """y[b, :3] = Conv2DMod(C, 3, 1, demod=False) of RGBBlock (:611, :621); returns the 4-channel bf16 NHWC
+    storage (channel 3 is zero) — slice [:, :3]."""
+    lib = _ensure_device(x)
+    assert is_cl(x) and x.dtype == torch.bfloat16
+    b, c, h, wd = x.shape
+    y = empty_cl((b, 4, h, wd), x)
+    s1, w = _f32(s1), _f32(w)
+    _check(lib.stylex_torgb_fwd(_ptr(x), _ptr(s1), _ptr(w), _ptr(y), _shape(b, h, wd, c), _stream()), "stylex_torgb_fwd")
+    return y
+
+
+def torgb_bwd(x, gy, s1, w, want_gx=True):
+    """Backward of torgb_fwd in one pass: returns (gx or None, T[B, 3, C] = sum_pixels x * gy)."""
+    lib = _ensure_device(x)
+    assert is_cl(x) and is_cl(gy) and gy.shape[1] == 4 and x.dtype == gy.dtype == torch.bfloat16
+    b, c, h, wd = x.shape
+    shp = _shape(b, h, wd, c)
+    nch = lib.stylex_torgb_chunks(shp)
+    partial = torch.empty((b, nch, 3, c), dtype=torch.float32, device=x.device)
+    gx = empty_cl(tuple(x.shape), x) if want_gx else None
+    s1, w = _f32(s1), _f32(w)
+    _check(lib.stylex_torgb_bwd(_ptr(x), _ptr(gy), _ptr(s1), _ptr(w), _ptr(gx), _ptr(partial), shp, _stream()),
+           "stylex_torgb_bwd")
+    return gx, (partial.sum(dim=1) if nch > 1 else partial[:, 0])
 
 
 def timing_enable(on):

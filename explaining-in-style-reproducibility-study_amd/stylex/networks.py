@@ -14,6 +14,8 @@ bias+LeakyReLU, blur and bilinear x2 are single fused kernels.
 import math
 from math import log2
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -135,8 +137,8 @@ class RGBBlock(nn.Module):  # reference :604-629
         self.conv = Conv2DMod(input_channel, 4 if rgba else 3, 1, demod=False)
         self.upsample = nn.Sequential(Upsample2x(), Blur()) if upsample else None
 
-    def forward(self, x, prev_rgb, istyle):
-        x = self.conv(x, self.to_style(istyle))
+    def forward(self, x, prev_rgb, istyle, style=None):
+        x = self.conv(x, self.to_style(istyle) if style is None else style)
         if exists(prev_rgb):
             x = x + prev_rgb
         if exists(self.upsample):
@@ -243,9 +245,16 @@ class Generator(nn.Module):  # reference :747-825
         x = self.initial_conv(self.initial_block.expand(batch, -1, -1, -1))
         rgb, coords = None, []
         # The toRGB chain (1x1 modulated conv to 3 channels, skip add, bilinear x2, blur: memory-bound kernels on
-        # 3-channel tensors) only feeds the NEXT toRGB, never the feature path, so it runs one block behind on a
-        # side HIP stream under the MFMA-bound convs of the next block; autograd replays it there in backward.
-        side = _side_stream(x)
+        # 3-channel tensors) only feeds the NEXT toRGB, never the feature path, so it CAN run one block behind on a
+        # side HIP stream under the MFMA-bound convs of the next block (STYLEX_G_SIDE=1).  Off by default since the
+        # streaming to-RGB kernels (csrc/torgb.hip) made the chain cheap: the overlap is worth 0.8 % (645 vs 650
+        # images/s), and with the short chain on a side stream the full-size determinism check (tools/
+        # determinism_check.py) stopped being bit-identical run to run — single pixels of the gradient handed from
+        # the side chain to the feature path differ (tools/probes/race_locator.py; the kernels themselves are
+        # reproducible under concurrency, tools/probes/torgb_concurrency_probe.py, and the autograd engine's
+        # cross-stream hand-off checks out in isolation, tools/probes/engine_stream_probe.py).  Root cause not found;
+        # until it is, the chain stays on the caller's stream.
+        side = _side_stream(x) if os.environ.get("STYLEX_G_SIDE", "0") == "1" else None
         if side is None:
             for li, block in enumerate(self.blocks):
                 x, sc = block.forward_main(x, styles[:, li], input_noise)
@@ -258,10 +267,12 @@ class Generator(nn.Module):  # reference :747-825
             for li, block in enumerate(self.blocks):
                 x, sc = block.forward_main(x, styles[:, li], input_noise)
                 coords.append(sc)
+                rgb_style = block.to_rgb.to_style(styles[:, li])  # the GEMMs stay on `main` (see below)
                 side.wait_stream(main)  # x is ready
                 x.record_stream(side)
+                rgb_style.record_stream(side)
                 with torch.cuda.stream(side):
-                    rgb = block.to_rgb(x, rgb, styles[:, li])
+                    rgb = block.to_rgb(x, rgb, None, style=rgb_style)
             main.wait_stream(side)
             rgb.record_stream(main)
         rgb = rgb.float()  # activations may be stored in bf16; the module API returns fp32 images

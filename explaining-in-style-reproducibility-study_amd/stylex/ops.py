@@ -23,6 +23,8 @@ double with ``use_impl`` to exercise the host logic without a GPU.
 """
 import math
 
+import os
+
 import torch
 
 import hip_backend as hb
@@ -433,6 +435,29 @@ class _ModConvFast(torch.autograd.Function):
         return gx, gs1, gd, gw, None, gnw, gnb, None, None
 
 
+class _ToRGBFast(torch.autograd.Function):
+    """RGBBlock's Conv2DMod(C, 3, 1, demod=False) (reference :611, :621) as one streaming kernel each way.
+    Returns the 4-channel storage (channel 3 zero); the caller slices [:, :3]."""
+
+    @staticmethod
+    def forward(ctx, x, s1, w):
+        x = _cl(x)
+        ctx.save_for_backward(x, s1, w)
+        return hb.torgb_fwd(x, s1, w)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, s1, w = ctx.saved_tensors
+        gx, t = hb.torgb_bwd(x, _cl(gy), s1, w, want_gx=ctx.needs_input_grad[0])
+        gs1 = gw = None
+        if ctx.needs_input_grad[1]:
+            gs1 = (t * w.reshape(1, 3, -1).float()).sum(dim=1)
+        if ctx.needs_input_grad[2]:
+            gw = (t * s1.float()[:, None, :]).sum(dim=0).reshape(w.shape).to(w.dtype)
+        return gx, gs1, gw
+
+
 class _BlurS2D(torch.autograd.Function):
     """blur3x3 whose output is stored space-to-depth ([B,4C,H/2,W/2]) for the stride-2 conv that follows."""
 
@@ -553,6 +578,8 @@ class HipOps:
         k = weight.shape[2]
         pad = (k - 1) // 2  # _get_same_padding for stride 1, dilation 1 (:644-645)
         n_out = weight.shape[0]
+        if fast_enabled() and n_out == 3 and k == 1 and not demod and hb.torgb_ok(x):
+            return _ToRGBFast.apply(x, s1, weight)[:, :3]  # to-RGB: a 3-column GEMM is an HBM stream, not MFMA work
         w_run = weight
         if n_out == 3:
             w_run = torch.cat([weight, weight.new_zeros(1, *weight.shape[1:])], dim=0)

@@ -192,6 +192,21 @@ int stylex_modconv_bwd_prep(const void* gy, const void* y, const float* noise, i
 int stylex_scale_reduce(const void* x, const void* t, const float* s, void* gx, float* partial, const int64_t* shape,
                         int nchunks, int act_dtype, void* stream);
 
+/* ---- to-RGB layer (RGBBlock.forward, stylex_train.py:618-621: Conv2DMod(C, 3, kernel 1, demod=False)) ----------
+ * Streaming kernels for the 3-output-channel modulated 1x1 convolution; bf16 NHWC activations only,
+ * C a power of two in [8, 512] (else STYLEX_NOT_APPLICABLE).  shape = {B, H, W, C}.
+ *   s1 = style + 1, fp32 [B][C];  w = the layer's weight, fp32 [3][C] (OIHW with 1x1 taps).
+ * stylex_torgb_fwd:  y[b,p,n] = sum_c x[b,p,c] * s1[b,c] * w[n,c]   -> y bf16 [B][H][W][4], channel 3 = 0.
+ * stylex_torgb_bwd:  gy bf16 [B][H][W][4] (channel 3 ignored);
+ *                    gx[b,p,c] = s1[b,c] * sum_n gy[b,p,n] w[n,c]   (gx may be NULL);
+ *                    partial[b][chunk][n][c] = sum over the chunk's pixels of x[b,p,c] * gy[b,p,n],
+ *                    chunk < stylex_torgb_chunks(shape); the caller sums over chunks and forms
+ *                    d style = sum_n w*T  and  dW = sum_b s1*T.  Deterministic. */
+int stylex_torgb_chunks(const int64_t* shape);
+int stylex_torgb_fwd(const void* x, const float* s1, const float* w, void* y, const int64_t* shape, void* stream);
+int stylex_torgb_bwd(const void* x, const void* gy, const float* s1, const float* w, void* gx, float* partial,
+                     const int64_t* shape, void* stream);
+
 /* Per-kernel timing hook: when enabled every conv launch is bracketed
  * by hipEvents on its stream; stylex_timing_report returns, per kernel class
  * (0=fwd,1=bwd_data,2=bwd_weight): launches, total ms, total algorithmic FLOPs and total algorithmic HBM

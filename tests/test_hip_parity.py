@@ -277,6 +277,45 @@ def test_dma_halo_kernel_bias_lrelu_epilogue():
         ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 20, 12), (2, 512, 4, 4), (2, 64, 33, 7), (2, 8, 16, 16), (1, 128, 64, 64),
+                                   (2, 256, 40, 40)])
+def test_torgb_streaming_kernels(shape):
+    """to-RGB (RGBBlock :611/:621 = Conv2DMod(C, 3, 1, demod=False)) on the streaming kernels: output, input
+    gradient, style gradient and weight gradient against the fp32 per-sample-weight formulation of :647-667."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    style = torch.randn(B, C, generator=g) * 0.5
+    w = torch.randn(3, C, 1, 1, generator=g) / C ** 0.5
+    r = torch.randn(B, 3, H, W, generator=g)
+    xr, sr, wr = x.clone().requires_grad_(), style.clone().requires_grad_(), w.clone().requires_grad_()
+    wmod = wr[None] * (sr[:, None, :, None, None] + 1)  # [B, 3, C, 1, 1]
+    yr = F.conv2d(xr.reshape(1, B * C, H, W), wmod.reshape(B * 3, C, 1, 1), groups=B).reshape(B, 3, H, W)
+    (yr * r).sum().backward()
+    ops.set_precision("bf16")
+    prev = ops.set_fast(True)
+    try:
+        xd, sd, wd = cl(x).requires_grad_(), style.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+        assert hb.torgb_ok(ops._act(xd))
+        y = ops.modulated_conv2d(xd, sd, wd, demod=False)
+        assert tuple(y.shape) == (B, 3, H, W)
+        (y.float() * r.to(DEV)).sum().backward()
+    finally:
+        ops.set_fast(prev)
+        ops.set_precision("fp32")
+    close(yr, y, TOLBF, "to-RGB out")
+    close(xr.grad, xd.grad, TOLBF, "to-RGB gx")
+    close(sr.grad, sd.grad, TOLBF, "to-RGB gstyle")
+    close(wr.grad, wd.grad, TOLBF, "to-RGB gw")
+
+
+def test_torgb_rejects_unsupported_channel_counts():
+    x = cl(torch.randn(1, 24, 4, 4)).to(torch.bfloat16)
+    assert not hb.torgb_ok(x)
+    with pytest.raises(hb.StylexHipError):
+        hb.torgb_fwd(x, torch.ones(1, 24, device=DEV), torch.ones(3, 24, 1, 1, device=DEV))
+
+
 def test_bf16_strip_blur_vs_oracle():
     """bf16 tensors take the column-strip blur kernels (forward and adjoint, plain and space-to-depth output):
     compare with the oracle on the bf16-rounded input; sizes exercise a partial last strip and both borders."""

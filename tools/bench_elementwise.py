@@ -51,6 +51,11 @@ def main():
             ("scale_reduce", lambda: hb.scale_reduce(x, y, s, want_gx=True), 3 * nb),
             ("bias_act_bwd", lambda: hb.bias_act_bwd(x, y), 3 * nb),
         ]
+        w3 = torch.randn(3, c, 1, 1, device=dev)
+        g4 = torch.randn(b, 4, r, r, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+        rgbb = b * r * r * 8.0
+        cases += [("torgb_fwd", lambda: hb.torgb_fwd(x, s, w3), nb + rgbb),
+                  ("torgb_bwd", lambda: hb.torgb_bwd(x, g4, s, w3), 2 * nb + rgbb)]
         if r <= 128:
             cases += [("upsample2x_fwd", lambda: hb.upsample2x_fwd(x), 5 * nb),
                       ("upsample2x_bwd", lambda: hb.upsample2x_bwd(x), 1.25 * nb)]
