@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
     const unsigned short* xs = reinterpret_cast<const unsigned short*>(p.a);
     const unsigned short* ws = reinterpret_cast<const unsigned short*>(p.w);
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page_fwd);
-    const int lr = lane >> 1, slot = lane & 1;  // row within a 32-row piece, 16-byte half of the 32-byte row
+    const int lr = lane >> 1, pslot = lane & 1;  // row within a 32-row piece, PHYSICAL 16-byte half of the 32-byte row
+    // Bank swizzle: LDS row R keeps channel half h at physical half h ^ bit3(R).  An MFMA operand read touches 16
+    // consecutive rows x ONE half per 16-lane pass (lane = row + 32 * half): unswizzled, rows r and r + 8 collide
+    // (32-byte rows = 8 banks, 64 banks) — measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.48; with the swap
+    // the 16 rows cover all 64 banks once.  Every piece starts at a multiple of 32 rows, so bit3(R) = bit3(lr).
+    const int slot = pslot ^ ((lr >> 3) & 1);   // logical channel half this lane fetches
 
     // per-wave piece list (same for every chunk): pieces wave, wave+4, ...; global element offsets without the chunk term
     long src_off[14];
@@ -116,8 +121,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
 
     // operand addressing: MFMA row-tile i of this wave = tile row 4*wave + i (32 pixels); lane li <-> pixel / channel
     const int li = lane & 31, lk = lane >> 5;
-    const int a_lane = ((4 * wave) * HWD + li) * ROW + lk * 16;  // + i*HWD*ROW + (kh*HWD + kw)*ROW
-    const int b_lane = HALO_BYTES + li * ROW + lk * 16;          // + (tap*128 + j*32)*ROW
+    const int a_row = (4 * wave) * HWD + li;  // halo row of this lane's pixel for (i, kh, kw) = (0, 0, 0)
+    int a_off[6][3];                          // swizzled byte offsets of the 18 distinct (i + kh, kw) operand rows
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int t = a_row + r * HWD + kw;
+            a_off[r][kw] = (t * ROW) | ((((t >> 3) ^ lk) & 1) << 4);
+        }
+    // weight rows tap*128 + j*32 + li: the tap / j terms are multiples of 16 rows, so bit3(row) = bit3(li)
+    const int b_lane = HALO_BYTES + li * ROW + ((((li >> 3) ^ lk) & 1) << 4);  // + (tap*128 + j*32)*ROW
 
     const int nchunks = (C + 15) / 16;
     issue(0, 0);
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
             bf16x8 av[4], bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                av[i] = *reinterpret_cast<const bf16x8*>(base + a_lane + ((i + kh) * HWD + kw) * ROW);
+                av[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i + kh][kw]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 bv[j] = *reinterpret_cast<const bf16x8*>(base + b_lane + (tap * BN + j * 32) * ROW);
