@@ -99,16 +99,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
         }
     }
 
-    auto issue = [&](int c0, int buf) {
+    auto issue_piece = [&](int c0, int buf, int it) {
         char* base = smem + buf * BUF;
         const bool cok = c0 + slot * 8 < C;
+        const int piece = wave + 4 * it;
+        const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + src_off[it] + c0;
+        const unsigned short* src = (src_ok[it] && cok) ? g : zero;
+        __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int c0, int buf) {
 #pragma unroll
-        for (int it = 0; it < 14; ++it) {
-            const int piece = wave + 4 * it;
-            const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + src_off[it] + c0;
-            const unsigned short* src = (src_ok[it] && cok) ? g : zero;
-            __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
-        }
+        for (int it = 0; it < 14; ++it) issue_piece(c0, buf, it);
     };
 
     f32x16 acc[4][4];
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
     for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ch + 1 < nchunks) issue((ch + 1) * 16, buf ^ 1);
+        const bool more = ch + 1 < nchunks;
         const char* base = smem + buf * BUF;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -156,6 +157,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            // the next chunk's 14 DMA pieces are issued two per tap, in the shadow of this tap's 16 MFMAs (a burst at
+            // the top of the chunk leaves the MFMA pipe empty while it is issued)
+            if (more && tap < 7) {
+                issue_piece((ch + 1) * 16, buf ^ 1, 2 * tap);
+                issue_piece((ch + 1) * 16, buf ^ 1, 2 * tap + 1);
+            }
         }
     }
     __syncthreads();  // every wave is done with the staging buffers: they become per-wave transpose scratch
