@@ -456,8 +456,8 @@ def rowwise_sumsq(x2d):
     return out
 
 
-def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True):
-    """dx = dy*scale*lrelu'(y); returns (dx or None, per-channel sum over b,h,w [C])."""
+def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True):
+    """dx = dy*scale*lrelu'(y); returns (dx or None, per-channel sum over b,h,w [C] or None when not wanted)."""
     lib = _ensure_device(dy)
     assert is_cl(dy) and (y is None or (is_cl(y) and y.dtype == dy.dtype))
     b, c, h, w = dy.shape
@@ -467,7 +467,7 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True):
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
     _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)),
                                      float(scale), _adt(dy), _stream()), "stylex_act_bwd_reduce")
-    return dx, partial.sum(dim=(0, 1))
+    return dx, (partial.sum(dim=(0, 1)) if want_sum else None)
 
 
 def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu):

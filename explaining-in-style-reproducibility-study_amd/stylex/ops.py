@@ -338,11 +338,11 @@ class _ConvBiasActFast(torch.autograd.Function):
         stride, pad, lrelu, scale, has_bias, has_res = ctx.cfg
         gy = _cl(gy)
         gb = None
+        want_gb = has_bias and ctx.needs_input_grad[2]  # False in the generator phase (D frozen): no reduction launch
         if _reducible(gy.shape[1]):
             want_dx = lrelu or scale != 1.0
-            if want_dx or has_bias:
-                gz, gsum = hb.act_bwd_reduce(gy, y, lrelu, scale, want_dx=want_dx)
-                gb = gsum if has_bias else None
+            if want_dx or want_gb:
+                gz, gb = hb.act_bwd_reduce(gy, y, lrelu, scale, want_dx=want_dx, want_sum=want_gb)
                 if not want_dx:
                     gz = gy
             else:
@@ -351,7 +351,7 @@ class _ConvBiasActFast(torch.autograd.Function):
             gz = hb.bias_act_bwd(gy, y) if lrelu else gy
             if scale != 1.0:
                 gz = gz * scale
-            gb = gz.sum(dim=(0, 2, 3), dtype=torch.float32) if has_bias else None
+            gb = gz.sum(dim=(0, 2, 3), dtype=torch.float32) if want_gb else None
         gx = hb.conv2d_bwd_data(gz, w, tuple(x.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[0] else None
         gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[1] else None
         if not ctx.needs_input_grad[2]:
@@ -505,9 +505,12 @@ class _DownS2DFast(torch.autograd.Function):
         n, c = w.shape[0], w.shape[1]
         gy = _cl(gy)
         want_dx = scale != 1.0
-        gz, gsum = hb.act_bwd_reduce(gy, None, False, scale, want_dx=want_dx)
-        if not want_dx:
-            gz = gy
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        gz, gsum = gy, None
+        if want_dx or want_gb:
+            gz, gsum = hb.act_bwd_reduce(gy, None, False, scale, want_dx=want_dx, want_sum=want_gb)
+            if not want_dx:
+                gz = gy
         gx2 = gw = None
         if ctx.needs_input_grad[0]:
             _, wb2 = hb.pack_weight_s2d(w)
@@ -516,7 +519,7 @@ class _DownS2DFast(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw2 = hb.conv2d_bwd_weight(x2, gz, (n, 4 * c, 3, 3), 1, 1, _PRECISION, s2d_c=c)
             gw = hb.fold_weight_grad_s2d(dw2, tuple(w.shape))
-        gb = gsum if (has_bias and ctx.needs_input_grad[2]) else None
+        gb = gsum if want_gb else None
         return gx2, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None
 
 
