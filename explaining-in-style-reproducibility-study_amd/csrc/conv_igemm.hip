@@ -407,34 +407,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
     }
 
     // ---- epilogue: D[i][j], col j = lane&31 (output channel), row i = (r&3)+8*(r>>2)+4*(lane>>5) (pixel)
+    // Rows are ordered (b, oh, ow) except in the phase-major gather, so the NHWC output offset of row m is m * N: the
+    // (b, oh, ow) decomposition (two integer divisions) is only needed for the per-image scale and the noise plane.
+    // It used to run for each of the 64 accumulator elements of a lane and was the ~40 us floor of every small launch.
     const int lj = lane & 31, lh = lane >> 5;
+    const bool split = p.ksplit > 1;
+    const bool need_pix = p.phase_major || (!split && (p.flags & (STYLEX_EPI_OSCALE | STYLEX_EPI_NOISE)));
+    int nn[TN];
+    float bias[TN], nw[TN], nb[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        int n = n0 + wn * TN * 32 + j * 32 + lj;
-        if (n >= p.N) continue;
-        float bias = (p.flags & STYLEX_EPI_BIAS) ? p.bias[n] : 0.f;
-        float nw = 0.f, nb = 0.f;
-        if (p.flags & STYLEX_EPI_NOISE) {
-            nw = p.noise_w[n];
-            nb = p.noise_b[n];
+        nn[j] = n0 + wn * TN * 32 + j * 32 + lj;
+        bias[j] = nw[j] = nb[j] = 0.f;
+        if (nn[j] < p.N && !split) {
+            if (p.flags & STYLEX_EPI_BIAS) bias[j] = p.bias[nn[j]];
+            if (p.flags & STYLEX_EPI_NOISE) {
+                nw[j] = p.noise_w[nn[j]];
+                nb[j] = p.noise_b[nn[j]];
+            }
         }
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                RowPix rp = decode_row(p, m);
-                long o = ((long)(rp.b * p.Ho + rp.oh) * p.Wo + rp.ow) * p.N + n;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            RowPix rp;
+            rp.b = rp.oh = rp.ow = 0;
+            long orow = (long)m * p.N;
+            if (need_pix) {
+                rp = decode_row(p, m);
+                orow = ((long)(rp.b * p.Ho + rp.oh) * p.Wo + rp.ow) * p.N;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nn[j];
+                if (n >= p.N) continue;
+                const long o = orow + n;
                 float v = acc[i][j][r];
-                if (p.ksplit > 1) {  // raw slice sum; the epilogue runs in splitk_epilogue_kernel
+                if (split) {  // raw slice sum; the epilogue runs in splitk_epilogue_kernel
                     p.partial[(long)kslice * p.M * p.N + o] = v;
                     continue;
                 }
                 if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)rp.b * p.N + n];
-                if (p.flags & STYLEX_EPI_BIAS) v += bias;
+                if (p.flags & STYLEX_EPI_BIAS) v += bias[j];
                 if (p.flags & STYLEX_EPI_NOISE)
-                    v += p.noise[((long)rp.b * p.noise_stride + rp.ow) * p.noise_stride + rp.oh] * nw + nb;
+                    v += p.noise[((long)rp.b * p.noise_stride + rp.ow) * p.noise_stride + rp.oh] * nw[j] + nb[j];
                 if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
                 if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
                 act_st1(p.y, o, v, p.act_bf16);
