@@ -834,8 +834,53 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, OUT* __restrict_
 }
 
 // y[o] = epilogue( sum_s partial[s][o] )   (fixed order => deterministic), o = ((b*Ho+oh)*Wo+ow)*N + n
+__device__ __forceinline__ float splitk_finish(const ConvKParams& p, float v, long o, int n, int b, int oh, int ow) {
+    if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)b * p.N + n];
+    if (p.flags & STYLEX_EPI_BIAS) v += p.bias[n];
+    if (p.flags & STYLEX_EPI_NOISE)
+        v += p.noise[((long)b * p.noise_stride + ow) * p.noise_stride + oh] * p.noise_w[n] + p.noise_b[n];
+    if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
+    if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
+    return v;
+}
+
+// VEC: N % 4 == 0 and M*N < 2^31 — four consecutive channels per thread (16-byte partial loads, one 32-bit division
+// per quad, and the (b, oh, ow) decomposition only when a per-image scale or the noise plane asks for it); the
+// element-at-a-time 64-bit form paid three 64-bit divisions per output.
+template <bool VEC>
 __global__ void splitk_epilogue_kernel(ConvKParams p) {
     const long total = (long)p.M * p.N;
+    if (VEC) {
+        const int tot = (int)total, N = p.N, hw = p.Ho * p.Wo;
+        const bool need_pix = p.flags & (STYLEX_EPI_OSCALE | STYLEX_EPI_NOISE);
+        for (int o = (blockIdx.x * blockDim.x + threadIdx.x) * 4; o < tot; o += gridDim.x * blockDim.x * 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < p.ksplit; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(p.partial + (long)s * total + o);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const int pix = o / N, n = o - pix * N;
+            int b = 0, oh = 0, ow = 0;
+            if (need_pix) {
+                b = pix / hw;
+                const int q = pix - b * hw;
+                oh = q / p.Wo;
+                ow = q - oh * p.Wo;
+            }
+            float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = splitk_finish(p, r[e], (long)o + e, n + e, b, oh, ow);
+            if (p.act_bf16) {
+                uint2 h;
+                h.x = pack_bf16(r[0], r[1]);
+                h.y = pack_bf16(r[2], r[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + o) = h;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+        return;
+    }
     for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int s = 0; s < p.ksplit; ++s) v += p.partial[(long)s * total + o];
@@ -845,13 +890,7 @@ __global__ void splitk_epilogue_kernel(ConvKParams p) {
         int b = (int)(pix / hw);
         int q = (int)(pix - (long)b * hw);
         int oh = q / p.Wo, ow = q - oh * p.Wo;
-        if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)b * p.N + n];
-        if (p.flags & STYLEX_EPI_BIAS) v += p.bias[n];
-        if (p.flags & STYLEX_EPI_NOISE)
-            v += p.noise[((long)b * p.noise_stride + ow) * p.noise_stride + oh] * p.noise_w[n] + p.noise_b[n];
-        if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
-        if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
-        act_st1(p.y, o, v, p.act_bf16);
+        act_st1(p.y, o, splitk_finish(p, v, o, n, b, oh, ow), p.act_bf16);
     }
 }
 
@@ -1036,9 +1075,14 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
     }
     if (rc || p.ksplit <= 1) return rc;
     long total = (long)p.M * p.N;
-    int blocks = (int)((total + 255) / 256);
+    const bool vec4 = p.N % 4 == 0 && total < (1L << 31) && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0;
+    int blocks = (int)(((vec4 ? total / 4 : total) + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
+    if (vec4)
+        hipLaunchKernelGGL(splitk_epilogue_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(splitk_epilogue_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
 
