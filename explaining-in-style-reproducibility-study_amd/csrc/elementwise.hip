@@ -79,16 +79,34 @@ __device__ __forceinline__ float up_coef(int o, int i, int n) {
     return (lo == i ? 1.f - wh : 0.f) + (hi == i ? wh : 0.f);
 }
 
+// i = ((b * Hd + h) * Wd + w) * cv + cq  ->  (cq, w, h, b); returns the pixel index i / cv.  32-bit divisions whenever
+// the flat index fits (always, for the StylEx shapes): a 64-bit division by a run-time value is ~100 VALU instructions
+// and the five of them per 16-byte vector made the resampling kernels issue-bound, not HBM-bound.
+__device__ __forceinline__ long decomp_index(long i, int cv, int Wd, int Hd, int& cq, int& w, int& h, int& b) {
+    if (i < (1L << 31)) {
+        const unsigned u = (unsigned)i, pix = u / (unsigned)cv, r = pix / (unsigned)Wd;
+        cq = (int)(u - pix * (unsigned)cv);
+        w = (int)(pix - r * (unsigned)Wd);
+        b = (int)(r / (unsigned)Hd);
+        h = (int)(r - (unsigned)b * (unsigned)Hd);
+        return (long)pix;
+    }
+    const long pix = i / cv, r = pix / Wd;
+    cq = (int)(i - pix * cv);
+    w = (int)(pix - r * Wd);
+    b = (int)(r / Hd);
+    h = (int)(r - (long)b * Hd);
+    return pix;
+}
+
 template <int V>
 __global__ void upsample2x_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int H, int W, int C, int bf) {
     const int cv = C / V;
     const long total = (long)B * 2 * H * 2 * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
-        int ow = (int)(pix % (2 * W));
-        int oh = (int)((pix / (2 * W)) % (2 * H));
-        int b = (int)(pix / ((long)4 * H * W));
+        int cq, ow, oh, b;
+        const long pix = decomp_index(i, cv, (2 * W), (2 * H), cq, ow, oh, b);
+        const int c = cq * V;
         int hl, hh, wl, wh_;
         float fh, fw;
         up_rule(oh, H, hl, hh, fh);
@@ -112,11 +130,9 @@ __global__ void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restr
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
-        int iw = (int)(pix % W);
-        int ih = (int)((pix / W) % H);
-        int b = (int)(pix / ((long)H * W));
+        int cq, iw, ih, b;
+        const long pix = decomp_index(i, cv, W, H, cq, iw, ih, b);
+        const int c = cq * V;
         const long base = (long)b * 4 * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
 #pragma unroll
@@ -153,11 +169,9 @@ __global__ void blur3x3_fwd_kernel(const void* __restrict__ x, void* __restrict_
     const long total = (long)B * H * W * cv;
     const float f[3] = {1.f, 2.f, 1.f};
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
-        int w = (int)(pix % W);
-        int h = (int)((pix / W) % H);
-        int b = (int)(pix / ((long)H * W));
+        int cq, w, h, b;
+        const long pix = decomp_index(i, cv, W, H, cq, w, h, b);
+        const int c = cq * V;
         const long base = (long)b * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
 #pragma unroll
@@ -188,11 +202,9 @@ __global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
-        int w = (int)(pix % W);
-        int h = (int)((pix / W) % H);
-        int b = (int)(pix / ((long)H * W));
+        int cq, w, h, b;
+        const long pix = decomp_index(i, cv, W, H, cq, w, h, b);
+        const int c = cq * V;
         const long base = (long)b * H * W * C + c;
         typename Vec<V>::T acc = Vec<V>::zero();
 #pragma unroll
@@ -222,11 +234,9 @@ __global__ void subsample2_fwd_kernel(const void* __restrict__ x, void* __restri
     const int cv = C / V, Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
     const long total = (long)B * Ho * Wo * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
-        int ow = (int)(pix % Wo);
-        int oh = (int)((pix / Wo) % Ho);
-        int b = (int)(pix / ((long)Ho * Wo));
+        int cq, ow, oh, b;
+        const long pix = decomp_index(i, cv, Wo, Ho, cq, ow, oh, b);
+        const int c = cq * V;
         Vec<V>::st(y, pix * C + c, Vec<V>::ld(x, (((long)b * H + 2 * oh) * W + 2 * ow) * C + c, bf), bf);
     }
 }
@@ -236,11 +246,9 @@ __global__ void subsample2_bwd_kernel(const void* __restrict__ dy, void* __restr
     const int cv = C / V, Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
-        int w = (int)(pix % W);
-        int h = (int)((pix / W) % H);
-        int b = (int)(pix / ((long)H * W));
+        int cq, w, h, b;
+        const long pix = decomp_index(i, cv, W, H, cq, w, h, b);
+        const int c = cq * V;
         typename Vec<V>::T v = Vec<V>::zero();
         if (!((h | w) & 1)) v = Vec<V>::ld(dy, (((long)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c, bf);
         Vec<V>::st(dx, pix * C + c, v, bf);
@@ -277,12 +285,9 @@ __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short
     const long total = (long)B * strips * W * cv;
     const bool in_s2d = ADJ && s2d, out_s2d = !ADJ && s2d;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * 8;
-        long t = i / cv;
-        const int w = (int)(t % W);
-        t /= W;
-        const int h0 = (int)(t % strips) * ROWS;
-        const int b = (int)(t / strips);
+        int cq, w, hs, b;
+        decomp_index(i, cv, W, strips, cq, w, hs, b);
+        const int c = cq * 8, h0 = hs * ROWS;
         int iw[3];
         float cw[3];
 #pragma unroll
@@ -332,15 +337,11 @@ __global__ void bias_act_fwd_kernel(const void* __restrict__ x, const float* __r
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % cv) * V;
-        long pix = i / cv;
+        int cq, w, h, b;
+        const long pix = decomp_index(i, cv, W, H, cq, w, h, b);
+        const int c = cq * V;
         float nz = 0.f;
-        if (noise) {
-            int w = (int)(pix % W);
-            int h = (int)((pix / W) % H);
-            int b = (int)(pix / ((long)H * W));
-            nz = noise[((long)b * ns + w) * ns + h];  // (sic) spatially transposed, stylex_train.py:696-698
-        }
+        if (noise) nz = noise[((long)b * ns + w) * ns + h];  // (sic) spatially transposed, stylex_train.py:696-698
         float v[V];
         *reinterpret_cast<typename Vec<V>::T*>(v) = Vec<V>::ld(x, pix * C + c, bf);
 #pragma unroll
