@@ -43,14 +43,23 @@ constexpr int TW = 32, TH = 16, HWD = TW + 2, NP = (TH + 2) * HWD;  // 612 halo 
 constexpr int ROW = 32;                                              // bytes per LDS row (16 bf16)
 constexpr int HALO_PIECES = (NP + 31) / 32;                          // 20 DMA pieces of 32 rows
 constexpr int HALO_BYTES = HALO_PIECES * 1024;
-constexpr int BN = 128;
-constexpr int W_PIECES = 9 * BN / 32;                                // 36
-constexpr int W_BYTES = W_PIECES * 1024;
-constexpr int BUF = HALO_BYTES + W_BYTES;                            // 57344
-constexpr int SMEM_BYTES = 2 * BUF;                                  // 112 KiB -> one block per CU
-static_assert(HALO_PIECES + W_PIECES == 56, "the staging loop assumes 14 DMA pieces per wave");
+// TNJ = 32-channel output sub-tiles per wave: 4 -> 128-channel block tile, 256 accumulator registers, 112 KiB of LDS,
+// one block per CU;  2 -> 64-channel tile for the N = 64 layers (64->64 @256^2, the 128->64 data gradient): 128
+// accumulator registers and 76 KiB, two blocks per CU, so one block's prologue / epilogue hides under the other's
+// MFMAs (the register-staged kernel spends ~2000 issue slots per wave and tile on staging and epilogue there).
+template <int TNJ>
+struct DmaCfg {
+    static constexpr int BN = TNJ * 32;
+    static constexpr int W_PIECES = 9 * BN / 32;
+    static constexpr int PIECES = HALO_PIECES + W_PIECES;      // 56 / 38
+    static constexpr int NIT = (PIECES + 3) / 4;               // DMA pieces per wave and chunk: 14 / 10
+    static constexpr int BUF = PIECES * 1024;                  // 57344 / 38912
+    static constexpr int SMEM_BYTES = 2 * BUF;
+};
 
-__global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p) {
+template <int TNJ>
+__global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel(ConvKParams p) {
+    constexpr int BN = DmaCfg<TNJ>::BN, PIECES = DmaCfg<TNJ>::PIECES, NIT = DmaCfg<TNJ>::NIT, BUF = DmaCfg<TNJ>::BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.Ho, W = p.Wo, C = p.Ck, N = p.N;
@@ -79,11 +88,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
     const int slot = pslot ^ ((lr >> 3) & 1);   // logical channel half this lane fetches
 
     // per-wave piece list (same for every chunk): pieces wave, wave+4, ...; global element offsets without the chunk term
-    long src_off[14];
-    bool src_ok[14];
+    long src_off[NIT];
+    bool src_ok[NIT];
 #pragma unroll
-    for (int it = 0; it < 14; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int piece = wave + 4 * it;
+        src_off[it] = 0;
+        src_ok[it] = false;
+        if (piece >= PIECES) continue;  // 38 pieces: waves 2 and 3 have nine
         if (piece < HALO_PIECES) {
             const int hp = piece * 32 + lr;
             const int hh = hp / HWD, ww = hp - hh * HWD;
@@ -91,8 +103,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
             src_ok[it] = hp < NP && y >= 0 && y < H && x >= 0 && x < W;
             src_off[it] = ((long)(b * H + y) * W + x) * C + slot * 8;
         } else {
-            const int r = (piece - HALO_PIECES) * 32 + lr;  // weight row = tap * 128 + n
-            const int tap = r >> 7, nl = r & 127;
+            const int r = (piece - HALO_PIECES) * 32 + lr;  // weight row = tap * BN + n
+            const int tap = r / BN, nl = r - tap * BN;
             const int gt = p.flip_taps ? 8 - tap : tap;
             src_ok[it] = n0 + nl < N;
             src_off[it] = ((long)(n0 + nl) * 9 + gt) * C + slot * 8;
@@ -103,20 +115,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
         char* base = smem + buf * BUF;
         const bool cok = c0 + slot * 8 < C;
         const int piece = wave + 4 * it;
+        if (piece >= PIECES) return;
         const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + src_off[it] + c0;
         const unsigned short* src = (src_ok[it] && cok) ? g : zero;
         __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
     };
     auto issue = [&](int c0, int buf) {
 #pragma unroll
-        for (int it = 0; it < 14; ++it) issue_piece(c0, buf, it);
+        for (int it = 0; it < NIT; ++it) issue_piece(c0, buf, it);
     };
 
-    f32x16 acc[4][4];
+    f32x16 acc[4][TNJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TNJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
             const int t = a_row + r * HWD + kw;
             a_off[r][kw] = (t * ROW) | ((((t >> 3) ^ lk) & 1) << 4);
         }
-    // weight rows tap*128 + j*32 + li: the tap / j terms are multiples of 16 rows, so bit3(row) = bit3(li)
+    // weight rows tap*BN + j*32 + li: the tap / j terms are multiples of 16 rows, so bit3(row) = bit3(li)
     const int b_lane = HALO_BYTES + li * ROW + ((((li >> 3) ^ lk) & 1) << 4);  // + (tap*128 + j*32)*ROW
 
     const int nchunks = (C + 15) / 16;
@@ -145,23 +158,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - kh * 3;
-            bf16x8 av[4], bv[4];
+            bf16x8 av[4], bv[TNJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 av[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i + kh][kw]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TNJ; ++j)
                 bv[j] = *reinterpret_cast<const bf16x8*>(base + b_lane + (tap * BN + j * 32) * ROW);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TNJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
             // the next chunk's 14 DMA pieces are issued two per tap, in the shadow of this tap's 16 MFMAs (a burst at
             // the top of the chunk leaves the MFMA pipe empty while it is issued)
-            if (more && tap < 7) {
+            if (more && 2 * tap < NIT) {
                 issue_piece((ch + 1) * 16, buf ^ 1, 2 * tap);
-                issue_piece((ch + 1) * 16, buf ^ 1, 2 * tap + 1);
+                if (2 * tap + 1 < NIT) issue_piece((ch + 1) * 16, buf ^ 1, 2 * tap + 1);
             }
         }
     }
@@ -170,13 +183,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
     // ---- epilogue: per row-tile i the wave's 32 px x 128 n block goes through LDS (8 KiB per wave) and leaves as
     // 16-byte row stores (a pixel's 128 channels = 256 contiguous bytes).  D[row = pixel][col = channel]:
     // col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    char* scratch = smem + wave * 8192;
+    char* scratch = smem + wave * (32 * BN * 2);
     const int lj = lane & 31, lh = lane >> 5;
     const bool act = (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) != 0;
     const float slope = (p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f;
-    float bias[4];
+    float bias[TNJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TNJ; ++j) {
         const int n = n0 + j * 32 + lj;
         bias[j] = ((p.flags & STYLEX_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
     }
@@ -184,23 +197,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TNJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[i][j][r] + bias[j];
                 if (act) v = v > 0.f ? v : slope * v;
-                *reinterpret_cast<unsigned short*>(scratch + px * 256 + (j * 32 + lj) * 2) = to_bf16(v);
+                *reinterpret_cast<unsigned short*>(scratch + px * (BN * 2) + (j * 32 + lj) * 2) = to_bf16(v);
             }
         // wave-private scratch: LDS operations of one wave are ordered, no barrier needed
         const int y = y0 + 4 * wave + i;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int id = lane + 64 * k;           // 512 slots of 16 B = 32 px x 16 slots
-            const int px = id >> 4, q = id & 15;
+        for (int k = 0; k < BN / 16; ++k) {
+            const int id = lane + 64 * k;           // 32 px x (BN / 8) slots of 16 B
+            const int px = id / (BN / 8), q = id % (BN / 8);
             const int x = x0 + px, n = n0 + q * 8;
             if (y < H && x < W && n < N) {
-                const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * 256 + q * 16);
+                const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * (BN * 2) + q * 16);
                 *reinterpret_cast<uint4*>(yout + ((long)(b * H + y) * W + x) * N + n) = v;
             }
         }
@@ -210,26 +223,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_dma_kernel(ConvKParams p)
 }  // namespace
 
 // STYLEX_NOT_APPLICABLE unless: bf16 activations, plain 3x3/s1/p1, no per-sample scales / noise / residual /
-// space-to-depth, >= 128 output and input channels (64 input channels = 4 chunks measured 7 % slower than the
-// register-staged kernel) in whole 8-channel slots, at least one 16x32 tile's worth of image.
-int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
-    static const bool on = !(getenv("STYLEX_HALO_DMA") && getenv("STYLEX_HALO_DMA")[0] == '0');
-    if (!on) return STYLEX_NOT_APPLICABLE;
-    if (!p.act_bf16 || p.s2d_c || p.a_scale) return STYLEX_NOT_APPLICABLE;
-    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) return STYLEX_NOT_APPLICABLE;
-    if (p.N < 128 || p.N % 8 != 0 || p.Ck % 8 != 0 || p.Ck < 128 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
-    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
-        (reinterpret_cast<uintptr_t>(p.y) & 15))
-        return STYLEX_NOT_APPLICABLE;
+// space-to-depth, whole 8-channel slots, at least one 16x32 tile's worth of image, >= 64 input channels, and an
+// output width that is a multiple of 64 (64-channel tiles) or >= 128 with >= 128 input channels (128-channel tiles).
+template <int TNJ>
+static int launch_dma(const ConvKParams& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_dma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_dma_kernel<TNJ>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<TNJ>::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
-    long blocks = tiles * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(conv3x3_halo_dma_kernel, dim3((unsigned)blocks), dim3(256), SMEM_BYTES, s, p);
+    long blocks = tiles * ((p.N + DmaCfg<TNJ>::BN - 1) / DmaCfg<TNJ>::BN);
+    hipLaunchKernelGGL(conv3x3_halo_dma_kernel<TNJ>, dim3((unsigned)blocks), dim3(256), DmaCfg<TNJ>::SMEM_BYTES, s, p);
     return (int)hipGetLastError();
+}
+
+int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
+    static const bool on = !(getenv("STYLEX_HALO_DMA") && getenv("STYLEX_HALO_DMA")[0] == '0');
+    static const bool on64 = !(getenv("STYLEX_HALO_DMA64") && getenv("STYLEX_HALO_DMA64")[0] == '0');
+    if (!on) return STYLEX_NOT_APPLICABLE;
+    if (!p.act_bf16 || p.s2d_c || p.a_scale) return STYLEX_NOT_APPLICABLE;
+    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) return STYLEX_NOT_APPLICABLE;
+    if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
+        (reinterpret_cast<uintptr_t>(p.y) & 15))
+        return STYLEX_NOT_APPLICABLE;
+    // Measured at B = 64 (fwd / dgrad ms, 128-channel tiles at one block per CU -> 64-channel tiles at two):
+    // 128->128 @128^2 .361/.351 -> .313/.311, 128->256 @64^2 .176 -> .149, 256->256 @64^2 .284/.281 -> .264/.273,
+    // 512->512 @32^2 .259/.264 -> .257/.263, 64->64 @256^2 (register-staged kernel) .430/.425 -> .377/.384: the second
+    // resident block hides more than the wider tile saves in LDS reads, so the 64-channel variant is the default and
+    // the 128-channel one serves output widths that are not a multiple of 64.
+    if (on64 && p.Ck >= 64 && p.N % 64 == 0) return launch_dma<2>(p, s);
+    if (p.N >= 128 && p.Ck >= 128) return launch_dma<4>(p, s);
+    return STYLEX_NOT_APPLICABLE;
 }

@@ -72,6 +72,9 @@ CONV_CASES = [
     (2, 128, 128, 32, 32, 3, 1, 1),   # bf16: LDS-DMA halo kernel (16x32 px x 128 n tiles), whole tiles
     (1, 136, 160, 20, 40, 3, 1, 1),   # bf16: LDS-DMA kernel, ragged: 8-channel tail, partial N tile, partial pixel tiles
     (1, 128, 256, 16, 32, 3, 1, 1),   # bf16: LDS-DMA kernel, one pixel tile, two N tiles
+    (1, 128, 160, 16, 40, 3, 1, 1),   # bf16: LDS-DMA kernel with 128-channel tiles (N not a multiple of 64), ragged N
+    (2, 64, 64, 24, 64, 3, 1, 1),     # bf16: LDS-DMA kernel with 64-channel tiles (two blocks per CU), ragged rows
+    (1, 128, 64, 16, 40, 3, 1, 1),    # bf16: 64-channel tiles, 8 chunks, ragged columns (the 128->64 data gradient)
 ]
 
 
@@ -246,12 +249,14 @@ def test_conv_bias_lrelu_and_second_order():
         close(a, b, 2e-4, "second-order grad " + nm)
 
 
-def test_dma_halo_kernel_bias_lrelu_epilogue():
-    """The LDS-DMA forward kernel's own epilogue (bias + LeakyReLU / ReLU) and its use as data gradient."""
+@pytest.mark.parametrize("cn", [(128, 256), (64, 64), (128, 160)])
+def test_dma_halo_kernel_bias_lrelu_epilogue(cn):
+    """The LDS-DMA forward kernel's own epilogue (bias + LeakyReLU / ReLU) and its use as data gradient, for the
+    64-channel tile variant (N % 64 == 0) and the 128-channel one (N = 160)."""
     ops.set_precision("bf16")
     try:
         g = torch.Generator().manual_seed(21)
-        B, C, N, H, W = 2, 128, 256, 24, 64
+        B, (C, N), H, W = 2, cn, 24, 64
         x = torch.randn(B, C, H, W, generator=g)
         w = torch.randn(N, C, 3, 3, generator=g) / (C * 9) ** 0.5
         b = torch.randn(N, generator=g)
