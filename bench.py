@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--classifier", default="resnet")
     ap.add_argument("--workdir", default="/tmp/stylex_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="keep MIOpen in immediate mode for the frozen classifier / LPIPS (the reference's cli.py setting)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--roofline-steps", type=int, default=4)
@@ -145,6 +147,11 @@ def main():
 
     hb.load_library()  # no fallback: fail loudly if the extension is missing
     ops.set_precision(args.precision)
+    # The frozen classifier / LPIPS convolutions run on stock MIOpen.  On a fresh box its immediate mode picks slower
+    # kernels than a search does (measured on one box: 641 images/s cold, 682 after one search had filled the user
+    # find-db); let the untimed warm-up steps do that search (cudnn.benchmark), as any training job on a warm machine
+    # would have.  ~60 s of extra warm-up.  The Trainer itself keeps the reference's setting (benchmark off).
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
     tr = build_trainer(args, device, rank, world)
 
     def sync():
@@ -233,7 +240,9 @@ def main():
                                    "4th step, ResNet-18 classifier" % args.gae,
                        "image_size": args.image_size, "batch_per_gpu": args.batch,
                        "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "frozen_nets": "stock MIOpen fp32, algorithms searched during the warm-up steps"
+                                      if not args.no_miopen_find else "stock MIOpen fp32, immediate mode"},
             "algorithmic_conv_gflop_per_image": round(gf, 1),
             "step_conv_tflops": round(gf * value / 1e3, 2),
             "roofline": roof, "cpu_baseline": cpu,

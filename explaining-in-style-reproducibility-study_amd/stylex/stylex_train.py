@@ -483,6 +483,8 @@ class Trainer:
             # noise source of a step is MIOpen's default algorithm choice for the frozen classifier / LPIPS.  Pinning
             # it makes a whole training run reproducible for about 1 % of step throughput.
             torch.backends.cudnn.deterministic = True
+        if os.environ.get("STYLEX_MIOPEN_BENCHMARK") == "1":  # experiment: let MIOpen search its algorithms
+            torch.backends.cudnn.benchmark = True
         self.save_training_state = save_training_state
         self.device = _dev(device if device is not None else rank)
         self.lpips_fn = lpips_fn
