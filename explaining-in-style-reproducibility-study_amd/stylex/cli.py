@@ -54,7 +54,10 @@ def timestamped_filename(prefix="generated-"):
 
 
 def set_seed(seed):
+    """reference cli.py:35-40: a seeded run also pins the (MIOpen) convolution algorithms of the frozen networks."""
     torch.manual_seed(seed)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
     np.random.seed(seed)
     random.seed(seed)
 
