@@ -4,6 +4,7 @@ This is the only place the Python host touches native code.  There is NO
 fallback: if the shared library is missing or a kernel returns an error the
 call raises.  PyTorch is used for device memory and the current HIP stream only.
 """
+import atexit
 import ctypes
 import os
 import weakref
@@ -180,6 +181,20 @@ _PACK_CACHE_MAX = 512
 
 def pack_cache_clear():
     _PACK_CACHE.clear()
+
+
+def _release_at_exit():
+    """Cached packs carry HIP events; dropping them while the interpreter tears modules down (after the HIP runtime
+    has started its own shutdown) is a classic source of crashes at exit — release them first, in order."""
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:  # noqa: BLE001
+        pass
+    _PACK_CACHE.clear()
+
+
+atexit.register(_release_at_exit)
 
 
 def _cache_hit(key, w):

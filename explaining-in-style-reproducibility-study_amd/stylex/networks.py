@@ -11,6 +11,7 @@ Differences by design: activations are kept NHWC (channels_last) end to end;
 ``Conv2DMod`` never materialises per-sample weights (ops.modulated_conv2d);
 bias+LeakyReLU, blur and bilinear x2 are single fused kernels.
 """
+import atexit
 import math
 from math import log2
 
@@ -28,6 +29,7 @@ def exists(v):
 
 
 _SIDE = {}
+atexit.register(_SIDE.clear)  # streams are released before the interpreter (and the HIP runtime) shut down
 
 
 def _side_stream(t, which=0):

@@ -16,6 +16,7 @@ AttFind notebook imports.  New, MI355X-first behaviour:
     gradient buckets (``parallel.py``), including the encoder the reference forgot
     to wrap (:1188-1193).
 """
+import atexit
 import json
 import math
 import multiprocessing
@@ -122,6 +123,19 @@ class _Staging:
         slot[1] = torch.cuda.Event()
         slot[1].record()
         return out
+
+
+def _release_staging_at_exit():
+    """Pinned buffers and their events are freed before interpreter teardown (see hip_backend._release_at_exit)."""
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:  # noqa: BLE001
+        pass
+    _Staging._slots.clear()
+
+
+atexit.register(_release_staging_at_exit)
 
 
 def noise(n, latent_dim, device):  # reference :319-320 — CPU RNG, then copy (keeps the draw order)
