@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "stylex_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -57,7 +59,37 @@ struct DmaCfg {
     static constexpr int SMEM_BYTES = 2 * BUF;
 };
 
-template <int TNJ>
+// One 16-channel chunk of MFMAs for the spatial taps in MASK; the chunk's weights are staged compactly, slot = rank of
+// the tap within MASK (space-to-depth data gradient: 1, 2 or 4 of the 9 taps exist for an output sub-position).
+template <int TNJ, unsigned MASK>
+__device__ __forceinline__ void dma_chunk_masked(const char* base, const int (&a_off)[6][3], int b_lane,
+                                                 f32x16 (&acc)[4][TNJ]) {
+    constexpr int BN = TNJ * 32;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (!((MASK >> tap) & 1u)) continue;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int slot = __builtin_popcount(MASK & ((1u << tap) - 1u));
+        bf16x8 av[4], bv[TNJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i + kh][kw]);
+#pragma unroll
+        for (int j = 0; j < TNJ; ++j)
+            bv[j] = *reinterpret_cast<const bf16x8*>(base + b_lane + (slot * BN + j * 32) * ROW);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TNJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// spatial taps of the space-to-depth DATA GRADIENT per output sub-position q = (sy, sx): weight tap 8 - t must be one
+// of the structurally non-zero taps of stylex_s2d_tap_mask(q)
+constexpr unsigned S2D_DGRAD_MASK[4] = {1u << 4, (1u << 4) | (1u << 5), (1u << 4) | (1u << 7),
+                                        (1u << 4) | (1u << 5) | (1u << 7) | (1u << 8)};
+
+template <int TNJ, bool S2D = false>
 __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel(ConvKParams p) {
     constexpr int BN = DmaCfg<TNJ>::BN, PIECES = DmaCfg<TNJ>::PIECES, NIT = DmaCfg<TNJ>::NIT, BUF = DmaCfg<TNJ>::BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,10 +135,19 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
             src_ok[it] = hp < NP && y >= 0 && y < H && x >= 0 && x < W;
             src_off[it] = ((long)(b * H + y) * W + x) * C + slot * 8;
         } else {
-            const int r = (piece - HALO_PIECES) * 32 + lr;  // weight row = tap * BN + n
-            const int tap = r / BN, nl = r - tap * BN;
+            const int r = (piece - HALO_PIECES) * 32 + lr;  // weight row = tap (S2D: tap slot) * BN + n
+            int tap = r / BN;
+            const int nl = r - tap * BN;
+            bool tap_ok = true;
+            if (S2D) {  // slot -> the slot-th spatial tap of this block's sub-position
+                const unsigned m = S2D_DGRAD_MASK[n0 / p.s2d_c];
+                tap_ok = tap < __builtin_popcount(m);
+                unsigned mm = m;
+                for (int k = 0; k < tap; ++k) mm &= mm - 1;  // drop the lowest set bits
+                tap = tap_ok ? __builtin_ctz(mm) : 0;
+            }
             const int gt = p.flip_taps ? 8 - tap : tap;
-            src_ok[it] = n0 + nl < N;
+            src_ok[it] = tap_ok && n0 + nl < N;
             src_off[it] = ((long)(n0 + nl) * 9 + gt) * C + slot * 8;
         }
     }
@@ -116,6 +157,7 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         const bool cok = c0 + slot * 8 < C;
         const int piece = wave + 4 * it;
         if (piece >= PIECES) return;
+        if (S2D && piece >= HALO_PIECES + 4 * TNJ) return;  // at most 4 tap slots are ever staged
         const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + src_off[it] + c0;
         const unsigned short* src = (src_ok[it] && cok) ? g : zero;
         __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
@@ -150,6 +192,25 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
     const int nchunks = (C + 15) / 16;
     issue(0, 0);
     int buf = 0;
+    if (S2D) {
+        // the tap set is uniform per block (output sub-position of its channel tile): one copy of the whole chunk loop
+        // per set (a switch inside the loop made the 128 accumulator registers a four-way phi and spilled them)
+        auto run = [&](auto mask_tag) {
+            constexpr unsigned MASK = decltype(mask_tag)::value;
+            for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (ch + 1 < nchunks) issue((ch + 1) * 16, buf ^ 1);
+                dma_chunk_masked<TNJ, MASK>(smem + buf * BUF, a_off, b_lane, acc);
+            }
+        };
+        switch (n0 / p.s2d_c) {
+            case 0: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[0]>{}); break;
+            case 1: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[1]>{}); break;
+            case 2: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[2]>{}); break;
+            default: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[3]>{}); break;
+        }
+    } else
     for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -225,31 +286,38 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
 // STYLEX_NOT_APPLICABLE unless: bf16 activations, plain 3x3/s1/p1, no per-sample scales / noise / residual /
 // space-to-depth, whole 8-channel slots, at least one 16x32 tile's worth of image, >= 64 input channels, and an
 // output width that is a multiple of 64 (64-channel tiles) or >= 128 with >= 128 input channels (128-channel tiles).
-template <int TNJ>
+template <int TNJ, bool S2D = false>
 static int launch_dma(const ConvKParams& p, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_dma_kernel<TNJ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_dma_kernel<TNJ, S2D>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<TNJ>::SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
     long blocks = tiles * ((p.N + DmaCfg<TNJ>::BN - 1) / DmaCfg<TNJ>::BN);
-    hipLaunchKernelGGL(conv3x3_halo_dma_kernel<TNJ>, dim3((unsigned)blocks), dim3(256), DmaCfg<TNJ>::SMEM_BYTES, s, p);
+    hipLaunchKernelGGL((conv3x3_halo_dma_kernel<TNJ, S2D>), dim3((unsigned)blocks), dim3(256), DmaCfg<TNJ>::SMEM_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
 int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
     static const bool on = !(getenv("STYLEX_HALO_DMA") && getenv("STYLEX_HALO_DMA")[0] == '0');
     static const bool on64 = !(getenv("STYLEX_HALO_DMA64") && getenv("STYLEX_HALO_DMA64")[0] == '0');
+    static const bool on_s2d = !(getenv("STYLEX_HALO_DMA_S2D") && getenv("STYLEX_HALO_DMA_S2D")[0] == '0');
     if (!on) return STYLEX_NOT_APPLICABLE;
-    if (!p.act_bf16 || p.s2d_c || p.a_scale) return STYLEX_NOT_APPLICABLE;
+    if (!p.act_bf16 || p.a_scale) return STYLEX_NOT_APPLICABLE;
     if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) return STYLEX_NOT_APPLICABLE;
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
         (reinterpret_cast<uintptr_t>(p.y) & 15))
         return STYLEX_NOT_APPLICABLE;
+    if (p.s2d_c) {
+        // space-to-depth stride-2 conv: only its data gradient (tap set uniform per output-channel tile, no epilogue)
+        if (!on_s2d || !on64 || !p.flip_taps || p.flags || p.s2d_c % 64 != 0 || p.N != 4 * p.s2d_c || p.Ck < 64)
+            return STYLEX_NOT_APPLICABLE;
+        return launch_dma<2, true>(p, s);
+    }
     // Measured at B = 64 (fwd / dgrad ms, 128-channel tiles at one block per CU -> 64-channel tiles at two):
     // 128->128 @128^2 .361/.351 -> .313/.311, 128->256 @64^2 .176 -> .149, 256->256 @64^2 .284/.281 -> .264/.273,
     // 512->512 @32^2 .259/.264 -> .257/.263, 64->64 @256^2 (register-staged kernel) .430/.425 -> .377/.384: the second

@@ -179,16 +179,19 @@ def test_fast_fused_path_matches_differentiable_path(prec):
         close(a, b_, tol * 5, "fast grad " + nm)
 
 
-def test_s2d_downsample_path_matches_strided_conv():
+@pytest.mark.parametrize("shape", [(2, 64, 128, 64, 64), (1, 128, 64, 48, 80), (2, 64, 64, 32, 32)])
+def test_s2d_downsample_path_matches_strided_conv(shape):
     """blur -> space-to-depth -> 3x3/s1 halo conv with skipped zero taps == blur -> 3x3/s2 conv (+bias+res)*c,
-    outputs and all gradients (bf16 mode: this path only exists on the bf16 kernels)."""
+    outputs and all gradients (bf16 mode: this path only exists on the bf16 kernels).  The first two shapes send the
+    data gradient through the LDS-DMA kernel's space-to-depth mode (>= 16x32 half-resolution image; the second with
+    ragged tiles), the third keeps it on the register-staged kernel."""
     ops.set_precision("bf16")
     g = torch.Generator().manual_seed(8)
-    B, C, N, H = 2, 64, 128, 64
-    x0 = torch.randn(B, C, H, H, generator=g)
+    B, C, N, H, W = shape
+    x0 = torch.randn(B, C, H, W, generator=g)
     w0 = torch.randn(N, C, 3, 3, generator=g) / 24
     b0 = torch.randn(N, generator=g)
-    r0 = torch.randn(B, N, H // 2, H // 2, generator=g)
+    r0 = torch.randn(B, N, H // 2, W // 2, generator=g)
 
     def run(fast):
         prev = ops.set_fast(fast)
