@@ -89,6 +89,13 @@ __device__ __forceinline__ void dma_chunk_masked(const char* base, const int (&a
 constexpr unsigned S2D_DGRAD_MASK[4] = {1u << 4, (1u << 4) | (1u << 5), (1u << 4) | (1u << 7),
                                         (1u << 4) | (1u << 5) | (1u << 7) | (1u << 8)};
 
+// FORWARD of the space-to-depth conv: the tap set depends on the sub-position q of the INPUT-channel chunk
+// (stylex_s2d_tap_mask(q)); taps listed low to high as nibbles for the staging slot -> tap lookup.
+constexpr unsigned S2D_FWD_MASK[4] = {1u << 4, (1u << 3) | (1u << 4), (1u << 1) | (1u << 4),
+                                      (1u << 0) | (1u << 1) | (1u << 3) | (1u << 4)};
+__device__ __forceinline__ int s2d_fwd_taps(int q) { return q == 0 ? 0x4 : q == 1 ? 0x43 : q == 2 ? 0x41 : 0x4310; }
+__device__ __forceinline__ int s2d_fwd_ntaps(int q) { return q == 0 ? 1 : q == 3 ? 4 : 2; }
+
 template <int TNJ, bool S2D = false>
 __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel(ConvKParams p) {
     constexpr int BN = DmaCfg<TNJ>::BN, PIECES = DmaCfg<TNJ>::PIECES, NIT = DmaCfg<TNJ>::NIT, BUF = DmaCfg<TNJ>::BUF;
@@ -122,11 +129,13 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
     // per-wave piece list (same for every chunk): pieces wave, wave+4, ...; global element offsets without the chunk term
     long src_off[NIT];
     bool src_ok[NIT];
+    int wslot[NIT];  // weight pieces: tap slot of the row this lane stages (S2D forward)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int piece = wave + 4 * it;
         src_off[it] = 0;
         src_ok[it] = false;
+        wslot[it] = 0;
         if (piece >= PIECES) continue;  // 38 pieces: waves 2 and 3 have nine
         if (piece < HALO_PIECES) {
             const int hp = piece * 32 + lr;
@@ -139,7 +148,10 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
             int tap = r / BN;
             const int nl = r - tap * BN;
             bool tap_ok = true;
-            if (S2D) {  // slot -> the slot-th spatial tap of this block's sub-position
+            wslot[it] = tap;
+            if (S2D && !p.flip_taps) {  // forward: the tap of a slot changes with the chunk's sub-position (added at issue time)
+                tap = 0;
+            } else if (S2D) {  // data gradient: slot -> the slot-th spatial tap of this block's sub-position
                 const unsigned m = S2D_DGRAD_MASK[n0 / p.s2d_c];
                 tap_ok = tap < __builtin_popcount(m);
                 unsigned mm = m;
@@ -158,8 +170,15 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         const int piece = wave + 4 * it;
         if (piece >= PIECES) return;
         if (S2D && piece >= HALO_PIECES + 4 * TNJ) return;  // at most 4 tap slots are ever staged
-        const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + src_off[it] + c0;
-        const unsigned short* src = (src_ok[it] && cok) ? g : zero;
+        long off = src_off[it] + c0;
+        bool ok = src_ok[it] && cok;
+        if (S2D && !p.flip_taps && piece >= HALO_PIECES) {
+            const int qn = c0 / p.s2d_c;
+            ok = ok && wslot[it] < s2d_fwd_ntaps(qn);
+            off += (long)((s2d_fwd_taps(qn) >> (4 * wslot[it])) & 0xF) * C;
+        }
+        const unsigned short* g = (piece < HALO_PIECES ? xs : ws) + off;
+        const unsigned short* src = ok ? g : zero;
         __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
     };
     auto issue = [&](int c0, int buf) {
@@ -195,20 +214,28 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
     if (S2D) {
         // the tap set is uniform per block (output sub-position of its channel tile): one copy of the whole chunk loop
         // per set (a switch inside the loop made the 128 accumulator registers a four-way phi and spilled them)
-        auto run = [&](auto mask_tag) {
+        auto run = [&](auto mask_tag, int ch_begin, int ch_end) {
             constexpr unsigned MASK = decltype(mask_tag)::value;
-            for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
+            for (int ch = ch_begin; ch < ch_end; ++ch, buf ^= 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (ch + 1 < nchunks) issue((ch + 1) * 16, buf ^ 1);
                 dma_chunk_masked<TNJ, MASK>(smem + buf * BUF, a_off, b_lane, acc);
             }
         };
-        switch (n0 / p.s2d_c) {
-            case 0: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[0]>{}); break;
-            case 1: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[1]>{}); break;
-            case 2: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[2]>{}); break;
-            default: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[3]>{}); break;
+        if (p.flip_taps) {
+            switch (n0 / p.s2d_c) {
+                case 0: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[0]>{}, 0, nchunks); break;
+                case 1: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[1]>{}, 0, nchunks); break;
+                case 2: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[2]>{}, 0, nchunks); break;
+                default: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[3]>{}, 0, nchunks); break;
+            }
+        } else {  // forward: the four input sub-positions one after the other, each with its own tap set
+            const int cpq = p.s2d_c / 16;
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[0]>{}, 0, cpq);
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[1]>{}, cpq, 2 * cpq);
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[2]>{}, 2 * cpq, 3 * cpq);
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[3]>{}, 3 * cpq, 4 * cpq);
         }
     } else
     for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
@@ -255,6 +282,45 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         bias[j] = ((p.flags & STYLEX_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
     }
     unsigned short* yout = reinterpret_cast<unsigned short*>(p.y);
+    if (S2D && (p.flags & STYLEX_EPI_RESIDUAL)) {
+        // block merge of DiscriminatorBlock (:743): (conv + bias + residual) * res_scale, evaluated in fp32 exactly as the
+        // register-staged kernel does — the transpose scratch holds fp32 here (32 px x BN x 4 B per wave)
+        char* fscr = smem + wave * (32 * BN * 4);
+        const unsigned short* res = reinterpret_cast<const unsigned short*>(p.residual);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < TNJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    *reinterpret_cast<float*>(fscr + px * (BN * 4) + (j * 32 + lj) * 4) = acc[i][j][r] + bias[j];
+                }
+            const int y = y0 + 4 * wave + i;
+#pragma unroll
+            for (int k = 0; k < BN / 16; ++k) {
+                const int id = lane + 64 * k;
+                const int px = id / (BN / 8), q = id % (BN / 8);
+                const int x = x0 + px, n = n0 + q * 8;
+                if (y < H && x < W && n < N) {
+                    const long o = ((long)(b * H + y) * W + x) * N + n;
+                    const float4 f0 = *reinterpret_cast<const float4*>(fscr + px * (BN * 4) + q * 32);
+                    const float4 f1 = *reinterpret_cast<const float4*>(fscr + px * (BN * 4) + q * 32 + 16);
+                    const uint4 rv = *reinterpret_cast<const uint4*>(res + o);
+                    const float sc = p.res_scale;
+                    auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+                    auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+                    uint4 out;
+                    out.x = to_bf16((f0.x + lo(rv.x)) * sc) | ((unsigned)to_bf16((f0.y + hi(rv.x)) * sc) << 16);
+                    out.y = to_bf16((f0.z + lo(rv.y)) * sc) | ((unsigned)to_bf16((f0.w + hi(rv.y)) * sc) << 16);
+                    out.z = to_bf16((f1.x + lo(rv.z)) * sc) | ((unsigned)to_bf16((f1.y + hi(rv.z)) * sc) << 16);
+                    out.w = to_bf16((f1.z + lo(rv.w)) * sc) | ((unsigned)to_bf16((f1.w + hi(rv.w)) * sc) << 16);
+                    *reinterpret_cast<uint4*>(yout + o) = out;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -313,9 +379,18 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
         (reinterpret_cast<uintptr_t>(p.y) & 15))
         return STYLEX_NOT_APPLICABLE;
     if (p.s2d_c) {
-        // space-to-depth stride-2 conv: only its data gradient (tap set uniform per output-channel tile, no epilogue)
-        if (!on_s2d || !on64 || !p.flip_taps || p.flags || p.s2d_c % 64 != 0 || p.N != 4 * p.s2d_c || p.Ck < 64)
-            return STYLEX_NOT_APPLICABLE;
+        // space-to-depth stride-2 conv.  Data gradient: tap set uniform per output-channel tile, no epilogue.
+        // Forward: tap set per input sub-position, epilogue bias (+ residual merge).
+        if (!on_s2d || !on64 || p.s2d_c % 64 != 0) return STYLEX_NOT_APPLICABLE;
+        if (p.flip_taps) {
+            if (p.flags || p.N != 4 * p.s2d_c || p.Ck < 64) return STYLEX_NOT_APPLICABLE;
+        } else {
+            static const bool on_fwd = !(getenv("STYLEX_HALO_DMA_S2D_FWD") && getenv("STYLEX_HALO_DMA_S2D_FWD")[0] == '0');
+            if (!on_fwd || (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_RESIDUAL)) || p.Ck != 4 * p.s2d_c || p.N % 64 != 0)
+                return STYLEX_NOT_APPLICABLE;
+            if ((p.flags & STYLEX_EPI_RESIDUAL) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15)))
+                return STYLEX_NOT_APPLICABLE;
+        }
         return launch_dma<2, true>(p, s);
     }
     // Measured at B = 64 (fwd / dgrad ms, 128-channel tiles at one block per CU -> 64-channel tiles at two):
