@@ -373,7 +373,8 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
     static const bool on_s2d = !(getenv("STYLEX_HALO_DMA_S2D") && getenv("STYLEX_HALO_DMA_S2D")[0] == '0');
     if (!on) return STYLEX_NOT_APPLICABLE;
     if (!p.act_bf16 || p.a_scale) return STYLEX_NOT_APPLICABLE;
-    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) return STYLEX_NOT_APPLICABLE;
+    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | (p.s2d_c ? STYLEX_EPI_RESIDUAL : 0)))
+        return STYLEX_NOT_APPLICABLE;
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
         (reinterpret_cast<uintptr_t>(p.y) & 15))
