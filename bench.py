@@ -62,7 +62,7 @@ def build_trainer(args, device, rank, world):
                     alternating_training=True, classifier_name=args.classifier, classifier_path=None,
                     evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None,
                     is_ddp=world > 1 or os.environ.get("STYLEX_FORCE_DDP") == "1", rank=rank,
-                    world_size=world, device=device)
+                    world_size=world, device=device, graphs=bool(getattr(args, "graphs", 0)))
     tr.loader = st.cycle(ring)
     tr.dataset = list(range(10 ** 6))
     tr.save = lambda *a, **k: None
@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--roofline-steps", type=int, default=4)
+    ap.add_argument("--graphs", type=int, default=int(os.environ.get("STYLEX_GRAPHS", "1")),
+                    help="1 = replay the step as captured HIP graphs after the eager warm-up calls (0 = eager enqueue)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,6 +163,13 @@ def main():
 
     for _ in range(args.warmup):
         tr.train()
+    # graph mode: both step shapes (with / without the gradient penalty) must have been captured before the timed
+    # region starts; with the default W=8 they are (4 eager calls, then one capture each) — a shorter warm-up gets
+    # the missing untimed calls here
+    extra = 0
+    while tr.graphs and len(tr._graph_cache) < 2 and extra < 12:
+        tr.train()
+        extra += 1
     tr.steps = 0  # the timed region starts on a GP step: 1 call in 4 carries the penalty
     sync()
     t0 = time.perf_counter()
@@ -182,6 +191,7 @@ def main():
         # event pair brackets one kernel class running alone (the timed region above runs with it on)
         prev_streams = os.environ.get("STYLEX_STREAMS")
         os.environ["STYLEX_STREAMS"] = "0"
+        tr.graphs = False  # the per-launch hipEvent pairs are recorded by the C-ABI calls: eager enqueue
         for _ in range(2):
             tr.train()
         torch.cuda.synchronize()

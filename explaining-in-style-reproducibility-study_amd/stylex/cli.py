@@ -113,7 +113,16 @@ def run_training(rank, world_size, model_args, data, load_from, new, num_train_s
         dist.destroy_process_group()
 
 
-def train_from_folder(**overrides):
+def train_from_folder(*positional, **overrides):
+    """reference cli.py:84-171.  Positional arguments map onto the reference's parameter order (`data`, `results_dir`,
+    `models_dir`, `name`, ...) exactly as python-fire / a direct call passes them."""
+    order = list(DEFAULTS)
+    if len(positional) > len(order):
+        raise TypeError("train_from_folder takes at most %d positional arguments (%d given)" % (len(order), len(positional)))
+    for key, val in zip(order, positional):
+        if key in overrides:
+            raise TypeError("train_from_folder got multiple values for argument %r" % key)
+        overrides[key] = val
     unknown = set(overrides) - set(DEFAULTS)
     if unknown:
         raise TypeError("unknown arguments: %s" % ", ".join(sorted(unknown)))
@@ -187,7 +196,10 @@ def parse_flags(argv):
 
 
 def main():
-    train_from_folder(**parse_flags(sys.argv[1:]))
+    argv, positional = sys.argv[1:], []
+    while argv and not argv[0].startswith("--"):  # fire also accepts leading positionals: `cli.py <data> --name x`
+        positional.append(_parse_value(argv.pop(0)))
+    train_from_folder(*positional, **parse_flags(argv))
 
 
 if __name__ == "__main__":

@@ -16,8 +16,13 @@ def load_classifier(model_name, cuda_rank, output_size=2, seed=1234):
     model = MobileNetV2()
     model.classifier[1] = nn.Linear(1280, output_size)
     torch.random.set_rng_state(state)
-    path = os.path.join("trained_classifiers", str(model_name))
-    if model_name is not None and os.path.isfile(path):
+    if model_name is not None:
+        # a named checkpoint must exist, like the reference (torch.load raises FileNotFoundError): silently training
+        # against a random classifier because of a typo / wrong cwd would be worse than stopping
+        path = os.path.join("trained_classifiers", str(model_name))
+        if not os.path.isfile(path):
+            raise FileNotFoundError("classifier checkpoint %r not found (cwd %s); pass classifier_path=None for the "
+                                    "seeded random-weight classifier of the synthetic benchmarks" % (path, os.getcwd()))
         model.load_state_dict(torch.load(path, map_location="cpu"))
     dev = torch.device("cuda:%d" % cuda_rank) if torch.cuda.is_available() else torch.device("cpu")
     return model.to(dev)

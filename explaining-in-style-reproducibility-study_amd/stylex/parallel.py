@@ -3,9 +3,8 @@ over xGMI on ROCm; "gloo" in the CPU tests).
 
 The reference's multi-GPU path is vestigial (DDP wrappers around S/G/D only, the encoder is never
 wrapped — stylex/stylex_train.py:1188-1193, README.md:81).  Here gradient exchange is explicit:
-the gradients of a phase are packed into flat 32 MB buckets and all-reduced (averaging done by the collective,
-ReduceOp.AVG on RCCL) from inside the last backward of the phase, bucket by bucket as they complete, then
-scattered back (class GradSync).  Non-final micro-steps never communicate
+the gradients of a phase live in persistent flat 32 MB buckets (every .grad is a view) that are all-reduced in place (averaging done by the collective,
+ReduceOp.AVG on RCCL) from inside the last backward of the phase, bucket by bucket as they complete (class GradSync).  Non-final micro-steps never communicate
 (== ``no_sync``, :274-285).
 """
 import torch
@@ -28,25 +27,26 @@ def broadcast_parameters(module, src=0):
 
 
 class GradSync:
-    """Bucketed gradient all-reduce, overlapped with the backward pass.
+    """Bucketed gradient all-reduce on persistent flat buffers, overlapped with the backward pass.
 
-    Parameters are grouped into flat buckets in reverse order (~ the order their gradients become ready).  `arm()`
-    before the last backward of a phase turns on per-parameter post-accumulate hooks: when every gradient of the
-    next bucket IN INDEX ORDER is ready its all-reduce is launched from inside the backward, so the xGMI transfer
-    runs under the rest of the backward (a 2-GPU all-reduce of the 400 MB of a step is ~7 ms on one xGMI link,
-    ~6 % of a step when issued afterwards).  Buckets are launched strictly in index order on every rank — the
-    collective sequence never depends on which gradient happened to arrive first.  `all_reduce()` after the
-    backward launches what is left (parameters without a gradient contribute zeros), waits, and scatters the
-    averaged gradients back.  Without `arm()` everything is launched by `all_reduce()` (same result)."""
+    Parameters are grouped into flat fp32 buckets in reverse order (~ the order their gradients become ready).  Every
+    ``p.grad`` IS a view into its bucket (`zero_grad()` zeroes the buckets and re-attaches the views; autograd then
+    accumulates in place), so a collective runs on the bucket directly: no packing copy before it, no scatter after
+    it, and the buffers a captured HIP graph writes are the buffers the collective reads.  `arm()` before the last
+    backward of a phase turns on per-parameter post-accumulate hooks: when every gradient of the next bucket IN INDEX
+    ORDER is ready its all-reduce is launched from inside the backward, so the xGMI transfer runs under the rest of
+    the backward (a 2-GPU all-reduce of the 400 MB of a step is ~7 ms on one xGMI link).  Buckets are launched
+    strictly in index order on every rank — the collective sequence never depends on which gradient happened to
+    arrive first.  `all_reduce()` after the backward launches what is left and waits.  Without `arm()` everything is
+    launched by `all_reduce()` (same result).  Non-final micro-steps never communicate (== ``no_sync``,
+    reference stylex_train.py:274-285)."""
 
     def __init__(self, params, bucket_bytes=None, overlap=None):
-        # Default: launch after the backward, few large buckets (every collective has ~100 us of launch latency; the
-        # 1-rank RCCL path measured 589 images/s this way and 576 with in-backward launches, which cannot pay off
-        # without a second GPU to talk to).  STYLEX_DDP_OVERLAP=1 (or overlap=True) selects the in-backward launch
-        # with 32 MB buckets — to be judged on real multi-GPU scaling numbers.
+        # overlap (in-backward launch, 32 MB buckets) is the default; STYLEX_DDP_OVERLAP=0 issues few large
+        # collectives after the backward instead (A/B switch for the scaling runs)
         import os
 
-        self.overlap = (os.environ.get("STYLEX_DDP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
+        self.overlap = (os.environ.get("STYLEX_DDP_OVERLAP", "1") == "1") if overlap is None else bool(overlap)
         if bucket_bytes is None:
             bucket_bytes = (32 if self.overlap else 128) * 1024 * 1024
         seen, self.params = set(), []
@@ -64,8 +64,22 @@ class GradSync:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): bi for bi, bucket in enumerate(self.buckets) for p in bucket}
+        self.flats, self._views = [], {}
+        for bucket in self.buckets:
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+            off = 0
+            for p in bucket:
+                self._views[id(p)] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flats.append(flat)
         self._armed = False
         self._reset()
+        with torch.no_grad():
+            for p in self.params:  # adopt gradients that already exist, then bind every .grad to its view
+                v = self._views[id(p)]
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -73,7 +87,23 @@ class GradSync:
         self._ready = [0] * len(self.buckets)
         self._events = [[] for _ in self.buckets]
         self._next = 0
-        self._flats, self._works = [], []
+        self._works = []
+
+    @torch.no_grad()
+    def zero_grad(self):
+        """Replaces optimizer.zero_grad(): zero the buckets (one fill per bucket) and make sure every .grad is its
+        bucket view (something may have set it to None, e.g. a plain optimizer.zero_grad())."""
+        for flat in self.flats:
+            flat.zero_()
+        for p in self.params:
+            v = self._views[id(p)]
+            if p.grad is not v:
+                p.grad = v
+
+    def no_sync(self):
+        from contextlib import nullcontext
+
+        return nullcontext()  # collectives only ever start after arm() / all_reduce()
 
     def arm(self):
         """Call right before the last backward of the phase (earlier micro-step backwards only accumulate)."""
@@ -96,16 +126,21 @@ class GradSync:
     @torch.no_grad()
     def _launch(self, bi):
         assert bi == self._next
-        bucket = self.buckets[bi]
         if self._events[bi]:
             cur = torch.cuda.current_stream()
             for ev in self._events[bi]:
                 cur.wait_event(ev)
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket]
-        flat = torch.cat(parts)
+        for p in self.buckets[bi]:  # a gradient that was re-bound (grad None -> fresh tensor) goes back into its view
+            v = self._views[id(p)]
+            if p.grad is None:  # no gradient this phase: contributes zeros
+                v.zero_()
+                p.grad = v
+            elif p.grad is not v:
+                v.copy_(p.grad)
+                p.grad = v
+        flat = self.flats[bi]
         avg = flat.is_cuda  # RCCL averages inside the collective; gloo (CPU tests) has no AVG
         self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True))
-        self._flats.append(flat)
         self._next += 1
 
     @torch.no_grad()
@@ -118,23 +153,18 @@ class GradSync:
         world = dist.get_world_size()
         while self._next < len(self.buckets):
             self._launch(self._next)
-        for bucket, flat, work in zip(self.buckets, self._flats, self._works):
+        for flat, work in zip(self.flats, self._works):
             work.wait()
             if not flat.is_cuda:
                 flat.div_(world)
-            off, dst, src = 0, [], []
-            for p in bucket:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    dst.append(p.grad)
-                    src.append(g)
-                off += n
-            if dst:
-                torch._foreach_copy_(dst, src)  # one multi-tensor launch per bucket instead of one per parameter
         self._reset()
+
+
+def all_reduce_max_(t):
+    """In-place MAX over the ranks, no host synchronisation (the NaN flag of a step rides this)."""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
 
 
 def all_reduce_scalar_flag(flag, device):

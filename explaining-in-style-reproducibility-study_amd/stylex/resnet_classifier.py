@@ -16,16 +16,21 @@ def _device(cuda_rank):
 
 
 def load_resnet_classifier(model_name, cuda_rank, output_size=2, seed=1234):
-    """ResNet-18 with a 2-logit head.  ``trained_classifiers/<model_name>`` is loaded when it
-    exists (reference :16-26); otherwise seeded random weights are used (synthetic benchmarks —
-    the torch.hub / checkpoint files are unavailable offline)."""
+    """ResNet-18 with a 2-logit head.  ``trained_classifiers/<model_name>`` is loaded (reference :16-26) and must
+    exist; ``model_name=None`` is the explicit opt-in for seeded random weights (synthetic benchmarks — the
+    torch.hub / checkpoint files are unavailable offline)."""
     state = torch.random.get_rng_state()
     torch.manual_seed(seed)
     model = ResNet18()
     model.fc = nn.Linear(512, output_size)
     torch.random.set_rng_state(state)
-    path = os.path.join("trained_classifiers", str(model_name))
-    if model_name is not None and os.path.isfile(path):
+    if model_name is not None:
+        # a named checkpoint must exist, like the reference (torch.load raises FileNotFoundError): silently training
+        # against a random classifier because of a typo / wrong cwd would be worse than stopping
+        path = os.path.join("trained_classifiers", str(model_name))
+        if not os.path.isfile(path):
+            raise FileNotFoundError("classifier checkpoint %r not found (cwd %s); pass classifier_path=None for the "
+                                    "seeded random-weight classifier of the synthetic benchmarks" % (path, os.getcwd()))
         model.load_state_dict(torch.load(path, map_location="cpu"))
     return model.to(_device(cuda_rank))
 

@@ -34,6 +34,7 @@ from torch.optim import Adam
 from torch.utils import data
 from torch.utils.data.distributed import DistributedSampler  # noqa: F401  (re-exported for the notebook)
 
+import networks
 import ops
 import parallel
 from lpips_alex import LPIPS
@@ -79,6 +80,39 @@ def is_empty(t):
 def set_requires_grad(model, flag):
     for p in model.parameters():
         p.requires_grad = flag
+
+
+def _cat(ts):
+    return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def raise_if_nan(t):  # reference :269-271
+    if torch.isnan(t):
+        raise NanException
+
+
+def gradient_accumulate_contexts(gradient_accumulate_every, is_ddp, ddps):
+    """Micro-step iterator of the reference (:274-285): under DDP every micro-step but the last runs without
+    gradient exchange.  `ddps` are objects with a ``no_sync()`` context manager — torch DDP wrappers, or this package's
+    ``parallel.GradSync`` (whose collectives only ever run after the last micro-step: its no_sync is a null context)."""
+    from contextlib import ExitStack, nullcontext
+
+    for i in range(gradient_accumulate_every):
+        last = i == gradient_accumulate_every - 1
+        with ExitStack() as stack:
+            if is_ddp and not last:
+                for d in ddps:
+                    stack.enter_context(d.no_sync() if hasattr(d, "no_sync") else nullcontext())
+            yield
+
+
+def loss_backwards(fp16, loss, optimizer, loss_id, **kwargs):  # reference :288-293 (apex fp16 is out of scope)
+    assert not fp16, "apex fp16 is out of scope; use ops.set_precision('bf16')"
+    loss.backward(**kwargs)
 
 
 def _dev(device):
@@ -354,7 +388,7 @@ class StylEx(nn.Module):
     def __init__(self, image_size, latent_dim=514, fmap_max=512, style_depth=8, network_capacity=16, transparent=False,
                  fp16=False, cl_reg=False, steps=1, lr=1e-4, ttur_mult=2, fq_layers=[], fq_dict_size=256,
                  attn_layers=[], no_const=False, lr_mlp=0.1, rank=0, classifier_labels=2, encoder_class=None,
-                 kl_rec_during_disc=False):
+                 kl_rec_during_disc=False, capturable=False):
         super().__init__()
         assert not fp16 and not cl_reg and encoder_class is None, "apex fp16 / cl_reg / debug encoders: out of scope"
         self.lr, self.steps, self.ema_beta, self.fp16 = lr, steps, 0.995, False
@@ -381,11 +415,16 @@ class StylEx(nn.Module):
         self._init_weights()
         self.reset_parameter_averaging()
         self.to(_dev(rank))
+        opt_kw = {}
         if _dev(rank).type == "cuda" and ops.get_precision() == "bf16":
             # speed mode: one fused multi-tensor Adam launch per optimiser instead of ~23 foreach launches (same
             # update rule; the fp32 parity mode keeps the default implementation the goldens were pinned with)
-            self.G_opt = Adam(generator_params, lr=self.lr, betas=(0.5, 0.9), fused=True)
-            self.D_opt = Adam(self.D.parameters(), lr=self.lr * ttur_mult, betas=(0.5, 0.9), fused=True)
+            opt_kw["fused"] = True
+        if _dev(rank).type == "cuda" and capturable:
+            opt_kw["capturable"] = True  # step counters live on the device: the step can sit inside a HIP graph
+        if opt_kw:
+            self.G_opt = Adam(generator_params, lr=self.lr, betas=(0.5, 0.9), **opt_kw)
+            self.D_opt = Adam(self.D.parameters(), lr=self.lr * ttur_mult, betas=(0.5, 0.9), **opt_kw)
 
     def _init_weights(self):
         for m in self.modules():  # the reference tests exact nn.Conv2d / nn.Linear types (:975-977)
@@ -449,7 +488,7 @@ class Trainer:
                  classifier_name=None,
                  # --- extensions (defaults reproduce the reference) ---
                  classifier=None, lpips_fn=None, gp_every=4, pl_every=32, pl_after=5000, device=None,
-                 save_training_state=False, *args, **kwargs):
+                 save_training_state=False, graphs=None, graph_warmup=4, *args, **kwargs):
         kwargs.pop("kl_rec_during_disc", None)  # cli.py forwards it; only the new architecture reads it
         self.model_params = [args, kwargs]
         self.StylEx = None
@@ -501,6 +540,12 @@ class Trainer:
             torch.backends.cudnn.benchmark = True
         self.save_training_state = save_training_state
         self.device = _dev(device if device is not None else rank)
+        # whole-step HIP graphs (see _graphs_enabled); the first `graph_warmup` train() calls run eagerly so that
+        # both step shapes, MIOpen's algorithm search and the allocator have been exercised before the capture
+        self.graphs = (os.environ.get("STYLEX_GRAPHS", "0") == "1") if graphs is None else bool(graphs)
+        self.graph_warmup = graph_warmup
+        self._static, self._graph_cache, self._graph_pool, self._calls = {}, {}, None, 0
+        self._nan_hook = os.environ.get("STYLEX_NAN_HOOK", "0") == "1"
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
         if classifier is not None:
@@ -538,7 +583,8 @@ class Trainer:
                              network_capacity=self.network_capacity, fmap_max=self.fmap_max,
                              transparent=self.transparent, fq_layers=self.fq_layers, fq_dict_size=self.fq_dict_size,
                              attn_layers=self.attn_layers, no_const=self.no_const, rank=self.device,
-                             classifier_labels=self.num_classes, *args, **kwargs)
+                             classifier_labels=self.num_classes, capturable=self.graphs, *args, **kwargs)
+        self._graph_cache, self._static = {}, {}  # graphs captured for a previous model instance are void
         if self.is_ddp:
             m = self.StylEx
             parallel.broadcast_parameters(m)
@@ -607,7 +653,7 @@ class Trainer:
                 self.last_gp_loss = vals[4]
             if keep_rec:
                 self.total_rec_loss, self.total_kl_loss = vals[2], vals[3]
-            self._nan = math.isnan(vals[0]) or math.isnan(vals[1])
+            self._nan = vals[5] > 0  # isnan(d_loss) | isnan(g_loss), OR-ed over the ranks under DDP
         if raise_nan and getattr(self, "_nan", False):
             self._nan = False
             print(f"NaN detected for generator or discriminator. Loading from checkpoint #{self.checkpoint_num}")
@@ -654,11 +700,229 @@ class Trainer:
         w = styles_def_to_tensor([(torch.cat((enc, logits), dim=1), m.G.num_layers)])
         return enc, logits, w
 
-    def _styles_from_noise(self, latents_fn, batch_size):
+    def _styles_of(self, entry):
+        """[B, L, latent] style tensor of a noise micro-step: ('noise', [(z, n_layers), ...], inoise) as drawn by
+        noise_list / mixed_list, or the graph form ('noise_static', z1, z2, tt, inoise) whose layer split `tt` is a
+        device scalar, so that one captured graph serves every split (pure selection: identical values)."""
         m = self.StylEx
-        style = latents_fn(batch_size, m.G.num_layers, m.G.latent_dim, device=self.device)
-        inoise = image_noise(batch_size, m.G.image_size, device=self.device)
-        return styles_def_to_tensor(latent_to_w(m.S, style)), inoise
+        if entry[0] == "noise":
+            return styles_def_to_tensor(latent_to_w(m.S, entry[1]))
+        _, z1, z2, tt, _ = entry
+        w1, w2 = m.S(z1), m.S(z2)
+        first = torch.arange(m.G.num_layers, device=z1.device) < tt
+        return torch.where(first[None, :, None], w1[:, None, :], w2[:, None, :])
+
+    # -- host side of a phase: every RNG draw / loader fetch of its micro-steps, in the reference's order ---------
+
+    def _draw_d(self, group, st, fuse):
+        """Discriminator-phase inputs of one micro-step group (:1299-1333): per micro-step the real batch, then either
+        (encoder micro-step) a second loader batch + image noise, or (noise micro-step) random() for mixed_prob,
+        [torch.rand(()) split], 1-2 latents, image noise; then the two AugWrapper draws."""
+        m = self.StylEx
+        batch_size = math.ceil(self.batch_size / self.world_size)
+        reals, micro = [], []
+        for _ in group:
+            reals.append(self._next_batch())
+            if (not self.alternating_training) or st["encoder_input"]:
+                micro.append(("enc", self._next_batch(), image_noise(batch_size, m.G.image_size, device=self.device)))
+                st["encoder_input"] = False
+            else:
+                st["latents_fn"] = mixed_list if random() < self.mixed_prob else noise_list
+                style = st["latents_fn"](batch_size, m.G.num_layers, m.G.latent_dim, device=self.device)
+                micro.append(("noise", style, image_noise(batch_size, m.G.image_size, device=self.device)))
+                if self.alternating_training:
+                    st["encoder_input"] = True
+            if fuse:
+                random(), random()  # the two AugWrapper draws of this micro-step (:1331-1333)
+        return reals, micro
+
+    def _draw_g(self, group, st, fuse, apply_pl):
+        """Generator-phase inputs of one group (:1376-1421): loader batch (drawn on noise micro-steps too), image
+        noise / latents, the AugWrapper draw, and the path-length noise where the reference draws it."""
+        m = self.StylEx
+        batch_size = math.ceil(self.batch_size / self.world_size)
+        micro, pl_noises = [], []
+        for _ in group:
+            batch = self._next_batch()
+            if (not self.alternating_training) or st["encoder_input"]:
+                micro.append(("enc", batch, image_noise(batch_size, m.G.image_size, device=self.device)))
+            else:
+                style = st["latents_fn"](batch_size, m.G.num_layers, m.G.latent_dim, device=self.device)
+                micro.append(("noise", style, image_noise(batch_size, m.G.image_size, device=self.device)))
+            if fuse:
+                random()  # the AugWrapper draw of this micro-step (:1417)
+                if apply_pl:
+                    pl_noises.append(draw_pl_noise((batch_size, 4 if self.transparent else 3, m.G.image_size,
+                                                    m.G.image_size), self.device))
+            st["encoder_input"] = not st["encoder_input"]
+        return micro, pl_noises
+
+    # -- device side of a phase: forward + backward of one micro-step group -------------------------------------
+
+    def _d_compute(self, reals, micro, apply_gp, gae, fuse, last, acc):
+        m = self.StylEx
+        aug = {"prob": self.aug_prob, "types": self.aug_types}
+
+        def D_call(images, detach=False):
+            if fuse:  # AugWrapper at prob 0 is D itself; its random() draw is issued where the reference draws it
+                return m.D(images.detach() if detach else images)
+            return m.D_aug(images, detach=detach, **aug)
+
+        with torch.no_grad():  # the generator/encoder graph is never used in this phase (:1330-1331)
+            ws = [self._styles_from_encoder(e[1])[2] if e[0] == "enc" else self._styles_of(e) for e in micro]
+            ops.set_fast(True)
+            generated = m.G(_cat(ws), _cat([e[-1] for e in micro]))
+        real = _cat(reals)
+        n_fake = generated.shape[0]
+        grad_norms = None
+        if apply_gp:
+            real = real.detach().requires_grad_()
+
+            def fake_branch():
+                ops.set_fast(True)  # the fake branch is only ever differentiated once
+                return D_call(generated, detach=True)
+
+            def real_branch():
+                ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
+                return D_call(real)
+
+            # the two D passes of a penalty step are independent until the loss: two HIP streams when D_aug is
+            # a pass-through (`fuse`; with augmentation the reference's fake-then-real draw order is kept)
+            if fuse:
+                real_out, fake_out = self._fork([real_branch, fake_branch])
+            else:
+                fake_out, real_out = fake_branch(), real_branch()
+            ops.set_fast(False)
+            grad_norms = gradient_norms(real, real_out)
+        else:
+            # D(fake) and D(real) are one pass over the concatenated batch
+            ops.set_fast(True)
+            if fuse:
+                both = D_call(torch.cat((generated, real), dim=0), detach=True)
+                fake_out, real_out = both[:n_fake], both[n_fake:]
+            else:
+                fake_out = D_call(generated, detach=True)
+                real_out = D_call(real)
+        disc_loss, lo = 0, 0
+        for r in reals:
+            sl = slice(lo, lo + r.shape[0])
+            lo += r.shape[0]
+            divergence = hinge_loss(real_out[sl], fake_out[sl])
+            disc_loss = disc_loss + divergence
+            if apply_gp:
+                gp = 10 * ((grad_norms[sl] - 1) ** 2).mean()
+                acc["gp"] = gp.detach()
+                disc_loss = disc_loss + gp
+            acc["d"] += divergence.detach() / gae
+        if self.is_ddp and last and not _capturing():
+            self._d_sync.arm()  # the all-reduce of D's gradients starts inside this backward
+        disc_loss = disc_loss / gae
+        if self._nan_hook:
+            disc_loss.register_hook(raise_if_nan)  # reference :1352 (opt-in: the check synchronises the host)
+        disc_loss.backward()
+
+    def _g_compute(self, micro, pl_noises, apply_pl, gae, fuse, last, acc):
+        m = self.StylEx
+        aug = {"prob": self.aug_prob, "types": self.aug_types}
+
+        def D_call(images):
+            return m.D(images) if fuse else m.D_aug(images, detach=False, **aug)
+
+        ws, encs = [], []
+        for e in micro:
+            if e[0] == "enc":
+                enc_out, real_logits, w_styles = self._styles_from_encoder(e[1])
+                encs.append((e[1], enc_out, real_logits))
+            else:
+                w_styles = self._styles_of(e)
+                encs.append(None)
+            ws.append(w_styles)
+        w_all = _cat(ws)
+        generated_all = m.G(w_all, _cat([e[-1] for e in micro]))
+        pl_all = calc_pl_lengths(w_all, generated_all, _cat(pl_noises)) if (apply_pl and pl_noises) else None
+        # four independent consumers of the generated batch: D, and per encoder micro-step the classifier,
+        # the encoder and LPIPS — forked over HIP streams (see _fork)
+        spans, lo = [], 0
+        for w_styles in ws:
+            spans.append(slice(lo, lo + w_styles.shape[0]))
+            lo += w_styles.shape[0]
+        branches, where = [lambda: D_call(generated_all)], []
+        for sl, enc in zip(spans, encs):
+            if enc is not None:
+                gen_i, batch_i = generated_all[sl], enc[0]
+                where.append(len(branches))
+                branches += [lambda g=gen_i: self._classify(g), lambda g=gen_i: m.encoder(g),
+                             lambda g=gen_i, b=batch_i: perceptual_loss(b, g, self.lpips_fn)]
+            else:
+                where.append(None)
+        outs = self._fork(branches)
+        fake_all = outs[0]
+        total_all = 0
+        for sl, enc, at in zip(spans, encs, where):
+            generated = generated_all[sl]
+            loss = gen_hinge_loss(fake_all[sl], None)
+            total = loss
+            if apply_pl:
+                pl_lengths = pl_all[sl] if pl_all is not None else calc_pl_lengths(w_all, generated)
+                acc["pl"] = float(np.mean(pl_lengths.detach().cpu().numpy()))
+                if not is_empty(self.pl_mean):
+                    pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
+                    if not torch.isnan(pl_loss):
+                        total = total + pl_loss
+            total = total / gae
+            if enc is not None:
+                batch, enc_out, real_logits = enc
+                gen_logits, gen_w, perceptual = outs[at:at + 3]
+                rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, gen_w, enc_out,
+                                                                 self.lpips_fn, perceptual=perceptual) / gae
+                kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
+                total = total + rec + kl  # one backward == the three backward calls of :1436-1438
+                acc["rec"] += rec.detach()
+                acc["kl"] += kl.detach()
+            total_all = total_all + total
+            acc["g"] += loss.detach() / gae
+        if self.is_ddp and last and not _capturing():
+            self._g_sync.arm()
+        if self._nan_hook:
+            total_all.register_hook(raise_if_nan)  # reference :1352, :1432 (opt-in: it synchronises the host)
+        total_all.backward()
+
+    def _new_acc(self):
+        acc = {k: torch.zeros((), device=self.device) for k in ("d", "g", "rec", "kl")}
+        acc["gp"], acc["pl"] = None, self.pl_mean
+        return acc
+
+    def _d_phase(self, groups, inputs, apply_gp, gae, fuse, acc, st=None):
+        """zero_grad + forward/backward of every group; `inputs` None = draw each group's inputs right before its
+        compute (eager mode: the host prepares the next group while the GPU runs this one)."""
+        self._zero_grad("D")
+        for gi, group in enumerate(groups):
+            reals, micro = inputs[gi] if inputs is not None else self._draw_d(group, st, fuse)
+            self._d_compute(reals, micro, apply_gp, gae, fuse, group is groups[-1], acc)
+
+    def _g_phase(self, groups, inputs, apply_pl, gae, fuse, acc, st=None):
+        m = self.StylEx
+        ops.set_fast(not apply_pl)  # path-length regularisation is the only double backward of this phase
+        self._zero_grad("G")
+        set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
+        try:
+            for gi, group in enumerate(groups):
+                micro, pl_noises = inputs[gi] if inputs is not None else self._draw_g(group, st, fuse, apply_pl)
+                self._g_compute(micro, pl_noises, apply_pl, gae, fuse, group is groups[-1], acc)
+        finally:
+            set_requires_grad(m.D, True)
+            ops.set_fast(False)
+
+    def _zero_grad(self, which):
+        m = self.StylEx
+        if self.is_ddp:  # gradients are views of the persistent flat buckets the collectives run on
+            (self._d_sync if which == "D" else self._g_sync).zero_grad()
+        else:
+            (m.D_opt if which == "D" else m.G_opt).zero_grad()
+
+    def _loss_stack(self, acc):
+        gp = acc["gp"]
+        return torch.stack((acc["d"], acc["g"], acc["rec"], acc["kl"], gp if gp is not None else acc["d"]))
 
     def train(self):
         """One optimiser step of D, then one of G (reference :1249-1506)."""
@@ -667,17 +931,9 @@ class Trainer:
             self.init_StylEx()
         m = self.StylEx
         m.train()
-        dev = self.device
         gae = self.gradient_accumulate_every
-        batch_size = math.ceil(self.batch_size / self.world_size)
-        image_size = m.G.image_size
-        aug = {"prob": self.aug_prob, "types": self.aug_types}
         apply_gp = self.steps % self.gp_every == 0
         apply_pl = (not self.no_pl_reg) and self.steps > self.pl_after and self.steps % self.pl_every == 0
-        tot_d, tot_g, tot_rec, tot_kl = (torch.zeros((), device=dev) for _ in range(4))
-        gp_val = None
-        avg_pl_length = self.pl_mean
-        latents_fn = None
 
         # Micro-step batching: G, D and the encoder carry no batch statistics, so the `gae` micro-steps of a
         # phase are evaluated as ONE pass over their concatenated batch (same per-sample arithmetic, the
@@ -687,172 +943,41 @@ class Trainer:
         # (AugWrapper consumes RNG per call) every micro-step stays its own group.
         fuse = not self.aug_prob
         groups = [list(range(gae))] if fuse else [[i] for i in range(gae)]
+        st = {"encoder_input": False, "latents_fn": None}
 
-        def D_call(images, detach=False):
-            if fuse:  # AugWrapper at prob 0 is D itself; its random() draw is issued where the reference draws it
-                return m.D(images.detach() if detach else images)
-            return m.D_aug(images, detach=detach, **aug)
+        self._calls = getattr(self, "_calls", 0) + 1
+        if self._graphs_enabled() and fuse and not apply_pl and self._calls > self.graph_warmup:
+            acc_host = self._train_graphed(groups[0], st, apply_gp, gae)
+            has_gp = apply_gp
+        else:
+            acc = self._new_acc()
+            # ---------------- discriminator phase ----------------
+            self._d_phase(groups, None, apply_gp, gae, fuse, acc, st)
+            if self.is_ddp:
+                self._d_sync.all_reduce()
+            self._resolve_losses()  # previous step's scalars: its copy finished long ago, the GPU keeps running
+            m.D_opt.step()
+            # ---------------- generator phase ----------------
+            if self.alternating_training:
+                st["encoder_input"] = False
+            self._g_phase(groups, None, apply_pl, gae, fuse, acc, st)
+            if self.is_ddp:
+                self._g_sync.all_reduce()
+            m.G_opt.step()
+            self._bump_packs()
+            acc_host, has_gp = self._loss_stack(acc), acc["gp"] is not None
+            if apply_pl and not np.isnan(acc["pl"]):  # EMA(0.99), reference :1128, :1471-1473
+                avg = float(acc["pl"])
+                self.pl_mean = avg if self.pl_mean is None else self.pl_mean * 0.99 + 0.01 * avg
 
-        def cat(ts):
-            return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
-
-        # ---------------- discriminator phase ----------------
-        m.D_opt.zero_grad()
-        encoder_input = False
-        for group in groups:
-            reals, ws, noises = [], [], []
-            with torch.no_grad():  # the generator/encoder graph is never used in this phase (:1330-1331)
-                for _ in group:
-                    reals.append(self._next_batch())
-                    if (not self.alternating_training) or encoder_input:
-                        _, _, w_styles = self._styles_from_encoder(self._next_batch())
-                        inoise = image_noise(batch_size, image_size, device=dev)
-                        encoder_input = False
-                    else:
-                        latents_fn = mixed_list if random() < self.mixed_prob else noise_list
-                        w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
-                        if self.alternating_training:
-                            encoder_input = True
-                    ws.append(w_styles)
-                    noises.append(inoise)
-                    if fuse:
-                        random(), random()  # the two AugWrapper draws of this micro-step (:1331-1333)
-                ops.set_fast(True)
-                generated = m.G(cat(ws), cat(noises))
-            real = cat(reals)
-            n_fake = generated.shape[0]
-            if apply_gp:
-                real.requires_grad_()
-
-                def fake_branch():
-                    ops.set_fast(True)  # the fake branch is only ever differentiated once
-                    return D_call(generated, detach=True)
-
-                def real_branch():
-                    ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
-                    return D_call(real)
-
-                # the two D passes of a penalty step are independent until the loss: two HIP streams when D_aug is
-                # a pass-through (`fuse`; with augmentation the reference's fake-then-real draw order is kept)
-                if fuse:
-                    real_out, fake_out = self._fork([real_branch, fake_branch])
-                else:
-                    fake_out, real_out = fake_branch(), real_branch()
-                ops.set_fast(False)
-                grad_norms = gradient_norms(real, real_out)
-            else:
-                # D(fake) and D(real) are one pass over the concatenated batch
-                ops.set_fast(True)
-                if fuse:
-                    both = D_call(torch.cat((generated, real), dim=0), detach=True)
-                    fake_out, real_out = both[:n_fake], both[n_fake:]
-                else:
-                    fake_out = D_call(generated, detach=True)
-                    real_out = D_call(real)
-            disc_loss, lo = 0, 0
-            for r in reals:
-                sl = slice(lo, lo + r.shape[0])
-                lo += r.shape[0]
-                divergence = hinge_loss(real_out[sl], fake_out[sl])
-                disc_loss = disc_loss + divergence
-                if apply_gp:
-                    gp = 10 * ((grad_norms[sl] - 1) ** 2).mean()
-                    gp_val = gp.detach()
-                    disc_loss = disc_loss + gp
-                tot_d += divergence.detach() / gae
-            if self.is_ddp and group is groups[-1]:
-                self._d_sync.arm()  # the all-reduce of D's gradients starts inside this backward
-            (disc_loss / gae).backward()
+        # all loss scalars of the step leave in one asynchronous copy (resolved lazily, see _resolve_losses); under
+        # DDP a NaN flag, OR-ed over the ranks ON THE DEVICE (no host sync), rides along so that every rank takes the
+        # checkpoint-reload path at the same step
+        stack = acc_host
+        flag = torch.isnan(stack[:2]).any().to(stack.dtype).reshape(1)
         if self.is_ddp:
-            self._d_sync.all_reduce()
-        self._resolve_losses()  # previous step's scalars: its copy finished long ago, the GPU keeps running
-        m.D_opt.step()
-
-        # ---------------- generator phase ----------------
-        if self.alternating_training:
-            encoder_input = False
-        # (path-length steps batch like the others: the pl noise of a micro-step is drawn right after its other draws,
-        # where the reference draws it, and its shape does not depend on the generated images)
-        ops.set_fast(not apply_pl)  # path-length regularisation is the only double backward of this phase
-        m.G_opt.zero_grad()
-        set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
-        try:
-            for group in groups:
-                ws, noises, micro, pl_noises = [], [], [], []
-                for _ in group:
-                    batch = self._next_batch()
-                    enc_step = (not self.alternating_training) or encoder_input
-                    if enc_step:
-                        enc_out, real_logits, w_styles = self._styles_from_encoder(batch)
-                        inoise = image_noise(batch_size, image_size, device=dev)
-                        micro.append((batch, enc_out, real_logits))
-                    else:
-                        w_styles, inoise = self._styles_from_noise(latents_fn, batch_size)
-                        micro.append(None)
-                    ws.append(w_styles)
-                    noises.append(inoise)
-                    if fuse:
-                        random()  # the AugWrapper draw of this micro-step (:1417)
-                        if apply_pl:
-                            pl_noises.append(draw_pl_noise((w_styles.shape[0], 4 if self.transparent else 3, image_size,
-                                                            image_size), dev))
-                    encoder_input = not encoder_input
-                w_all = cat(ws)
-                generated_all = m.G(w_all, cat(noises))
-                pl_all = calc_pl_lengths(w_all, generated_all, cat(pl_noises)) if (apply_pl and pl_noises) else None
-                # four independent consumers of the generated batch: D, and per encoder micro-step the classifier,
-                # the encoder and LPIPS — forked over HIP streams (see _fork)
-                spans, lo = [], 0
-                for w_styles in ws:
-                    spans.append(slice(lo, lo + w_styles.shape[0]))
-                    lo += w_styles.shape[0]
-                branches, where = [lambda: D_call(generated_all)], []
-                for sl, enc in zip(spans, micro):
-                    if enc is not None:
-                        gen_i, batch_i = generated_all[sl], enc[0]
-                        where.append(len(branches))
-                        branches += [lambda g=gen_i: self._classify(g), lambda g=gen_i: m.encoder(g),
-                                     lambda g=gen_i, b=batch_i: perceptual_loss(b, g, self.lpips_fn)]
-                    else:
-                        where.append(None)
-                outs = self._fork(branches)
-                fake_all = outs[0]
-                total_all = 0
-                for sl, enc, at in zip(spans, micro, where):
-                    generated = generated_all[sl]
-                    loss = gen_hinge_loss(fake_all[sl], None)
-                    total = loss
-                    if apply_pl:
-                        pl_lengths = pl_all[sl] if pl_all is not None else calc_pl_lengths(w_all, generated)
-                        avg_pl_length = np.mean(pl_lengths.detach().cpu().numpy())
-                        if not is_empty(self.pl_mean):
-                            pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
-                            if not torch.isnan(pl_loss):
-                                total = total + pl_loss
-                    total = total / gae
-                    if enc is not None:
-                        batch, enc_out, real_logits = enc
-                        gen_logits, gen_w, perceptual = outs[at:at + 3]
-                        rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, gen_w, enc_out,
-                                                                         self.lpips_fn, perceptual=perceptual) / gae
-                        kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
-                        total = total + rec + kl  # one backward == the three backward calls of :1436-1438
-                        tot_rec += rec.detach()
-                        tot_kl += kl.detach()
-                    total_all = total_all + total
-                    tot_g += loss.detach() / gae
-                if self.is_ddp and group is groups[-1]:
-                    self._g_sync.arm()
-                total_all.backward()
-        finally:
-            set_requires_grad(m.D, True)
-            ops.set_fast(False)
-        if self.is_ddp:
-            self._g_sync.all_reduce()
-        m.G_opt.step()
-
-        # all loss scalars of the step leave in one asynchronous copy (resolved lazily, see _resolve_losses)
-        stack = torch.stack((tot_d, tot_g, tot_rec, tot_kl, gp_val if gp_val is not None else tot_d))
+            parallel.all_reduce_max_(flag)
+        stack = torch.cat((stack, flag))
         keep_rec = (not self.alternating_training) or gae > 1
         if stack.is_cuda:
             host = torch.empty(stack.shape, dtype=stack.dtype, pin_memory=True)
@@ -861,14 +986,12 @@ class Trainer:
             done.record()
         else:
             host, done = stack, None
-        self._pending = (host, done, gp_val is not None, keep_rec)
+        self._pending = (host, done, has_gp, keep_rec)
         if exists(self.tb_writer):
             for k, v in (("G", self.g_loss), ("D", self.d_loss), ("rec", self.total_rec_loss),
                          ("kl", self.total_kl_loss)):
                 self.tb_writer.add_scalar("loss/" + k, v, self.steps)
 
-        if apply_pl and not np.isnan(avg_pl_length):  # EMA(0.99), reference :1128, :1471-1473
-            self.pl_mean = avg_pl_length if self.pl_mean is None else self.pl_mean * 0.99 + 0.01 * avg_pl_length
         if self.is_main and self.steps % 10 == 0 and self.steps > 20000:
             m.EMA()
         if self.is_main and self.steps <= 25000 and self.steps % 1000 == 2:
@@ -884,6 +1007,102 @@ class Trainer:
                 self.last_fid = self.calculate_fid(math.ceil(self.calculate_fid_num_images / self.batch_size))
         self.steps += 1
         self.av = None
+
+    # -- HIP-graph replay of the whole step ---------------------------------------------------------------------
+
+    def _graphs_enabled(self):
+        """Whole-step HIP graphs: opt-in with Trainer(graphs=True) / STYLEX_GRAPHS=1 (bench.py turns them on).  A step
+        is ~1100 kernel launches issued through ctypes/ATen (~70 ms of host time per step); captured once
+        per step shape (with / without the gradient penalty) it replays with one hipGraphLaunch."""
+        return self.graphs and self.device.type == "cuda"
+
+    def _bump_packs(self):
+        import hip_backend as hb
+
+        hb.pack_cache_clear()  # optimiser steps inside a replayed graph do not advance Parameter._version
+
+    def _bind(self, key, t):
+        """Copy a freshly drawn input into the static device buffer the captured graph reads."""
+        buf = self._static.get(key)
+        if buf is None:
+            buf = self._static[key] = torch.empty_like(t)
+        buf.copy_(t, non_blocking=True)
+        return buf
+
+    def _bind_micro(self, phase, i, e, layers):
+        if e[0] == "enc":
+            return ("enc", self._bind((phase, i, "x"), e[1]), self._bind((phase, i, "n"), e[2]))
+        style = e[1]
+        z1 = self._bind((phase, i, "z1"), style[0][0])
+        z2 = self._bind((phase, i, "z2"), style[1][0] if len(style) > 1 else style[0][0])
+        tt = self._static.get((phase, i, "tt"))
+        if tt is None:
+            tt = self._static[(phase, i, "tt")] = torch.zeros((), dtype=torch.int64, device=self.device)
+        tt.fill_(style[0][1] if len(style) > 1 else layers)
+        return ("noise_static", z1, z2, tt, self._bind((phase, i, "n"), e[2]))
+
+    def _train_graphed(self, group, st, apply_gp, gae):
+        m = self.StylEx
+        layers = m.G.num_layers
+        # host: every draw of the step in the reference's order, then into the static input buffers.  The previous
+        # replay is still running on the GPU while this happens (stream-ordered copies).
+        reals, micro_d = self._draw_d(group, st, True)
+        if self.alternating_training:
+            st["encoder_input"] = False
+        micro_g, _ = self._draw_g(group, st, True, False)
+        reals = [self._bind(("d", i, "real"), r) for i, r in enumerate(reals)]
+        micro_d = [self._bind_micro("d", i, e, layers) for i, e in enumerate(micro_d)]
+        micro_g = [self._bind_micro("g", i, e, layers) for i, e in enumerate(micro_g)]
+        self._resolve_losses()
+        entry = self._graph_cache.get(apply_gp)
+        if entry is None:
+            entry = self._capture(apply_gp, gae, [group], [(reals, micro_d)], [(micro_g, [])])
+            self._graph_cache[apply_gp] = entry
+        graphs, out = entry
+        syncs = [self._d_sync.all_reduce, self._g_sync.all_reduce, None] if self.is_ddp else [None]
+        for g, sync in zip(graphs, syncs):
+            g.replay()
+            if sync is not None:
+                sync()
+        self._bump_packs()
+        return out
+
+    def _capture(self, apply_gp, gae, groups, d_in, g_in):
+        """Capture the step as HIP graph(s): one graph, or under DDP three (D forward/backward | D step + G
+        forward/backward | G step) with the RCCL gradient all-reduces issued between the replays."""
+        m = self.StylEx
+        acc = {}
+
+        def seg_d():
+            acc.update(self._new_acc())
+            self._d_phase(groups, d_in, apply_gp, gae, True, acc)
+
+        def seg_g():
+            m.D_opt.step()
+            self._g_phase(groups, g_in, False, gae, True, acc)
+
+        def seg_tail():
+            m.G_opt.step()
+            acc["out"] = self._loss_stack(acc)
+
+        segments = [[seg_d], [seg_g], [seg_tail]] if self.is_ddp else [[seg_d, seg_g, seg_tail]]
+        torch.cuda.synchronize()
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        for fns in segments:
+            self._bump_packs()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                networks.CAPTURE_ORIGIN = torch.cuda.current_stream().cuda_stream
+                try:
+                    for fn in fns:
+                        fn()
+                finally:
+                    networks.CAPTURE_ORIGIN = None
+            graphs.append(g)
+        self._bump_packs()
+        return graphs, acc["out"]
 
     # ---- evaluation / generation (reference :1508-1698) ---------------------------------------
 
@@ -994,7 +1213,8 @@ class Trainer:
             # extension: the reference drops optimiser moments, step count and the path-length mean on
             # every restart; extra keys are ignored by the reference's loader (:1707-1716)
             data["training_state"] = {"G_opt": self.StylEx.G_opt.state_dict(), "D_opt": self.StylEx.D_opt.state_dict(),
-                                      "steps": self.steps, "pl_mean": self.pl_mean}
+                                      "steps": self.steps,
+                                      "pl_mean": None if self.pl_mean is None else float(self.pl_mean)}
         torch.save(data, self.model_name(num))
         self.write_config()
 

@@ -3,7 +3,7 @@ container: it imports the reference (/root/reference) through ``ref_shim`` and
 writes input/expected-output vectors to ``tests/golden/*.npz``.  The vectors are
 data; no reference source travels.
 
-    python oracle/make_golden.py [--only init,ops,nets,losses,steps,curve]
+    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,diffaug,curve]
 
 Conventions: every fixture stores the seeds needed to regenerate weights
 (``torch.manual_seed(seed)`` then construct ``StylEx(...)``), all inputs that are
@@ -225,6 +225,9 @@ STEP_CASES = {
     "gae2_alt": (2, True, 5, 0, None),
     "gae2_noalt": (2, False, 3, 0, None),
     "gae2_pl": (2, True, 2, 5024, 0.05),
+    # discriminator augmentation on (AugWrapper.forward :558-571 + diff_augment.py, translation + cutout): every
+    # micro-step is its own D pass, the random() gates and the augmentation parameters interleave with the other draws
+    "gae2_aug": (2, True, 3, 0, None, 0.6),
 }
 
 
@@ -236,10 +239,13 @@ def param_stats(model):
     return np.array(names), np.stack(st_)
 
 
-def gen_steps(st):
+def gen_steps(st, only=None):
     """(5) step parity: Trainer.train() x N on synthetic data."""
     size, cap, fmax, bs = 32, 4, 64, 2
-    for tag, (gae, alt, n, start, pl0) in STEP_CASES.items():
+    for tag, case in STEP_CASES.items():
+        if only and tag not in only:
+            continue
+        (gae, alt, n, start, pl0), aug = case[:5], (case[5] if len(case) > 5 else 0.)
         cls = ref_shim.TinyClassifier(seed=99)
         gd = torch.Generator().manual_seed(7)
         batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
@@ -248,7 +254,7 @@ def gen_steps(st):
         tr = ref_shim.make_reference_trainer(st, tmp, cls, batches, image_size=size, network_capacity=cap,
                                              fmap_max=fmax, batch_size=bs, gradient_accumulate_every=gae,
                                              alternating_training=alt, lr=2e-4, ttur_mult=1.5, rec_scaling=1,
-                                             kl_scaling=1)
+                                             kl_scaling=1, aug_prob=aug)
         tr.init_StylEx()
         tr.steps = start
         tr.pl_mean = pl0
@@ -262,7 +268,83 @@ def gen_steps(st):
         names, pst = param_stats(tr.StylEx)
         save("steps_" + tag, config=np.array([size, cap, fmax, bs, gae, int(alt), n, start]),
              pl_mean0=np.nan if pl0 is None else pl0, data_seed=7, seed=42, cls_seed=99, lpips_seed=4242,
-             scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst)
+             scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst, aug_prob=aug)
+
+
+def gen_cfg4(st):
+    """BASELINE config 4 in miniature: MobileNetV2 classifier through the reference's own wrapper
+    (stylex/mobilenet_classifier.py:57-73: nearest interpolate to image_size, ImageNet normalise), R1 every 4th
+    step + path-length regularisation (step 5024: both penalties; reference interval 32, :1272-1273)."""
+    size, cap, fmax, bs, gae, n, start, pl0 = 32, 4, 64, 2, 2, 2, 5024, 0.05
+    mod = ref_shim.import_reference_mobilenet()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "trained_classifiers"))
+    torch.save(ref_shim.seeded_mobilenet_state(77), os.path.join(tmp, "trained_classifiers", "mnv2_seed77.pth"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        st.MobileNet = mod.MobileNet  # Trainer(classifier_name='mobilenet') builds it (:1104-1107)
+        gd = torch.Generator().manual_seed(7)
+        batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+        seed_all(42)
+        tr = st.Trainer(name="gold", base_dir=tmp, classifier_name="mobilenet", classifier_path="mnv2_seed77.pth",
+                        tensorboard_dir=None, evaluate_every=10 ** 9, save_every=10 ** 9, image_size=size,
+                        network_capacity=cap, fmap_max=fmax, batch_size=bs, gradient_accumulate_every=gae,
+                        alternating_training=True, lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1)
+        assert isinstance(tr.classifier, mod.MobileNet)
+        # constructing the classifier drew from the global RNG (torch.hub's constructor does too, differently):
+        # re-seed so that the fixture does not depend on how many numbers a model constructor consumes
+        seed_all(42)
+        tr.loader = st.cycle(batches)
+        tr.dataset = list(range(1000))
+        tr.save = lambda *a, **k: None
+        tr.evaluate = lambda *a, **k: None
+        tr.init_StylEx()
+        tr.steps = start
+        tr.pl_mean = pl0
+        logits = tr.classifier.classify_images(batches[0])
+        rows = []
+        for i in range(n):
+            tr.train()
+            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                         tr.last_gp_loss if tr.last_gp_loss is not None else np.nan,
+                         tr.pl_mean if tr.pl_mean is not None else np.nan])
+            print("cfg4", i, rows[-1])
+    finally:
+        os.chdir(cwd)
+    names, pst = param_stats(tr.StylEx)
+    save("steps_cfg4", config=np.array([size, cap, fmax, bs, gae, 1, n, start]), pl_mean0=pl0, data_seed=7, seed=42,
+         cls_seed=77, lpips_seed=4242, scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst,
+         logits_batch0=logits)
+
+
+def gen_diffaug(st):
+    """N2: DiffAugment (stylex/diff_augment.py) per augmentation type and through AugWrapper.forward (:558-571: the
+    random() gate, random_hflip, DiffAugment) on a non-square batch; seeds recorded, CPU generator."""
+    da = ref_shim._load_by_path("ref_diff_augment", os.path.join(ref_shim.REF_STYLEX, "diff_augment.py"))
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 3, 16, 12, generator=g)
+    r = torch.randn(3, 3, 16, 12, generator=g)
+    out = {"x": x, "r": r, "types": np.array(sorted(da.AUGMENT_FNS))}
+    for i, t in enumerate(sorted(da.AUGMENT_FNS)):
+        for rep in range(2):
+            seed_all(900 + 10 * i + rep)
+            xr = x.clone().requires_grad_()
+            y = da.DiffAugment(xr, types=[t])
+            (y * r).sum().backward()
+            out["%s/%d/y" % (t, rep)], out["%s/%d/gx" % (t, rep)] = y, xr.grad
+            out["%s/%d/seed" % (t, rep)] = 900 + 10 * i + rep
+
+    class Ident(torch.nn.Module):
+        def forward(self, im):
+            return im
+
+    wrap = st.AugWrapper(Ident(), 16)
+    for k in range(6):
+        seed_all(950 + k)
+        out["wrap/%d/y" % k] = wrap(x, prob=0.7, types=["translation", "cutout"], detach=True)
+        out["wrap/%d/after" % k] = np.array([random.random(), float(torch.rand(()))])  # RNG consumption
+    save("diffaug", **out)
 
 
 def gen_curve(st, n=100):
@@ -291,13 +373,18 @@ def gen_curve(st, n=100):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="init,ops,nets,losses,steps")
+    ap.add_argument("--step-cases", default="", help="comma list of STEP_CASES tags (default: all)")
     a = ap.parse_args()
     st = ref_shim.import_reference()
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
-                     ("steps", gen_steps), ("curve", gen_curve)):
+                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("diffaug", gen_diffaug),
+                     ("curve", gen_curve)):
         if name in todo:
-            fn(st)
+            if name == "steps" and a.step_cases:
+                fn(st, set(a.step_cases.split(",")))
+            else:
+                fn(st)
 
 
 if __name__ == "__main__":

@@ -182,3 +182,62 @@ def make_reference_trainer(st, base_dir, classifier, batches, **kw):
     tr.save = lambda *a, **k: None
     tr.evaluate = lambda *a, **k: None
     return tr
+
+
+def _load_by_path(name, path):
+    import importlib.util
+
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _tv_models():
+    """The product's in-repo torchvision-compatible architecture definitions, loaded by path (its directory is not
+    put on sys.path: module names there collide with the reference's)."""
+    return _load_by_path("stylex_amd_tv_models", os.path.join(os.path.dirname(_HERE),
+                                                             "explaining-in-style-reproducibility-study_amd", "stylex",
+                                                             "tv_models.py"))
+
+
+def seeded_mobilenet_state(seed=77, output_size=2):
+    """State dict of a MobileNetV2 (torchvision key layout, 2-logit head) with seeded random weights AND non-trivial
+    BatchNorm statistics — the stand-in for ``trained_classifiers/<name>`` in the config-4 fixtures (the real
+    torch.hub weights / checkpoints are unavailable offline).  Uses the in-repo architecture definition
+    (tv_models.MobileNetV2): weights only; the forward that the golden records is the reference wrapper's."""
+    MobileNetV2 = _tv_models().MobileNetV2
+    state = torch.random.get_rng_state()
+    try:
+        torch.manual_seed(seed)
+        model = MobileNetV2()
+        model.classifier[1] = nn.Linear(1280, output_size)
+        g = torch.Generator().manual_seed(seed + 1)
+        for m in model.modules():
+            if isinstance(m, nn.Conv2d):  # He init: default-initialised, the 53-layer net maps every input to the same logits
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                with torch.no_grad():
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+                with torch.no_grad():
+                    m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+        with torch.no_grad():
+            model.classifier[1].weight.copy_(torch.randn(output_size, 1280, generator=g) * 0.05)
+    finally:
+        torch.random.set_rng_state(state)
+    return model.state_dict()
+
+
+def import_reference_mobilenet():
+    """The reference's own ``MobileNet`` wrapper class (stylex/mobilenet_classifier.py:28-73) with
+    ``torch.hub.load`` replaced by the in-repo architecture (no network)."""
+    import_reference()  # installs the torchvision stubs
+    MobileNetV2 = _tv_models().MobileNetV2
+    torch.hub.load = lambda *a, **k: MobileNetV2()
+    return _load_by_path("ref_mobilenet_classifier", os.path.join(REF_STYLEX, "mobilenet_classifier.py"))

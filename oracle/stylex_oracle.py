@@ -433,6 +433,29 @@ def classifier_kl_loss(real_logits, fake_logits):
 # --------------------------------------------------------------------------
 
 
+class OFrozenClassifier:
+    """classify_images of the two frozen-classifier wrappers, restated:
+    kind='mobilenet' (stylex/mobilenet_classifier.py:57-73): F.interpolate(images, size=image_size) — nearest, the
+    identity at native size — then ImageNet normalisation, then the network;
+    kind='resnet' (stylex/resnet_classifier.py:56-71): torchvision resize to 224x224 (= bilinear, align_corners=False,
+    no antialias on tensors in 0.11.1), normalisation, network.  `model` is any nn.Module in eval mode."""
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def __init__(self, model, kind, image_size, normalize=True):
+        self.model, self.kind, self.image_size, self.normalize = model.eval(), kind, image_size, normalize
+        for p in self.model.parameters():
+            p.requires_grad = False
+
+    def classify_images(self, images):
+        if self.kind == "mobilenet":
+            x = F.interpolate(images, size=self.image_size)
+        else:
+            x = F.interpolate(images, size=[224, 224], mode="bilinear", align_corners=False)
+        if self.normalize:
+            x = (x - torch.tensor(self.MEAN).view(1, 3, 1, 1)) / torch.tensor(self.STD).view(1, 3, 1, 1)
+        return self.model(x)
+
+
 class NanException(Exception):
     pass
 

@@ -41,8 +41,11 @@ def test_train_from_folder_cpu(tmp_path):
     rng = np.random.RandomState(0)
     for i in range(6):
         Image.fromarray(rng.randint(0, 255, (40, 48, 3), dtype=np.uint8)).save(data / f"{i}.png")
-    cli.train_from_folder(data=str(data), results_dir=str(tmp_path / "results"), models_dir=str(tmp_path / "models"),
-                          name="t", new=True, image_size=32, network_capacity=4, fmap_max=64, batch_size=2,
+    # positional use as python-fire / a direct caller passes them (reference cli.py:84: data, results_dir,
+    # models_dir, name, new, ...)
+    with pytest.raises(TypeError):
+        cli.train_from_folder(str(data), data=str(data))
+    cli.train_from_folder(str(data), str(tmp_path / "results"), str(tmp_path / "models"), "t", True, image_size=32, network_capacity=4, fmap_max=64, batch_size=2,
                           gradient_accumulate_every=2, num_train_steps=1, num_workers=0, save_every=1,
                           evaluate_every=1, tensorboard_dir=None, classifier_path=None)
     assert (tmp_path / "models" / "t" / "model_0.pt").exists()

@@ -18,7 +18,7 @@ import stylex_train as st  # noqa: E402
 from conftest import load_golden  # noqa: E402
 from lpips_standin import LPIPSStandIn  # noqa: E402
 from test_oracle_vs_golden import build_nets_model, close_stats  # noqa: E402
-from test_host_logic_cpu import make_trainer, run_steps  # noqa: E402
+from test_host_logic_cpu import assert_param_stats, make_cfg4_trainer, make_trainer, run_steps  # noqa: E402
 
 DEV = "cuda:0"
 TOL32, TOLBF = 2e-5, 4e-2
@@ -508,7 +508,7 @@ def test_gp_and_pl_double_backward_vs_reference_golden():
     close(g["pl/grad_w"], w.grad, 5e-4, "pl grad w")
 
 
-@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl"])
+@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl", "gae2_aug"])
 def test_trainer_step_parity_gpu(tag, tmp_path):
     """Trainer.train() on the HIP path reproduces the reference's loss scalars (1e-3, north_star)."""
     g = load_golden("steps_" + tag)
@@ -517,6 +517,79 @@ def test_trainer_step_parity_gpu(tag, tmp_path):
     gold = g["scalars"]
     np.testing.assert_allclose(rows[0], gold[0], rtol=2e-4, atol=2e-5, equal_nan=True)
     np.testing.assert_allclose(rows, gold, rtol=2e-3, atol=2e-3, equal_nan=True)
+    # all 226 parameter tensors after the last step vs the reference's: sums to 2e-3 of the abs-sum; single elements to
+    # n * lr_D (an element whose gradient is summation-order noise takes a +-lr Adam step in either direction)
+    assert_param_stats(tr, g, head_atol=n * 3e-4)
+
+
+def test_config4_mobilenet_pl_step_parity_gpu(tmp_path):
+    """BASELINE config 4 in miniature on the HIP path: Trainer(classifier_name='mobilenet') with the MobileNetV2
+    checkpoint on the GPU, R1 + path-length step (both double backwards), vs the reference's Trainer + its own
+    MobileNet wrapper (tests/golden/steps_cfg4.npz)."""
+    g = load_golden("steps_cfg4")
+    tr, n, batches = make_cfg4_trainer(g, tmp_path, device=torch.device(DEV))
+    close(g["logits_batch0"], tr.classifier.classify_images(batches[0].to(DEV)), 1e-4, "MobileNetV2 logits")
+    rows = run_steps(tr, n)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=2e-4, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=2e-3, atol=2e-3, equal_nan=True)
+    assert_param_stats(tr, g, head_atol=n * 3e-4)
+
+
+def test_block_level_goldens_on_hip():
+    """GeneratorBlock (transposed noise, toRGB + upsample), DiscriminatorBlock and StyleVectorizer of tests/golden/
+    ops.npz (captured from the reference's modules with their own weights) through the HIP modules."""
+    g = load_golden("ops")
+
+    def load_sd(mod, prefix):
+        mod.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)})
+        return mod.to(DEV)
+
+    blk = load_sd(st.GeneratorBlock(20, 8, 12, upsample=True, upsample_rgb=True), "gblock/sd/")
+    xo, rgb, sc = blk(*(torch.from_numpy(g["gblock/" + n]).to(DEV) for n in ("x", "prev", "istyle", "inoise")))
+    close(g["gblock/xo"], xo, what="gblock x")
+    close(g["gblock/rgb"], rgb, what="gblock rgb")
+    close(g["gblock/coords"], sc, what="gblock coords")
+    with torch.no_grad():  # the fused fast path (one kernel per conv) must agree as well
+        xo2, rgb2, _ = blk(*(torch.from_numpy(g["gblock/" + n]).to(DEV) for n in ("x", "prev", "istyle", "inoise")))
+    close(g["gblock/xo"], xo2, what="gblock x (fused)")
+    close(g["gblock/rgb"], rgb2, what="gblock rgb (fused)")
+    dblk = load_sd(st.DiscriminatorBlock(6, 10, downsample=True), "dblock/sd/")
+    x = torch.from_numpy(g["dblock/x"]).to(DEV)
+    close(g["dblock/y"], dblk(x), what="dblock")
+    with torch.no_grad():
+        close(g["dblock/y"], dblk(x), what="dblock (fused)")
+    torch.manual_seed(int(g["svec/seed"]))
+    sv = st.StyleVectorizer(24, 8, lr_mul=0.1).to(DEV)
+    close(g["svec/w"], sv(torch.from_numpy(g["svec/z"]).to(DEV)), what="style vectorizer")
+    g32 = load_golden("nets_32")
+    prev = ops.use_impl(ops.HipOps)
+    m = build_nets_model(g32, cls=st.StylEx).to(DEV)
+    ops.use_impl(prev)
+    close(g32["s_out"], m.S(torch.from_numpy(g32["w"]).to(DEV)[:, 0]), what="S(w) of nets_32")
+
+
+def test_bf16_step_band_vs_reference_golden(tmp_path):
+    """The benchmarked mode (bf16 MFMA operands + bf16 activation tensors) against the fp32 reference trajectory
+    steps_gae2_alt.  Band for the first train() call: every conv rounds its two operands to bf16 (relative 2^-9
+    each); a loss scalar sits behind ~30 chained convs of forward (+ as many of backward for the penalty), a random
+    walk of sqrt(60)*2^-8 = 3e-2, so 5e-2 of max(1,|x|) for the hinge / rec / kl terms; the gradient penalty is a
+    squared norm of a double-rounded gradient: 1e-1.  Later calls of an untrained GAN are chaotic (the reference
+    against itself at another thread count leaves 1e-3 at call 4): finite, and of the golden's order of magnitude."""
+    g = load_golden("steps_gae2_alt")
+    ops.set_precision("bf16")
+    try:
+        tr, n = make_trainer(g, tmp_path, device=torch.device(DEV))
+        rows = run_steps(tr, n)
+    finally:
+        ops.set_precision("fp32")
+    gold = g["scalars"]
+    print("bf16 rows\n", rows, "\ngolden\n", gold)
+    scale = np.maximum(1.0, np.abs(gold[0, :4]))
+    assert (np.abs(rows[0, :4] - gold[0, :4]) <= 5e-2 * scale).all(), (rows[0], gold[0])
+    assert abs(rows[0, 4] - gold[0, 4]) <= 1e-1 * max(1.0, abs(gold[0, 4])), (rows[0, 4], gold[0, 4])
+    assert np.isfinite(rows[:, :5]).all()
+    assert np.abs(rows[:, :4]).max() <= 10 * np.abs(gold[:, :4]).max()
 
 
 def test_loss_curve_short_horizon_vs_reference():

@@ -91,10 +91,11 @@ def make_trainer(g, tmp_path, device=None):
     torch.manual_seed(seed)
     np.random.seed(seed)
     random.seed(seed)
+    aug = float(g["aug_prob"]) if "aug_prob" in g.files else 0.
     tr = st.Trainer(name="t", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax,
                     batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4,
                     ttur_mult=1.5, rec_scaling=1, kl_scaling=1, classifier=cls, lpips_fn=lp, classifier_name="resnet",
-                    evaluate_every=10 ** 9, save_every=10 ** 9, device=device)
+                    evaluate_every=10 ** 9, save_every=10 ** 9, device=device, aug_prob=aug)
     tr.loader = st.cycle(batches)
     tr.dataset = list(range(1000))
     tr.save = lambda *a, **k: None
@@ -104,6 +105,59 @@ def make_trainer(g, tmp_path, device=None):
     pl0 = float(g["pl_mean0"])
     tr.pl_mean = None if np.isnan(pl0) else pl0
     return tr, n
+
+
+def make_cfg4_trainer(g, tmp_path, device=None):
+    """BASELINE config 4 in miniature: Trainer(classifier_name='mobilenet') loading a MobileNetV2 checkpoint from
+    ./trained_classifiers (seeded stand-in weights, oracle/ref_shim.py), path-length + R1 step."""
+    import os
+
+    from ref_shim import seeded_mobilenet_state
+
+    size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
+    os.makedirs(os.path.join(str(tmp_path), "trained_classifiers"), exist_ok=True)
+    torch.save(seeded_mobilenet_state(int(g["cls_seed"])), os.path.join(str(tmp_path), "trained_classifiers", "mnv2.pth"))
+    gd = torch.Generator().manual_seed(int(g["data_seed"]))
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    lp = LPIPSStandIn(seed=int(g["lpips_seed"]))
+    if device is not None:
+        lp = lp.to(device)
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        tr = st.Trainer(name="t", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax,
+                        batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4,
+                        ttur_mult=1.5, rec_scaling=1, kl_scaling=1, lpips_fn=lp, classifier_name="mobilenet",
+                        classifier_path="mnv2.pth", evaluate_every=10 ** 9, save_every=10 ** 9, device=device,
+                        rank=0)
+    finally:
+        os.chdir(cwd)
+    assert isinstance(tr.classifier, st.MobileNet)
+    torch.manual_seed(seed)  # the fixture re-seeds after the classifier is built (see gen_cfg4)
+    np.random.seed(seed)
+    random.seed(seed)
+    if device is not None:
+        assert next(tr.classifier.model.parameters()).device.type == device.type
+    tr.loader = st.cycle(batches)
+    tr.dataset = list(range(1000))
+    tr.save = lambda *a, **k: None
+    tr.evaluate = lambda *a, **k: None
+    tr.init_StylEx()
+    tr.steps = start
+    tr.pl_mean = float(g["pl_mean0"])
+    return tr, n, batches
+
+
+def assert_param_stats(tr, g, tol=2e-3, head_atol=1e-4):
+    """post-step parameter checksums of the golden: after N Adam steps an element may legitimately differ by a
+    fraction of lr (2e-4)"""
+    params = dict(tr.StylEx.named_parameters())
+    for name, gs in zip(g["param_names"], g["param_stats"]):
+        close_stats(gs, params[str(name)].detach().cpu(), tol, head_atol=head_atol)
 
 
 def run_steps(tr, n):
@@ -116,7 +170,7 @@ def run_steps(tr, n):
     return np.array(rows, dtype=np.float64)
 
 
-@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl"])
+@pytest.mark.parametrize("tag", ["gae1_alt", "gae2_alt", "gae2_noalt", "gae2_pl", "gae2_aug"])
 def test_trainer_step_parity_cpu(tag, tmp_path):
     g = load_golden("steps_" + tag)
     tr, n = make_trainer(g, tmp_path)
@@ -124,10 +178,58 @@ def test_trainer_step_parity_cpu(tag, tmp_path):
     gold = g["scalars"]
     np.testing.assert_allclose(rows[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
     np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
-    params = dict(tr.StylEx.named_parameters())
-    for name, gs in zip(g["param_names"], g["param_stats"]):
-        # after N Adam steps an element may legitimately differ by a fraction of lr (2e-4)
-        close_stats(gs, params[str(name)], 2e-3, head_atol=1e-4)
+    assert_param_stats(tr, g)
+
+
+def test_config4_mobilenet_pl_step_parity_cpu(tmp_path):
+    """BASELINE config 4 (MobileNetV2 classifier, R1 + path-length step) against the reference's own Trainer +
+    MobileNet wrapper (tests/golden/steps_cfg4.npz, oracle/make_golden.py::gen_cfg4)."""
+    g = load_golden("steps_cfg4")
+    tr, n, batches = make_cfg4_trainer(g, tmp_path)
+    close(g["logits_batch0"], tr.classifier.classify_images(batches[0]), 1e-5)
+    rows = run_steps(tr, n)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
+    assert_param_stats(tr, g)
+
+
+def test_missing_classifier_checkpoint_raises(tmp_path, monkeypatch):
+    """A named classifier checkpoint that does not exist is an error (as in the reference, where torch.load raises),
+    never a silent random-weight classifier; None is the explicit opt-in used by the synthetic benchmarks."""
+    monkeypatch.chdir(tmp_path)
+    for name in ("resnet", "mobilenet"):
+        with pytest.raises(FileNotFoundError):
+            st.Trainer(name="x", base_dir=str(tmp_path), image_size=32, classifier_name=name,
+                       classifier_path="does-not-exist.pth", device=torch.device("cpu"))
+    st.Trainer(name="x", base_dir=str(tmp_path), image_size=32, classifier_name="mobilenet", classifier_path=None,
+               device=torch.device("cpu"))
+
+
+def test_a20_helpers_exported():
+    """reference :269-293: raise_if_nan, gradient_accumulate_contexts, loss_backwards keep their names/semantics."""
+    with pytest.raises(st.NanException):
+        st.raise_if_nan(torch.tensor(float("nan")))
+    st.raise_if_nan(torch.tensor(1.0))
+    entered = []
+
+    class FakeDDP:
+        def no_sync(self):
+            from contextlib import contextmanager
+
+            @contextmanager
+            def cm():
+                entered.append(1)
+                yield
+
+            return cm()
+
+    assert sum(1 for _ in st.gradient_accumulate_contexts(3, True, [FakeDDP(), FakeDDP()])) == 3
+    assert len(entered) == 4  # no_sync on every micro-step but the last, for both wrappers
+    assert sum(1 for _ in st.gradient_accumulate_contexts(3, False, [FakeDDP()])) == 3 and len(entered) == 4
+    w = torch.ones(2, requires_grad=True)
+    st.loss_backwards(False, (w * 3).sum(), None, 0)
+    assert torch.equal(w.grad, torch.full((2,), 3.0))
 
 
 def test_checkpoint_roundtrip(tmp_path):
@@ -157,9 +259,10 @@ def test_checkpoint_with_training_state(tmp_path):
     tr.save_every = 10 ** 9
     for _ in range(2):
         tr.train()
-    tr.pl_mean = 0.25
+    tr.pl_mean = np.float32(0.25)  # what np.mean() hands back: must not end up in the pickle (weights_only load)
     st.Trainer.save(tr, 7)
-    ck = torch.load(tr.model_name(7), weights_only=False)
+    ck = torch.load(tr.model_name(7), weights_only=True)
+    assert type(ck["training_state"]["pl_mean"]) is float
     assert {"StylEx", "version", "training_state"} == set(ck.keys())
     tr2, _ = make_trainer(g, tmp_path)
     tr2.save_training_state = True

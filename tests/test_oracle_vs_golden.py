@@ -191,9 +191,9 @@ def test_loss_parity():
     close(g["rec/value"], so.reconstruction_loss(lp, i1, i2, w2, w1), 1e-6)
 
 
-def run_oracle_steps(g):
+def run_oracle_steps(g, cls=None):
     size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
-    cls = TinyClassifier(seed=int(g["cls_seed"]))
+    cls = cls or TinyClassifier(seed=int(g["cls_seed"]))
     gd = torch.Generator().manual_seed(int(g["data_seed"]))
     batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
 
@@ -236,4 +236,26 @@ def test_step_parity(tag):
     for n, gs in zip(g["param_names"], g["param_stats"]):
         # after N Adam steps an element may differ by a fraction of lr (2e-4) when the summation order
         # (thread count) differs
+        close_stats(gs, params[str(n)], 2e-3, head_atol=1e-4)
+
+
+def test_step_parity_config4_mobilenet():
+    """BASELINE config 4 in miniature (MobileNetV2 wrapper, R1 + path-length step): the oracle, with its restatement
+    of MobileNet.classify_images, reproduces what the reference's Trainer + its own wrapper class produced."""
+    import ref_shim
+
+    g = load_golden("steps_cfg4")
+    net = ref_shim._tv_models().MobileNetV2()
+    net.classifier[1] = torch.nn.Linear(1280, 2)
+    net.load_state_dict(ref_shim.seeded_mobilenet_state(int(g["cls_seed"])))
+    cls = so.OFrozenClassifier(net, "mobilenet", image_size=int(g["config"][0]))
+    gd = torch.Generator().manual_seed(int(g["data_seed"]))
+    first = torch.rand(int(g["config"][3]), 3, int(g["config"][0]), int(g["config"][0]), generator=gd)
+    close(g["logits_batch0"], cls.classify_images(first), 1e-5)
+    tr, rows = run_oracle_steps(g, cls)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=2e-5, atol=2e-6, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
+    params = dict(tr.model.named_parameters())
+    for n, gs in zip(g["param_names"], g["param_stats"]):
         close_stats(gs, params[str(n)], 2e-3, head_atol=1e-4)
