@@ -247,12 +247,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 for (int r = 0; r < 16; ++r) {
                     const int pix = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float v = acc[i][j][r] * osc + bias;
-                    if (EPIX && (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL))) {
+                    if (EPIX && (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE))) {
                         const int ph = pix / TW, pw = pix - ph * TW;
                         const int y = min(y0 + ph, H - 1), x = min(x0 + pw, W - 1);
                         if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
                         if ((p.flags & STYLEX_EPI_RESIDUAL) && nok)
                             v = (v + act_ld1(p.residual, ((long)(b * H + y) * W + x) * p.N + n, p.act_bf16)) * p.res_scale;
+                        if ((p.flags & STYLEX_EPI_GATE) && nok)
+                            v = act_ld1(p.residual, ((long)(b * H + y) * W + x) * p.N + n, p.act_bf16) > 0.f ? v : p.res_scale * v;
                     }
                     if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
                     char* d = smem + pix * OROW + (j * 32 + lj) * OUT_ES;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 if (p.flags & STYLEX_EPI_BIAS) v += bias;
                 if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
                 if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
+                if (p.flags & STYLEX_EPI_GATE) v = act_ld1(p.residual, o, p.act_bf16) > 0.f ? v : p.res_scale * v;
                 if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
                 act_st1(p.y, o, v, p.act_bf16);
             }
@@ -340,7 +343,7 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
     const bool wide = p.Wo >= 32;
-    const bool epix = (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL)) != 0;
+    const bool epix = (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE)) != 0;
     if (p.act_bf16) {
         if (p.s2d_c) {  // always N >= 64 here (s2d_c % 64 == 0)
             if (p.N > 32) return wide ? launch_halo<32, 2, true, true, true>(p, s) : launch_halo<16, 2, true, true, true>(p, s);

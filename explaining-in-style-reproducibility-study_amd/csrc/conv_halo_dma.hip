@@ -282,6 +282,8 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         bias[j] = ((p.flags & STYLEX_EPI_BIAS) && n < N) ? p.bias[n] : 0.f;
     }
     unsigned short* yout = reinterpret_cast<unsigned short*>(p.y);
+    const unsigned short* gate = (!S2D && (p.flags & STYLEX_EPI_GATE)) ? reinterpret_cast<const unsigned short*>(p.residual) : nullptr;
+    const float gslope = p.res_scale;
     if (S2D && (p.flags & STYLEX_EPI_RESIDUAL)) {
         // block merge of DiscriminatorBlock (:743): (conv + bias + residual) * res_scale, evaluated in fp32 exactly as the
         // register-staged kernel does — the transpose scratch holds fp32 here (32 px x BN x 4 B per wave)
@@ -340,8 +342,21 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
             const int px = id / (BN / 8), q = id % (BN / 8);
             const int x = x0 + px, n = n0 + q * 8;
             if (y < H && x < W && n < N) {
-                const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * (BN * 2) + q * 16);
-                *reinterpret_cast<uint4*>(yout + ((long)(b * H + y) * W + x) * N + n) = v;
+                uint4 v = *reinterpret_cast<const uint4*>(scratch + px * (BN * 2) + q * 16);
+                const long o = ((long)(b * H + y) * W + x) * N + n;
+                if (gate) {  // activation derivative of the layer below: dx *= (gate > 0 ? 1 : slope), 8 channels per lane
+                    const uint4 gv = *reinterpret_cast<const uint4*>(gate + o);
+                    auto g2 = [&](unsigned u, unsigned g) -> unsigned {
+                        const float a = __uint_as_float(u << 16), c = __uint_as_float(u & 0xffff0000u);
+                        const float ga = __uint_as_float(g << 16), gc = __uint_as_float(g & 0xffff0000u);
+                        return (unsigned)to_bf16(ga > 0.f ? a : gslope * a) | ((unsigned)to_bf16(gc > 0.f ? c : gslope * c) << 16);
+                    };
+                    v.x = g2(v.x, gv.x);
+                    v.y = g2(v.y, gv.y);
+                    v.z = g2(v.z, gv.z);
+                    v.w = g2(v.w, gv.w);
+                }
+                *reinterpret_cast<uint4*>(yout + o) = v;
             }
         }
     }
@@ -373,8 +388,9 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
     static const bool on_s2d = !(getenv("STYLEX_HALO_DMA_S2D") && getenv("STYLEX_HALO_DMA_S2D")[0] == '0');
     if (!on) return STYLEX_NOT_APPLICABLE;
     if (!p.act_bf16 || p.a_scale) return STYLEX_NOT_APPLICABLE;
-    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | (p.s2d_c ? STYLEX_EPI_RESIDUAL : 0)))
+    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | (p.s2d_c ? STYLEX_EPI_RESIDUAL : STYLEX_EPI_GATE)))
         return STYLEX_NOT_APPLICABLE;
+    if ((p.flags & STYLEX_EPI_GATE) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15))) return STYLEX_NOT_APPLICABLE;
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
         (reinterpret_cast<uintptr_t>(p.y) & 15))

@@ -198,7 +198,7 @@ __device__ __forceinline__ float blur_coef(int o, int i, int n) {
 
 template <int V>
 __global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C, int bf,
-                                   int s2d) {
+                                   int s2d, const void* __restrict__ gate, float gslope) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -220,6 +220,14 @@ __global__ void blur3x3_bwd_kernel(const void* __restrict__ dy, void* __restrict
                 Vec<V>::fma(acc, ch * cw * (1.f / 16.f),
                             Vec<V>::ld(dy, s2d ? s2d_off(b, oh, ow, c, H, W, C) : base + ((long)oh * W + ow) * C, bf));
             }
+        }
+        if (gate) {  // derivative of the (Leaky)ReLU that produced the blurred tensor, fused into the adjoint
+            float a[V], g[V];
+            *reinterpret_cast<typename Vec<V>::T*>(a) = acc;
+            *reinterpret_cast<typename Vec<V>::T*>(g) = Vec<V>::ld(gate, pix * C + c, bf);
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] = g[e] > 0.f ? a[e] : gslope * a[e];
+            acc = *reinterpret_cast<typename Vec<V>::T*>(a);
         }
         Vec<V>::st(dx, pix * C + c, acc, bf);
     }
@@ -255,6 +263,28 @@ __global__ void subsample2_bwd_kernel(const void* __restrict__ dy, void* __restr
     }
 }
 
+// dst[b, 2i, 2j, :] += src[b, i, j, :]  (in place; dst full resolution [B,H,W,C], src [B,ceil(H/2),ceil(W/2),C]).
+// The merge of a DiscriminatorBlock's two input gradients: the 3x3 path's data gradient (dst) and the adjoint of the
+// even-pixel gather of the 1x1/stride-2 residual conv (zero insertion of src) — without materialising the
+// zero-inserted tensor and without a full-resolution add.
+template <int V>
+__global__ void add_at_even_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H, int W, int C, int bf) {
+    const int cv = C / V, Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+    const long total = (long)B * Ho * Wo * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cq, ow, oh, b;
+        const long pix = decomp_index(i, cv, Wo, Ho, cq, ow, oh, b);
+        const int c = cq * V;
+        const long o = (((long)b * H + 2 * oh) * W + 2 * ow) * C + c;
+        float a[V], d[V];
+        *reinterpret_cast<typename Vec<V>::T*>(a) = Vec<V>::ld(src, pix * C + c, bf);
+        *reinterpret_cast<typename Vec<V>::T*>(d) = Vec<V>::ld(dst, o, bf);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] += a[e];
+        Vec<V>::st(dst, o, *reinterpret_cast<typename Vec<V>::T*>(d), bf);
+    }
+}
+
 // ---- bf16 column-strip blur (forward and adjoint) ---------------------------------------------
 // One lane owns 8 channels of one column and walks ROWS output rows with a 3-row sliding window of
 // horizontally filtered values, so every input row is fetched once per strip (+2 halo rows) instead of three
@@ -279,7 +309,7 @@ __device__ __forceinline__ void blur_tap(int pos, int d, int n, int& idx, float&
 template <bool ADJ, int ROWS>
 __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short* __restrict__ in,
                                                             unsigned short* __restrict__ out, int B, int H, int W, int C,
-                                                            int s2d) {
+                                                            int s2d, const unsigned short* __restrict__ gate, float gslope) {
     const int cv = C >> 3;
     const int strips = (H + ROWS - 1) / ROWS;
     const long total = (long)B * strips * W * cv;
@@ -321,6 +351,14 @@ __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short
 #pragma unroll
             for (int a = 0; a < 3; ++a) Vec<8>::fma(acc, cv3[a] * (1.f / 16.f), win[a]);
             const long o = out_s2d ? s2d_off(b, h, w, c, H, W, C) : (((long)b * H + h) * W + w) * C + c;
+            if (ADJ && gate) {  // activation derivative fused into the adjoint (see blur3x3_bwd_kernel)
+                float a[8], g[8];
+                *reinterpret_cast<F8*>(a) = acc;
+                *reinterpret_cast<F8*>(g) = Vec<8>::ld(gate, o, 1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = g[e] > 0.f ? a[e] : gslope * a[e];
+                acc = *reinterpret_cast<F8*>(a);
+            }
             Vec<8>::st(out, o, acc, 1);
             win[0] = win[1];
             win[1] = win[2];
@@ -423,13 +461,15 @@ static bool blur_strip_ok(int bf, int H, int C, const void* a, const void* b) {
            ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
 }
 template <bool ADJ>
-static int launch_blur_strip(const void* in, void* out, int B, int H, int W, int C, int s2d, hipStream_t s) {
+static int launch_blur_strip(const void* in, void* out, int B, int H, int W, int C, int s2d, hipStream_t s,
+                             const void* gate = nullptr, float gslope = 0.f) {
     constexpr int ROWS = 8;
     long work = (long)B * ((H + ROWS - 1) / ROWS) * W * (C / 8);
     long blocks = (work + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((blur3x3_strip_kernel<ADJ, ROWS>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       (const unsigned short*)in, (unsigned short*)out, B, H, W, C, s2d);
+                       (const unsigned short*)in, (unsigned short*)out, B, H, W, C, s2d, (const unsigned short*)gate,
+                       gslope);
     return (int)hipGetLastError();
 }
 
@@ -458,11 +498,26 @@ int stylex_blur3x3_reflect_fwd(const void* x, void* y, EW_ARGS) {
     if (blur_strip_ok(bf, H, C, x, y)) return launch_blur_strip<false>(x, y, B, H, W, C, 0, s);
     LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 0);
 }
-int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, EW_ARGS) {
+static int blur_bwd_impl(const void* dy, const void* gate, float gslope, void* dx, int s2d, EW_ARGS) {
     EW_UNPACK
-    if (B <= 0 || H < 2 || W < 2 || C <= 0) return STYLEX_EINVAL;
-    if (blur_strip_ok(bf, H, C, dy, dx)) return launch_blur_strip<true>(dy, dx, B, H, W, C, 0, s);
-    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 0);
+    if (B <= 0 || H < 2 || W < 2 || C <= 0 || (s2d && ((H & 1) || (W & 1)))) return STYLEX_EINVAL;
+    const bool gate_ok = !gate || (reinterpret_cast<uintptr_t>(gate) & 15) == 0;
+    if (gate_ok && blur_strip_ok(bf, H, C, dy, dx)) return launch_blur_strip<true>(dy, dx, B, H, W, C, s2d, s, gate, gslope);
+    if (gate && !gate_ok) {
+        hipLaunchKernelGGL(blur3x3_bwd_kernel<1>, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, dy, dx, B, H, W, C, bf,
+                           s2d, gate, gslope);
+        return (int)hipGetLastError();
+    }
+    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, s2d, gate, gslope);
+}
+int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, EW_ARGS) { return blur_bwd_impl(dy, nullptr, 0.f, dx, 0, sh, act_dtype, stream); }
+int stylex_blur3x3_reflect_bwd_gate(const void* dy, const void* gate, float slope, void* dx, EW_ARGS) {
+    if (!gate) return STYLEX_EINVAL;
+    return blur_bwd_impl(dy, gate, slope, dx, 0, sh, act_dtype, stream);
+}
+int stylex_blur3x3_s2d_bwd_gate(const void* dy, const void* gate, float slope, void* dx, EW_ARGS) {
+    if (!gate) return STYLEX_EINVAL;
+    return blur_bwd_impl(dy, gate, slope, dx, 1, sh, act_dtype, stream);
 }
 int stylex_blur3x3_s2d_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK
@@ -470,12 +525,7 @@ int stylex_blur3x3_s2d_fwd(const void* x, void* y, EW_ARGS) {
     if (blur_strip_ok(bf, H, C, x, y)) return launch_blur_strip<false>(x, y, B, H, W, C, 1, s);
     LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 1);
 }
-int stylex_blur3x3_s2d_bwd(const void* dy, void* dx, EW_ARGS) {
-    EW_UNPACK
-    if (B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
-    if (blur_strip_ok(bf, H, C, dy, dx)) return launch_blur_strip<true>(dy, dx, B, H, W, C, 1, s);
-    LAUNCH_EW(blur3x3_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf, 1);
-}
+int stylex_blur3x3_s2d_bwd(const void* dy, void* dx, EW_ARGS) { return blur_bwd_impl(dy, nullptr, 0.f, dx, 1, sh, act_dtype, stream); }
 int stylex_subsample2_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
@@ -485,6 +535,11 @@ int stylex_subsample2_bwd(const void* dy, void* dx, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
     LAUNCH_EW(subsample2_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
+}
+int stylex_add_at_even(const void* src, void* dst, EW_ARGS) {
+    EW_UNPACK
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || !src || !dst) return STYLEX_EINVAL;
+    LAUNCH_EW(add_at_even_kernel, (long)B * ((H + 1) / 2) * ((W + 1) / 2) * C, src, dst, src, dst, B, H, W, C, bf);
 }
 int stylex_bias_act_fwd(const void* x, const float* bias, const float* noise, int64_t noise_stride,
                         const float* noise_w, const float* noise_b, void* y, EW_ARGS) {

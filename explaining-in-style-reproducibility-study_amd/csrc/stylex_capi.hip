@@ -213,7 +213,8 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
                            void* stream) {
     if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
-    if (flags & ~(STYLEX_EPI_OSCALE)) return STYLEX_EINVAL;
+    if (flags & ~(STYLEX_EPI_OSCALE | STYLEX_EPI_GATE)) return STYLEX_EINVAL;
+    if ((flags & STYLEX_EPI_GATE) && (!epi || !epi->residual)) return STYLEX_EINVAL;
     ConvKParams p;
     bwd_data_params(p, sh);
     p.a = (const float*)dy;
@@ -229,6 +230,8 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
         if (epi) {
             q.a_scale = epi->in_scale;
             q.out_scale = epi->out_scale;
+            q.residual = (const float*)epi->residual;  // gate tensor (STYLEX_EPI_GATE)
+            q.res_scale = epi->res_scale;
             q.s2d_c = (int)epi->s2d_c;
             if (q.s2d_c && (q.N != 4 * q.s2d_c || q.s2d_c % 64)) return STYLEX_EINVAL;
         }
@@ -250,6 +253,8 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
     if (epi) {
         p.a_scale = epi->in_scale;    // [B][N_f] applied to dy (demodulation coefficient)
         p.out_scale = epi->out_scale; // [B][C_f] applied to dx (modulation)
+        p.residual = (const float*)epi->residual;  // gate tensor (STYLEX_EPI_GATE)
+        p.res_scale = epi->res_scale;
     }
     if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
     // algorithmic FLOPs of a data gradient = those of the forward conv

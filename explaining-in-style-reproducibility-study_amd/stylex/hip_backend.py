@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylex_hip.so")
 
 F32, BF16, BF16_ACT = 0, 1, 2  # BF16_ACT: bf16 MFMA + bf16 activation tensors in HBM
-EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL, EPI_RELU = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL, EPI_RELU, EPI_GATE = 1, 2, 4, 8, 16, 32, 64
 
 _c_f = ctypes.c_void_p  # device pointers travel as void*
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -51,6 +51,9 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_reflect_bwd_gate": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_s2d_bwd_gate": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_add_at_even": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_subsample2_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_subsample2_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_pack_weight_s2d": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
@@ -220,15 +223,16 @@ def _cache_put(key, w_param, wf, wb):
     _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream)
 
 
-def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
+def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
     """OIHW fp32 parameter -> K-contiguous operand layouts, fp32 or bf16 according to `precision`.
     Packs of nn.Parameters are cached until the parameter is modified in place (optimizer step):
-    D runs three forwards per step on the same weights."""
+    D runs three forwards per step on the same weights.  `scale`: pack scale * w (a constant folded into the operand,
+    e.g. the 1/sqrt(2) of the residual merge for the backward of a DiscriminatorBlock)."""
     lib = _ensure_device(w)
     cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
     key = None
     if cacheable:
-        key = (w.data_ptr(), w._version, tuple(w.shape), precision)
+        key = (w.data_ptr(), w._version, tuple(w.shape), precision, scale)
         hit = _cache_hit(key, w)
         if hit is not None:
             return hit
@@ -237,6 +241,8 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     w = w.contiguous()
     if w.dtype != torch.float32:
         w = w.float()
+    if scale is not None:
+        w = w.detach() * scale
     n, c, kh, kw = w.shape
     dt = torch.float32 if precision == F32 else torch.bfloat16
     wf = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_fwd else None
@@ -248,16 +254,18 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32):
     return wf, wb
 
 
-def pack_weight_s2d(w):
+def pack_weight_s2d(w, scale=None):
     """OIHW {N,C,3,3} parameter of a stride-2 conv -> bf16 operands of its space-to-depth form (cached)."""
     lib = _ensure_device(w)
     key = None
     if isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32:
-        key = (w.data_ptr(), w._version, tuple(w.shape), "s2d")
+        key = (w.data_ptr(), w._version, tuple(w.shape), "s2d", scale)
         hit = _cache_hit(key, w)
         if hit is not None:
             return hit
     wc = w.contiguous().float()
+    if scale is not None:
+        wc = wc.detach() * scale
     n, c, kh, kw = wc.shape
     assert kh == 3 and kw == 3
     wf = torch.empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
@@ -336,7 +344,9 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
 
 
 def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_scale=None, packed=None, w_shape=None,
-                    s2d_c=0):
+                    s2d_c=0, gate=None, gate_slope=0.2):
+    """`gate` (shape of dx, activation dtype): dx *= (gate > 0 ? 1 : gate_slope) in the kernel's store — the
+    LeakyReLU derivative of the layer that produced this conv's input (which IS the gate tensor)."""
     lib = _ensure_device(dy)
     adt = act_dtype(precision)
     assert is_cl(dy) and dy.dtype == adt, (dy.dtype, adt)
@@ -353,6 +363,11 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     if out_scale is not None:
         flags |= EPI_OSCALE
         epi.out_scale = out_scale.data_ptr()
+    if gate is not None:
+        assert is_cl(gate) and tuple(gate.shape) == tuple(x_shape) and gate.dtype == adt
+        flags |= EPI_GATE
+        epi.residual = gate.data_ptr()
+        epi.res_scale = gate_slope
     shp = _shape(*sh)
     ws, ws_bytes = _split_workspace(lib, shp, 1, precision, dy)
     _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), shp, flags, ctypes.byref(epi), precision,
@@ -414,14 +429,40 @@ def blur3x3_s2d_fwd(x):
     return y
 
 
-def blur3x3_s2d_bwd(dy2):
+def blur3x3_s2d_bwd(dy2, gate=None, slope=0.2):
+    """adjoint of blur3x3_s2d_fwd; with `gate` (the blur's forward input) the LeakyReLU derivative is fused in."""
     lib = _ensure_device(dy2)
     assert is_cl(dy2)
     b, c4, h2, w2 = dy2.shape
     dx = empty_cl((b, c4 // 4, 2 * h2, 2 * w2), dy2)
-    _check(lib.stylex_blur3x3_s2d_bwd(_ptr(dy2), _ptr(dx), _shape(b, 2 * h2, 2 * w2, c4 // 4), _adt(dy2), _stream()),
-           "stylex_blur3x3_s2d_bwd")
+    shp = _shape(b, 2 * h2, 2 * w2, c4 // 4)
+    if gate is None:
+        _check(lib.stylex_blur3x3_s2d_bwd(_ptr(dy2), _ptr(dx), shp, _adt(dy2), _stream()), "stylex_blur3x3_s2d_bwd")
+    else:
+        assert is_cl(gate) and gate.shape == dx.shape and gate.dtype == dy2.dtype
+        _check(lib.stylex_blur3x3_s2d_bwd_gate(_ptr(dy2), _ptr(gate), float(slope), _ptr(dx), shp, _adt(dy2), _stream()),
+               "stylex_blur3x3_s2d_bwd_gate")
     return dx
+
+
+def blur3x3_bwd_gate(dy, gate, slope=0.2):
+    lib = _ensure_device(dy)
+    assert is_cl(dy) and is_cl(gate) and gate.shape == dy.shape and gate.dtype == dy.dtype
+    b, c, h, w = dy.shape
+    dx = empty_cl(tuple(dy.shape), dy)
+    _check(lib.stylex_blur3x3_reflect_bwd_gate(_ptr(dy), _ptr(gate), float(slope), _ptr(dx), _shape(b, h, w, c), _adt(dy),
+                                               _stream()), "stylex_blur3x3_reflect_bwd_gate")
+    return dx
+
+
+def add_at_even_(dst, src):
+    """dst[:, :, ::2, ::2] += src, in place (dst full resolution)."""
+    lib = _ensure_device(dst)
+    assert is_cl(dst) and is_cl(src) and dst.dtype == src.dtype
+    b, c, h, w = dst.shape
+    assert tuple(src.shape) == (b, c, (h + 1) // 2, (w + 1) // 2), (src.shape, dst.shape)
+    _check(lib.stylex_add_at_even(_ptr(src), _ptr(dst), _shape(b, h, w, c), _adt(dst), _stream()), "stylex_add_at_even")
+    return dst
 
 
 def subsample2_fwd(x):

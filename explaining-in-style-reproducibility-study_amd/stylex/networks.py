@@ -198,6 +198,11 @@ class DiscriminatorBlock(nn.Module):  # reference :721-744
         self.downsample = nn.Sequential(Blur(), HipConv2d(filters, filters, 3, padding=1, stride=2)) if downsample else None
 
     def forward(self, x):
+        fused = getattr(ops.impl(), "dblock", None)
+        if fused is not None:  # first-order passes: the whole block is one autograd node (ops._DBlockFast)
+            out = fused(x, self.conv_res, self.net[0], self.net[2], self.downsample[1] if exists(self.downsample) else None)
+            if out is not None:
+                return out
         # the 1x1 residual conv is independent of the two 3x3 convs until the merge: side stream
         side = _side_stream(x)
         if side is None:

@@ -523,6 +523,143 @@ class _DownS2DFast(torch.autograd.Function):
         return gx2, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None
 
 
+class _DBlockFast(torch.autograd.Function):
+    """A whole DiscriminatorBlock (reference :721-744) as ONE autograd node on the fused kernels:
+
+        res = conv1x1_s2(x) + b_r ;  y1 = lrelu(conv3x3(x) + b1) ;  y2 = lrelu(conv3x3(y1) + b2)
+        out = (conv3x3_s2(blur(y2)) + b3 + res) / sqrt(2)              (last block: (y2 + res) / sqrt(2))
+
+    Why one node: the backward can then fuse ACROSS the layers — the LeakyReLU derivative of y1 rides the store of
+    conv2's data gradient and that of y2 the store of the blur adjoint (STYLEX_EPI_GATE: no separate
+    activation-derivative pass over the two largest tensors of the block), the bias gradient of the residual conv and
+    of the down conv is the same reduction, and the gradient of the 1x1/stride-2 path is added into the 3x3 path's
+    input gradient at the even pixels in place (no zero-inserted tensor, no full-resolution add).  First-order only
+    (used when no double backward can be requested, see set_fast)."""
+
+    @staticmethod
+    def forward(ctx, x, w_res, b_res, w1, b1, w2, b2, w3, b3, downsample):
+        c = 1 / math.sqrt(2)
+        x = _cl(_act(x))
+        cin = x.shape[1]
+        if cin == 3:  # RGB input: pad to one 16-byte channel slot (see _pad_rgb); gradients are sliced back
+            x, w1p, _ = _pad_rgb(x, w1)
+            x = _cl(x)
+            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], x.shape[1] - 3, 1, 1)], dim=1)
+        else:
+            w1p, wrp = w1, w_res
+        xs = hb.subsample2_fwd(x) if downsample else x
+        res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
+        y1 = hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True)
+        y2 = hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True)
+        s2d, xb = False, None
+        if downsample:
+            n, h, w = y2.shape[1], y2.shape[2], y2.shape[3]
+            s2d = (_PRECISION != hb.F32 and n % 64 == 0 and h % 2 == 0 and w % 2 == 0 and w // 2 >= 16 and h // 2 >= 16)
+            if s2d:
+                xb = hb.blur3x3_s2d_fwd(y2)
+                wf2, _ = hb.pack_weight_s2d(w3)
+                out = hb.conv2d_fwd(xb, None, 1, 1, _PRECISION, bias=b3, residual=res, res_scale=c, packed=wf2,
+                                    w_shape=(w3.shape[0], 4 * n, 3, 3), s2d_c=n)
+            else:
+                xb = hb.blur3x3_fwd(y2)
+                out = hb.conv2d_fwd(xb, w3, 2, 1, _PRECISION, bias=b3, residual=res, res_scale=c)
+        else:
+            out = (y2 + res) * c
+        ctx.save_for_backward(x, xs if downsample else None, y1, y2, xb, w_res, w1, w2, w3)
+        ctx.cfg = (bool(downsample), s2d, cin, c)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        x, xs, y1, y2, xb, w_res, w1, w2, w3 = ctx.saved_tensors
+        downsample, s2d, cin, c = ctx.cfg
+        if xs is None:
+            xs = x
+        need = ctx.needs_input_grad
+        want_x = need[0]
+        want_b = need[2] or need[4] or need[6] or need[8]  # bias gradients (False for the frozen D of the G phase)
+        want_w = need[1] or need[3] or need[5] or need[7]
+        g_out = _cl(g_out)
+        prec = _PRECISION
+        gw_res = gb_res = gw1 = gb1 = gw2 = gb2 = gw3 = gb3 = gx = None
+        # (. + res) / sqrt(2).  In the bf16 modes the constant c never touches the activation gradient: it is folded
+        # into the packed data-gradient operands (c*w3, c*w_res) and into the (small) weight / bias gradients, which
+        # removes one full pass over the block's output gradient; the fp32 parity mode scales explicitly.
+        alg = downsample and prec != hb.F32
+        if alg:
+            gz3 = g_out
+            gsum3 = _channel_sum(g_out) * c if want_b else None
+        elif _reducible(g_out.shape[1]):
+            gz3, gsum3 = hb.act_bwd_reduce(g_out, None, False, c, want_dx=True, want_sum=want_b)
+        else:
+            gz3 = g_out * c
+            gsum3 = gz3.sum(dim=(0, 2, 3), dtype=torch.float32) if want_b else None
+        wsc = c if alg else 1.0  # factor still owed by gradients computed from the unscaled gz3
+        gb_res = gsum3  # the per-channel sum is the bias gradient of BOTH conv_res and the down conv
+        if downsample:
+            gb3 = gsum3
+            n = y2.shape[1]
+            if s2d:
+                _, wb2 = hb.pack_weight_s2d(w3, scale=c if alg else None)
+                gxb = hb.conv2d_bwd_data(gz3, None, tuple(xb.shape), 1, 1, prec, packed=wb2, w_shape=(w3.shape[0], 4 * n, 3, 3),
+                                         s2d_c=n)
+                if want_w:
+                    gw3 = hb.fold_weight_grad_s2d(hb.conv2d_bwd_weight(xb, gz3, (w3.shape[0], 4 * n, 3, 3), 1, 1, prec, s2d_c=n),
+                                                  tuple(w3.shape))
+                gz2 = hb.blur3x3_s2d_bwd(gxb, gate=y2)  # blur adjoint + LeakyReLU derivative of y2 in one pass
+            else:
+                wb3 = hb.pack_weight(w3, False, True, prec, scale=c)[1] if alg else None
+                gxb = hb.conv2d_bwd_data(gz3, w3, tuple(xb.shape), 2, 1, prec, packed=wb3, w_shape=tuple(w3.shape))
+                if want_w:
+                    gw3 = hb.conv2d_bwd_weight(xb, gz3, tuple(w3.shape), 2, 1, prec)
+                gz2 = hb.blur3x3_bwd_gate(gxb, y2)
+            if want_w and alg:
+                gw3 = gw3 * wsc
+        else:
+            gz2 = hb.bias_act_bwd(gz3, y2)
+        if want_b:
+            gb2 = _channel_sum(gz2)
+        if want_w:
+            gw2 = hb.conv2d_bwd_weight(y1, gz2, tuple(w2.shape), 1, 1, prec)
+        gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1)  # + LeakyReLU derivative of y1
+        if want_b:
+            gb1 = _channel_sum(gz1)
+        if cin == 3:  # x was saved padded; only the weights need padding again
+            extra = x.shape[1] - 3
+            w1p = torch.cat([w1, w1.new_zeros(w1.shape[0], extra, 3, 3)], dim=1)
+            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], extra, 1, 1)], dim=1)
+        else:
+            w1p, wrp = w1, w_res
+        if want_w:
+            gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec)
+            gw_res = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec)
+            if alg:
+                gw_res = gw_res * wsc
+            if cin == 3:
+                gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
+        if want_x:
+            gx = hb.conv2d_bwd_data(gz1, w1p, tuple(x.shape), 1, 1, prec)
+            wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
+            gxs = hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+            if downsample:
+                hb.add_at_even_(gx, gxs)  # adjoint of the even-pixel gather, summed in place
+            else:
+                gx += gxs
+            if cin == 3:
+                gx = gx[:, :3]
+        return (gx, gw_res if need[1] else None, gb_res if need[2] else None, gw1 if need[3] else None,
+                gb1 if need[4] else None, gw2 if need[5] else None, gb2 if need[6] else None,
+                gw3 if need[7] else None, gb3 if need[8] else None, None)
+
+
+def _channel_sum(t):
+    """per-channel sum over (b, h, w) in fp32 (bias gradient): read-only reduction kernel, fixed order."""
+    if _reducible(t.shape[1]):
+        return hb.act_bwd_reduce(t, None, False, 1.0, want_dx=False, want_sum=True)[1]
+    return t.sum(dim=(0, 2, 3), dtype=torch.float32)
+
+
 # ------------------------------------------------------------------------------------------
 # the HIP implementation object
 # ------------------------------------------------------------------------------------------
@@ -644,6 +781,18 @@ class HipOps:
     @staticmethod
     def residual_merge(x, res):
         return (x + res) * (1 / math.sqrt(2))
+
+    @staticmethod
+    def dblock(x, conv_res, conv1, conv2, down):
+        """Whole DiscriminatorBlock as one fused autograd node, or None when the composable path must run (a double
+        backward may be requested, or STYLEX_DBLOCK=0)."""
+        if not fast_enabled() or os.environ.get("STYLEX_DBLOCK", "1") == "0":
+            return None
+        if conv1.weight.shape[0] % 4 != 0:
+            return None
+        return _DBlockFast.apply(x, conv_res.weight, conv_res.bias, conv1.weight, conv1.bias, conv2.weight, conv2.bias,
+                                 down.weight if down is not None else None, down.bias if down is not None else None,
+                                 down is not None)
 
     @staticmethod
     def rowwise_sumsq(x2d):

@@ -1059,7 +1059,7 @@ class Trainer:
             entry = self._capture(apply_gp, gae, [group], [(reals, micro_d)], [(micro_g, [])])
             self._graph_cache[apply_gp] = entry
         graphs, out = entry
-        syncs = [self._d_sync.all_reduce, self._g_sync.all_reduce, None] if self.is_ddp else [None]
+        syncs = [self._d_sync.all_reduce, self._g_sync.all_reduce, None] if self.is_ddp else [None, None, None]
         for g, sync in zip(graphs, syncs):
             g.replay()
             if sync is not None:
@@ -1068,8 +1068,8 @@ class Trainer:
         return out
 
     def _capture(self, apply_gp, gae, groups, d_in, g_in):
-        """Capture the step as HIP graph(s): one graph, or under DDP three (D forward/backward | D step + G
-        forward/backward | G step) with the RCCL gradient all-reduces issued between the replays."""
+        """Capture the step as three HIP graphs (D forward/backward | D step + G forward/backward | G step); under
+        DDP the RCCL gradient all-reduces are issued between the replays."""
         m = self.StylEx
         acc = {}
 
@@ -1085,7 +1085,9 @@ class Trainer:
             m.G_opt.step()
             acc["out"] = self._loss_stack(acc)
 
-        segments = [[seg_d], [seg_g], [seg_tail]] if self.is_ddp else [[seg_d, seg_g, seg_tail]]
+        # always three graphs: each phase captures fine on its own, but D phase + G phase in ONE capture with the
+        # branch streams on crashes hipStreamEndCapture (ROCm 7.2, tools/graph_stage_probe.py stage "step")
+        segments = [[seg_d], [seg_g], [seg_tail]]
         torch.cuda.synchronize()
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()

@@ -54,6 +54,9 @@ extern "C" {
 #define STYLEX_EPI_NOISE 8     /* + noise[b][w][h] * noise_w[n] + noise_b[n] (sic: transposed) */
 #define STYLEX_EPI_RESIDUAL 16 /* (acc + residual[m][n]) * res_scale                 */
 #define STYLEX_EPI_RELU 32     /* max(v, 0) last (instead of LRELU; frozen ResNet blocks) */
+#define STYLEX_EPI_GATE 64     /* bwd_data only: dx *= (gate[m][c] > 0 ? 1 : res_scale) — the derivative of the
+                                * (Leaky)ReLU that produced this conv's input, applied while dx is written; the gate
+                                * tensor (= that input, [B][Hi][Wi][C], activation dtype) travels in epi->residual */
 
 /* One-time per-process/per-device initialisation (kernel attributes). */
 int stylex_init(int device);
@@ -108,7 +111,9 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
  * double-backward chain of gradient_penalty, stylex_train.py:296-303). */
 /* Modulated form: epi->in_scale [B][N] scales dy while it is staged (demodulation
  * coefficient) and, with STYLEX_EPI_OSCALE, epi->out_scale [B][C] scales dx
- * (style+1).  flags may only contain STYLEX_EPI_OSCALE; epi may be NULL. */
+ * (style+1).  flags may only contain STYLEX_EPI_OSCALE and STYLEX_EPI_GATE (the activation-derivative pass of the
+ * layer below fused into this launch: reference F.leaky_relu backward, stylex_train.py:724-731); epi may be NULL
+ * when flags == 0. */
 int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const int64_t* shape, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                            void* stream);
@@ -147,6 +152,17 @@ int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, const int64_t* shape, i
  * the s2d conv ([N][4C][3][3]) back to the parameter layout.  H, W even. */
 int stylex_blur3x3_s2d_fwd(const void* x, void* y_s2d, const int64_t* shape, int act_dtype, void* stream);
 int stylex_blur3x3_s2d_bwd(const void* dy_s2d, void* dx, const int64_t* shape, int act_dtype, void* stream);
+/* The two blur adjoints with the activation derivative of the layer below fused into the store:
+ * dx = adjoint(dy) * (gate > 0 ? 1 : slope), gate = the blur's forward input (the LeakyReLU output of
+ * DiscriminatorBlock.net, reference stylex_train.py:726-733), shape/dtype of dx. */
+int stylex_blur3x3_reflect_bwd_gate(const void* dy, const void* gate, float slope, void* dx, const int64_t* shape,
+                                    int act_dtype, void* stream);
+int stylex_blur3x3_s2d_bwd_gate(const void* dy_s2d, const void* gate, float slope, void* dx, const int64_t* shape,
+                                int act_dtype, void* stream);
+/* dst[b,2i,2j,:] += src[b,i,j,:] in place; shape = the FULL-resolution {B,H,W,C} of dst.  Sum of the two input
+ * gradients of a DiscriminatorBlock (3x3 path + zero-inserted gradient of the 1x1/stride-2 conv_res path,
+ * reference stylex_train.py:739-743) without the zero-inserted tensor. */
+int stylex_add_at_even(const void* src, void* dst, const int64_t* shape, int act_dtype, void* stream);
 
 /* Even-pixel gather y[b,i,j,:] = x[b,2i,2j,:] and its adjoint (zero insertion).  shape = the FULL-resolution
  * {B,H,W,C}; the low-resolution tensor is [B,(H+1)/2,(W+1)/2,C].  With these the reference's 1x1 / stride-2

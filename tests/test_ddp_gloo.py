@@ -160,3 +160,130 @@ def test_gradsync_overlapped_matches_manual_average():
     for rank, results in res:
         assert results["armed"][0] < 1e-6 and results["plain"][0] < 1e-6, results
         assert results["armed"][1] >= 2, "no bucket was launched during the backward: %r" % (results,)
+
+
+def _uneven_worker(rank, world, port, q):
+    import torch.nn as nn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import parallel
+
+        torch.manual_seed(0)
+        heads = [nn.Linear(30, 50) for _ in range(6)]  # six independent sub-graphs -> six buckets
+        params = [p for h in heads for p in h.parameters()]
+        sync = parallel.GradSync(params, bucket_bytes=50 * 30 * 4, overlap=True)
+        assert len(sync.buckets) == 6
+        x = torch.randn(8, 30, generator=torch.Generator().manual_seed(10 + rank))
+        order = [(i + 2 * rank) % 6 for i in range(6)]  # every rank finishes its buckets in a different order
+        if rank % 2:
+            order.reverse()
+        # manual average for reference
+        for h in heads:
+            h(x).square().mean().backward()
+        local = torch.cat([p.grad.reshape(-1).clone() for p in params])
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered) / world
+        sync.zero_grad()
+        launch_log = []
+        orig = sync._launch
+        sync._launch = lambda bi: (launch_log.append(bi), orig(bi))[1]
+        sync.arm()
+        for i in order:
+            heads[i](x).square().mean().backward()
+        in_backward = len(launch_log)
+        sync.all_reduce()
+        got = torch.cat([p.grad.reshape(-1) for p in params])
+        views_ok = all(p.grad.data_ptr() == sync._views[id(p)].data_ptr() for p in params)
+        q.put((rank, float((got - want).abs().max()), launch_log, in_backward, views_ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradsync_world4_uneven_bucket_readiness():
+    """Four ranks whose gradients become ready in four different orders: the collectives still go out strictly in
+    bucket-index order on every rank (no cross-rank mismatch / deadlock), the result is the rank average, and the
+    gradients stay views of the persistent flat buckets (no pack / scatter copies)."""
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, log, in_backward, views_ok in res:
+        assert err < 1e-6, (rank, err)
+        assert log == list(range(6)), (rank, log)
+        assert views_ok
+    assert any(r[3] > 0 for r in res)
+
+
+def _nan_worker(rank, world, port, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ops
+        import stylex_train as st
+        from cpu_ops import CpuOracleOps
+        from lpips_standin import LPIPSStandIn
+        from ref_shim import TinyClassifier
+
+        ops.use_impl(CpuOracleOps)
+        size = 16
+        gd = torch.Generator().manual_seed(7 + rank)
+        batches = [torch.rand(2, 3, size, size, generator=gd) for _ in range(8)]
+        tr = st.Trainer(name="n%d" % rank, base_dir=tmp, image_size=size, network_capacity=2, fmap_max=16, batch_size=4,
+                        gradient_accumulate_every=1, classifier=TinyClassifier(seed=99), lpips_fn=LPIPSStandIn(seed=4242),
+                        classifier_name="resnet", evaluate_every=10 ** 9, save_every=10 ** 9, is_ddp=True, rank=rank,
+                        world_size=world, device=torch.device("cpu"))
+        tr.loader = st.cycle(batches)
+        tr.save = lambda *a, **k: None
+        tr.evaluate = lambda *a, **k: None
+        loads = []
+        tr.load = lambda num=-1: loads.append((tr.steps, num))
+        tr.init_StylEx()
+        real_stack = tr._loss_stack
+        events = []
+        for call in range(4):
+            if call == 1 and rank == 1:  # ONLY rank 1 sees a NaN loss, on its second call
+                tr._loss_stack = lambda acc: real_stack(acc) * float("nan")
+            else:
+                tr._loss_stack = real_stack
+            try:
+                tr.train()
+                events.append("ok")
+            except st.NanException:
+                events.append("nan")
+        q.put((rank, events, loads))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_nan_restart_is_collective(tmp_path):
+    """A NaN loss on ONE rank makes EVERY rank take the reload-and-raise path at the same train() call (the flag is
+    MAX-reduced on the device inside the step that produced it), so the collectives of load()/the next step line up."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ev0, loads0), (r1, ev1, loads1) = res
+    assert ev0 == ev1 == ["ok", "ok", "nan", "ok"], (ev0, ev1)  # detected while enqueueing the call after the NaN one
+    assert loads0 == loads1 and len(loads0) == 1

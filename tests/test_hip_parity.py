@@ -574,8 +574,12 @@ def test_bf16_step_band_vs_reference_golden(tmp_path):
     steps_gae2_alt.  Band for the first train() call: every conv rounds its two operands to bf16 (relative 2^-9
     each); a loss scalar sits behind ~30 chained convs of forward (+ as many of backward for the penalty), a random
     walk of sqrt(60)*2^-8 = 3e-2, so 5e-2 of max(1,|x|) for the hinge / rec / kl terms; the gradient penalty is a
-    squared norm of a double-rounded gradient: 1e-1.  Later calls of an untrained GAN are chaotic (the reference
-    against itself at another thread count leaves 1e-3 at call 4): finite, and of the golden's order of magnitude."""
+    squared norm of a double-rounded gradient: 1e-1.  g_loss is NOT in the band even on the first call: it is evaluated
+    after D's first Adam step, which is lr*sign(grad) element-wise (m/sqrt(v) = +-1 at t=1) — every gradient element
+    that is bf16-noise flips the update of its weight by 2*lr, and D(G(z)) through 37 M such weights moves by O(1)
+    (measured: -0.21 vs 3.88; the fp32 HIP path reproduces 3.88 to 2e-4, test_trainer_step_parity_gpu).  Later calls of
+    an untrained GAN are chaotic in any arithmetic (the reference against itself at another thread count leaves 1e-3
+    at call 4): finite, and of the golden's order of magnitude."""
     g = load_golden("steps_gae2_alt")
     ops.set_precision("bf16")
     try:
@@ -585,8 +589,9 @@ def test_bf16_step_band_vs_reference_golden(tmp_path):
         ops.set_precision("fp32")
     gold = g["scalars"]
     print("bf16 rows\n", rows, "\ngolden\n", gold)
-    scale = np.maximum(1.0, np.abs(gold[0, :4]))
-    assert (np.abs(rows[0, :4] - gold[0, :4]) <= 5e-2 * scale).all(), (rows[0], gold[0])
+    cols = [0, 2, 3]  # d_loss, rec, kl: functions of the not-yet-updated weights
+    scale = np.maximum(1.0, np.abs(gold[0, cols]))
+    assert (np.abs(rows[0, cols] - gold[0, cols]) <= 5e-2 * scale).all(), (rows[0], gold[0])
     assert abs(rows[0, 4] - gold[0, 4]) <= 1e-1 * max(1.0, abs(gold[0, 4])), (rows[0, 4], gold[0, 4])
     assert np.isfinite(rows[:, :5]).all()
     assert np.abs(rows[:, :4]).max() <= 10 * np.abs(gold[:, :4]).max()
@@ -669,3 +674,85 @@ def test_attfind_batched_engine_on_hip_vs_reference_notebook_golden():
     m = m.to(DEV)
     out = attfind.attfind_extraction(m, clf, images, len(images), noise, shift_size=float(g["shift_size"]), chunk=64)
     check(out, g, 2e-4)
+
+
+# ---- round 2: cross-layer fusions of the DiscriminatorBlock backward ----------------------------------------
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 64, 64, 32, 64),    # LDS-DMA halo kernel (C >= 64, >= 16x32 px)
+                                  (2, 128, 64, 16, 16),   # register-staged halo kernel (16 px)
+                                  (4, 64, 64, 8, 8),      # generic implicit GEMM (+ split-K epilogue)
+                                  (2, 32, 24, 16, 32)])   # N % 64 != 0
+def test_dgrad_gate_epilogue_matches_unfused(case, prec):
+    """STYLEX_EPI_GATE (activation derivative of the layer below in the data gradient's store) == data gradient followed
+    by the stand-alone activation-derivative kernel, on every kernel family the data gradient can take."""
+    B, C, N, H, W = case
+    ops.set_precision(prec)
+    P = {"fp32": hb.F32, "bf16": hb.BF16_ACT}[prec]
+    adt = hb.act_dtype(P)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn(B, N, H, W, device=DEV, generator=g).to(adt).contiguous(memory_format=torch.channels_last)
+    gate = torch.randn(B, C, H, W, device=DEV, generator=g).to(adt).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
+    fused = hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P, gate=gate)
+    plain = hb.bias_act_bwd(hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P), gate)
+    # bf16: the unfused path rounds dx to bf16 before the 0.2 multiply, the fused one after: one bf16 ulp
+    close(plain.float(), fused.float(), 1e-6 if prec == "fp32" else 8e-3, "gated dgrad")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_blur_adjoint_gate_and_add_at_even(prec):
+    ops.set_precision(prec)
+    adt = hb.act_dtype({"fp32": hb.F32, "bf16": hb.BF16_ACT}[prec])
+    g = torch.Generator(device=DEV).manual_seed(6)
+    for (B, C, H, W) in [(2, 64, 32, 32), (2, 8, 6, 10), (1, 3, 8, 8)]:
+        dy = torch.randn(B, C, H, W, device=DEV, generator=g).to(adt).contiguous(memory_format=torch.channels_last)
+        gate = torch.randn(B, C, H, W, device=DEV, generator=g).to(adt).contiguous(memory_format=torch.channels_last)
+        tol = 1e-6 if prec == "fp32" else 8e-3
+        close(hb.bias_act_bwd(hb.blur3x3_bwd(dy), gate).float(), hb.blur3x3_bwd_gate(dy, gate).float(), tol, "blur gate")
+        if C % 4 == 0:
+            dy2 = hb.blur3x3_s2d_fwd(dy)  # any tensor in the space-to-depth layout
+            close(hb.bias_act_bwd(hb.blur3x3_s2d_bwd(dy2), gate).float(), hb.blur3x3_s2d_bwd(dy2, gate=gate).float(), tol,
+                  "s2d blur gate")
+        src = torch.randn(B, C, (H + 1) // 2, (W + 1) // 2, device=DEV, generator=g).to(adt).contiguous(memory_format=torch.channels_last)
+        want = dy.float().clone()
+        want[:, :, ::2, ::2] += src.float()
+        got = hb.add_at_even_(dy.clone(memory_format=torch.channels_last), src)
+        close(want, got.float(), 1e-6 if prec == "fp32" else 8e-3, "add_at_even")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(3, 64, 64, True), (64, 64, 64, True), (64, 128, 32, True), (32, 48, 16, True),
+                                  (64, 64, 8, True), (64, 64, 2, False)])
+def test_fused_dblock_matches_composable_path(case, prec):
+    """ops._DBlockFast (whole DiscriminatorBlock as one autograd node, gate / add-at-even fusions) against the
+    composable double-differentiable path of the same module: output and every gradient."""
+    import os
+
+    cin, cout, size, down = case
+    ops.set_precision(prec)
+    torch.manual_seed(11)
+    blk = st.DiscriminatorBlock(cin, cout, downsample=down).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(3, cin, size, size, device=DEV, generator=g)
+    results = []
+    for fused in (False, True):
+        os.environ["STYLEX_DBLOCK"] = "1" if fused else "0"
+        try:
+            blk.zero_grad()
+            xr = x.clone().requires_grad_()
+            ops.set_fast(fused)
+            y = blk(xr)
+            r = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(13)).to(y.dtype)
+            (y.float() * r.float()).sum().backward()
+        finally:
+            ops.set_fast(False)
+            os.environ.pop("STYLEX_DBLOCK", None)
+        results.append((y.detach().float(), xr.grad.float(), [p.grad.float().clone() for p in blk.parameters()]))
+    (y0, gx0, gp0), (y1, gx1, gp1) = results
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    close(y0, y1, tol, "dblock out")
+    close(gx0, gx1, tol, "dblock gx")
+    for (name, _), a, b in zip(blk.named_parameters(), gp0, gp1):
+        close(a, b, tol, "dblock grad " + name)
