@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <array>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -11,12 +13,19 @@
 
 namespace {
 
+typedef std::array<int64_t, 9> LayerKey;  // cls, B, Hi, Wi, C, N, KH, stride, s2d_c
 struct TimedLaunch {
     hipEvent_t start, stop;
     int cls;
     double flops;
     double bytes;  // algorithmic HBM bytes of the launch: operands in + result out, each once
+    LayerKey key;
 };
+struct LayerAcc {
+    int64_t launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+std::map<LayerKey, LayerAcc> g_layers;
 std::mutex g_mu;
 bool g_timing = false;
 std::vector<TimedLaunch> g_pending;
@@ -29,11 +38,14 @@ struct ScopedTimer {
     bool on;
     TimedLaunch t;
     hipStream_t s;
-    ScopedTimer(int cls, double flops, double bytes, hipStream_t stream) : on(g_timing), s(stream) {
+    ScopedTimer(int cls, double flops, double bytes, hipStream_t stream, const int64_t* sh = nullptr, int s2d = 0)
+        : on(g_timing), s(stream) {
         if (!on) return;
         t.cls = cls;
         t.flops = flops;
         t.bytes = bytes;
+        t.key = LayerKey{cls, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (sh) t.key = LayerKey{cls, sh[0], sh[1], sh[2], sh[3], sh[4], sh[5], sh[7], s2d};
         (void)hipEventCreate(&t.start);
         (void)hipEventCreate(&t.stop);
         (void)hipEventRecord(t.start, s);
@@ -56,6 +68,11 @@ void drain_pending() {
         g_ms[t.cls] += ms;
         g_flops[t.cls] += t.flops;
         g_bytes[t.cls] += t.bytes;
+        LayerAcc& la = g_layers[t.key];
+        la.launches += 1;
+        la.ms += ms;
+        la.flops += t.flops;
+        la.bytes += t.bytes;
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
@@ -115,8 +132,28 @@ int stylex_timing_enable(int on) {
             g_flops[i] = 0;
             g_bytes[i] = 0;
         }
+        g_layers.clear();
     }
     return 0;
+}
+
+// Per-layer view of the same measurements: one row per (class, conv shape).  meta[r] = {cls, B, Hi, Wi, C, N, KH,
+// stride, s2d_c, launches}, vals[r] = {total ms, total algorithmic FLOPs, total algorithmic bytes}.  Returns the
+// number of rows written (<= cap).
+int stylex_timing_layers(int64_t* meta, double* vals, int64_t cap) {
+    drain_pending();
+    std::lock_guard<std::mutex> lk(g_mu);
+    int64_t r = 0;
+    for (const auto& kv : g_layers) {
+        if (r >= cap) break;
+        for (int i = 0; i < 9; ++i) meta[r * 10 + i] = kv.first[i];
+        meta[r * 10 + 9] = kv.second.launches;
+        vals[r * 3 + 0] = kv.second.ms;
+        vals[r * 3 + 1] = kv.second.flops;
+        vals[r * 3 + 2] = kv.second.bytes;
+        ++r;
+    }
+    return (int)r;
 }
 
 int stylex_timing_report(int cls, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes) {
@@ -204,7 +241,7 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
     if ((flags & STYLEX_EPI_RESIDUAL) && !p.residual) return STYLEX_EINVAL;
     if (p.s2d_c && (p.Ck != 4 * p.s2d_c || p.KH != 3 || p.stride != 1 || p.pad != 1 || p.s2d_c % 64)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (p.s2d_c ? 4.0 : 1.0);  // algorithmic: 9*C, not 36*C
-    ScopedTimer tm(0, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream);
+    ScopedTimer tm(0, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream, sh, p.s2d_c);
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -237,7 +274,7 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
         }
         if (!((flags & STYLEX_EPI_OSCALE) && !q.out_scale)) {
             double fl = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6] / (q.s2d_c ? 4.0 : 1.0);
-            ScopedTimer tmh(1, fl, conv_bytes(sh, q.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream);
+            ScopedTimer tmh(1, fl, conv_bytes(sh, q.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream, sh, q.s2d_c);
             int rc = stylex_launch_halo(q, (hipStream_t)stream);
             if (rc != STYLEX_NOT_APPLICABLE) return rc;
             if (tmh.on) {  // not applicable: nothing was launched; fall through to the generic kernel
@@ -259,7 +296,7 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
     if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
     // algorithmic FLOPs of a data gradient = those of the forward conv
     double flops = 2.0 * (double)sh[0] * sh[9] * sh[10] * (double)sh[4] * sh[3] * sh[5] * sh[6];
-    ScopedTimer tm(1, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream);
+    ScopedTimer tm(1, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, false), (hipStream_t)stream, sh, 0);
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -312,7 +349,7 @@ int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* wor
     p.s2d_c = s2d_c;
     if (s2d_c && (p.Ck != 4 * s2d_c || s2d_c % 64 || p.KH != 3 || p.stride != 1)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (s2d_c ? 4.0 : 1.0);
-    ScopedTimer tm(2, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, true), (hipStream_t)stream);
+    ScopedTimer tm(2, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, true), (hipStream_t)stream, sh, s2d_c);
     return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream);
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "stylex_torgb_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_torgb_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
+    "stylex_timing_layers": (ctypes.c_int, [_i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
@@ -610,3 +611,16 @@ def timing_report():
         lib.stylex_timing_report(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
         out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
     return out
+
+
+def timing_layers(cap=512):
+    """Per-(class, conv shape) rows of the instrumented launches: dicts with cls, B, H, W, C, N, k, stride, s2d,
+    launches, ms, flops, bytes (totals)."""
+    lib = load_library()
+    meta = (ctypes.c_int64 * (cap * 10))()
+    vals = (ctypes.c_double * (cap * 3))()
+    n = lib.stylex_timing_layers(meta, vals, cap)
+    names = ("fwd", "bwd_data", "bwd_weight")
+    return [dict(cls=names[meta[r * 10]], B=meta[r * 10 + 1], H=meta[r * 10 + 2], W=meta[r * 10 + 3], C=meta[r * 10 + 4],
+                 N=meta[r * 10 + 5], k=meta[r * 10 + 6], stride=meta[r * 10 + 7], s2d=meta[r * 10 + 8],
+                 launches=meta[r * 10 + 9], ms=vals[r * 3], flops=vals[r * 3 + 1], bytes=vals[r * 3 + 2]) for r in range(n)]

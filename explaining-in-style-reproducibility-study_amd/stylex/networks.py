@@ -297,7 +297,7 @@ class Generator(nn.Module):  # reference :747-825
 
 class DiscriminatorE(nn.Module):  # reference :842-909 (D: 1 logit; encoder: encoder_dim outputs)
     def __init__(self, image_size, network_capacity=16, fq_layers=[], fq_dict_size=256, attn_layers=[],
-                 transparent=False, encoder=False, encoder_dim=512, fmap_max=512):
+                 transparent=False, encoder=False, encoder_dim=512, fmap_max=512, conditional=False):
         super().__init__()
         assert not fq_layers and not attn_layers, "fq / attention variants are out of scope (SURVEY §2a)"
         filters = discriminator_filters(image_size, network_capacity, fmap_max, transparent)
@@ -310,10 +310,19 @@ class DiscriminatorE(nn.Module):  # reference :842-909 (D: 1 logit; encoder: enc
         self.final_conv = HipConv2d(chan_last, chan_last, 3, padding=1)
         self.flatten = Flatten()
         self.encoder_dim = encoder_dim
-        self.fc = nn.Linear(2 * 2 * chan_last, encoder_dim if encoder else 1)
+        self.encoder = encoder
+        # conditional = the "new architecture" discriminator (reference stylex_train_new.py:887-916): two logits,
+        # combined with the classifier probabilities of the conditioning batch (projection-style conditional GAN)
+        self.conditional = conditional and not encoder
+        self.fc = nn.Linear(2 * 2 * chan_last, encoder_dim if encoder else (2 if self.conditional else 1))
 
-    def forward(self, x):
+    def forward(self, x, probabilities=None):
         for block in self.blocks:
             x = block(x)
         x = self.final_conv(x)
-        return self.fc(self.flatten(x).float()).squeeze()
+        x = self.fc(self.flatten(x).float())
+        if self.conditional:
+            if probabilities is None:  # the reference's default argument torch.Tensor([0.0, 0.0]) (:892)
+                probabilities = x.new_zeros(1, 2)
+            x = x[:, 0] * probabilities[:, 0] + x[:, 1] * probabilities[:, 1]
+        return x.squeeze()

@@ -185,8 +185,12 @@ def mixed_list(n, layers, latent_dim, device):
     return noise_list(n, tt, latent_dim, device) + noise_list(n, layers - tt, latent_dim, device)
 
 
-def latent_to_w(style_vectorizer, latent_descr):
-    return [(style_vectorizer(z), num_layers) for z, num_layers in latent_descr]
+def latent_to_w(style_vectorizer, latent_descr, probabilities=None):
+    """reference :332-333; with `probabilities` the new architecture's form (stylex_train_new.py:332-333): the
+    classifier probabilities of the conditioning batch are appended to every mapped latent."""
+    if probabilities is None:
+        return [(style_vectorizer(z), num_layers) for z, num_layers in latent_descr]
+    return [(torch.cat((style_vectorizer(z), probabilities), dim=1), num_layers) for z, num_layers in latent_descr]
 
 
 def image_noise(n, im_size, device):  # reference :336-337
@@ -367,7 +371,7 @@ class AugWrapper(nn.Module):  # reference :558-571
         super().__init__()
         self.D = D
 
-    def forward(self, images, prob=0., types=[], detach=False):
+    def forward(self, images, prob=0., types=[], detach=False, probabilities=None):
         if random() < prob:  # one Python random() per call even at prob 0 (RNG parity)
             from diff_augment import DiffAugment
 
@@ -376,6 +380,8 @@ class AugWrapper(nn.Module):  # reference :558-571
             images = DiffAugment(images, types=types)
         if detach:
             images = images.detach()
+        if probabilities is not None:  # conditional discriminator (stylex_train_new.py:564-572)
+            return self.D(images, probabilities=probabilities)
         return self.D(images)
 
 
@@ -388,20 +394,26 @@ class StylEx(nn.Module):
     def __init__(self, image_size, latent_dim=514, fmap_max=512, style_depth=8, network_capacity=16, transparent=False,
                  fp16=False, cl_reg=False, steps=1, lr=1e-4, ttur_mult=2, fq_layers=[], fq_dict_size=256,
                  attn_layers=[], no_const=False, lr_mlp=0.1, rank=0, classifier_labels=2, encoder_class=None,
-                 kl_rec_during_disc=False, capturable=False):
+                 kl_rec_during_disc=False, capturable=False, conditional=False):
         super().__init__()
         assert not fp16 and not cl_reg and encoder_class is None, "apex fp16 / cl_reg / debug encoders: out of scope"
         self.lr, self.steps, self.ema_beta, self.fp16 = lr, steps, 0.995, False
+        # conditional = the reference's second shipped architecture (stylex_train_new.py:922-969): the mapping
+        # network works on latent_dim - 2 dimensions (the 2 classifier probabilities are appended to W), D has two
+        # logits weighted by those probabilities, and the encoder trains at a fixed lr of 1e-5
+        self.conditional, self.num_classes = conditional, 2
+        s_dim = latent_dim - self.num_classes if conditional else latent_dim
         # construction ORDER is part of the contract: it fixes the RNG stream of the initial weights
         self.encoder = DiscriminatorE(image_size, network_capacity, encoder=True, fq_layers=fq_layers,
                                       fq_dict_size=fq_dict_size, attn_layers=attn_layers, transparent=transparent,
                                       fmap_max=fmap_max)
-        self.S = StyleVectorizer(latent_dim, style_depth, lr_mul=lr_mlp)
+        self.S = StyleVectorizer(s_dim, style_depth, lr_mul=lr_mlp)
         self.G = Generator(image_size, latent_dim, network_capacity, transparent=transparent, attn_layers=attn_layers,
                            no_const=no_const, fmap_max=fmap_max)
         self.D = DiscriminatorE(image_size, network_capacity, fq_layers=fq_layers, fq_dict_size=fq_dict_size,
-                                attn_layers=attn_layers, transparent=transparent, fmap_max=fmap_max)
-        self.SE = StyleVectorizer(latent_dim, style_depth, lr_mul=lr_mlp)
+                                attn_layers=attn_layers, transparent=transparent, fmap_max=fmap_max,
+                                conditional=conditional)
+        self.SE = StyleVectorizer(s_dim, style_depth, lr_mul=lr_mlp)
         self.GE = Generator(image_size, latent_dim, network_capacity, transparent=transparent, attn_layers=attn_layers,
                             no_const=no_const, fmap_max=fmap_max)  # the reference omits fmap_max here (:937-938) and
         # then crashes in reset_parameter_averaging for any fmap_max that actually caps a layer; identical at 512
@@ -410,6 +422,9 @@ class StylEx(nn.Module):
         set_requires_grad(self.SE, False)
         set_requires_grad(self.GE, False)
         generator_params = list(self.G.parameters()) + list(self.S.parameters()) + list(self.encoder.parameters())
+        if conditional:  # stylex_train_new.py:967-969: encoder in its own parameter group at lr 1e-5
+            generator_params = [{"params": list(self.G.parameters()) + list(self.S.parameters())},
+                                {"params": list(self.encoder.parameters()), "lr": 1e-5}]
         self.G_opt = Adam(generator_params, lr=self.lr, betas=(0.5, 0.9))
         self.D_opt = Adam(self.D.parameters(), lr=self.lr * ttur_mult, betas=(0.5, 0.9))
         self._init_weights()
@@ -488,12 +503,21 @@ class Trainer:
                  classifier_name=None,
                  # --- extensions (defaults reproduce the reference) ---
                  classifier=None, lpips_fn=None, gp_every=4, pl_every=32, pl_after=5000, device=None,
-                 save_training_state=False, graphs=None, graph_warmup=4, *args, **kwargs):
-        kwargs.pop("kl_rec_during_disc", None)  # cli.py forwards it; only the new architecture reads it
+                 save_training_state=False, graphs=None, graph_warmup=4, new_architecture=False, *args, **kwargs):
+        kl_rec_during_disc = kwargs.pop("kl_rec_during_disc", False)  # cli.py forwards it; only the new architecture reads it
+        # new_architecture = the conditional-D variant the reference ships as stylex_train_new.py (cli.py:17-22)
+        self.new_architecture = bool(new_architecture)
+        assert not (self.new_architecture and kl_rec_during_disc), \
+            "kl_rec_during_disc only changes what is logged in the reference (its gradients are zeroed by the generator " \
+            "phase's G_opt.zero_grad, stylex_train_new.py:1392-1410,1430) and is not implemented"
         self.model_params = [args, kwargs]
         self.StylEx = None
         self.kl_scaling, self.rec_scaling = kl_scaling, rec_scaling
         self.alternating_training = alternating_training
+        if self.new_architecture and alternating_training:
+            # stylex_train_new.py:1166-1171: the x2 of the alternating schedule is applied once here instead of per loss
+            self.rec_scaling *= 2
+            self.kl_scaling *= 2
         self.name = name
         base_dir = Path(base_dir)
         self.base_dir = base_dir
@@ -583,7 +607,8 @@ class Trainer:
                              network_capacity=self.network_capacity, fmap_max=self.fmap_max,
                              transparent=self.transparent, fq_layers=self.fq_layers, fq_dict_size=self.fq_dict_size,
                              attn_layers=self.attn_layers, no_const=self.no_const, rank=self.device,
-                             classifier_labels=self.num_classes, capturable=self.graphs, *args, **kwargs)
+                             classifier_labels=self.num_classes, capturable=self.graphs,
+                             conditional=self.new_architecture, *args, **kwargs)
         self._graph_cache, self._static = {}, {}  # graphs captured for a previous model instance are void
         if self.is_ddp:
             m = self.StylEx
@@ -695,19 +720,22 @@ class Trainer:
         return self.classifier.classify_images(_frozen_layout(images))
 
     def _styles_from_encoder(self, batch):
+        """W of an encoder micro-step: encoder output ++ classifier logits (:1309-1314) — ++ classifier PROBABILITIES in
+        the new architecture (stylex_train_new.py:1339-1343)."""
         m = self.StylEx
         enc, logits = self._fork([lambda: m.encoder(batch), lambda: self._classify(batch)])
-        w = styles_def_to_tensor([(torch.cat((enc, logits), dim=1), m.G.num_layers)])
+        cond = F.softmax(logits, dim=1) if self.new_architecture else logits
+        w = styles_def_to_tensor([(torch.cat((enc, cond), dim=1), m.G.num_layers)])
         return enc, logits, w
 
-    def _styles_of(self, entry):
+    def _styles_of(self, entry, probs=None):
         """[B, L, latent] style tensor of a noise micro-step: ('noise', [(z, n_layers), ...], inoise) as drawn by
-        noise_list / mixed_list, or the graph form ('noise_static', z1, z2, tt, inoise) whose layer split `tt` is a
+        noise_list / mixed_list, or the graph form ('noise_static', z1, z2, inoise, tt) whose layer split `tt` is a
         device scalar, so that one captured graph serves every split (pure selection: identical values)."""
         m = self.StylEx
         if entry[0] == "noise":
-            return styles_def_to_tensor(latent_to_w(m.S, entry[1]))
-        _, z1, z2, tt, _ = entry
+            return styles_def_to_tensor(latent_to_w(m.S, entry[1], probs))
+        _, z1, z2, _, tt = entry
         w1, w2 = m.S(z1), m.S(z2)
         first = torch.arange(m.G.num_layers, device=z1.device) < tt
         return torch.where(first[None, :, None], w1[:, None, :], w2[:, None, :])
@@ -721,15 +749,21 @@ class Trainer:
         m = self.StylEx
         batch_size = math.ceil(self.batch_size / self.world_size)
         reals, micro = [], []
+        new = self.new_architecture
+        z_dim = m.G.latent_dim - (m.num_classes if new else 0)
         for _ in group:
             reals.append(self._next_batch())
+            # new architecture: EVERY micro-step draws a conditioning batch (stylex_train_new.py:1329-1334); an
+            # encoder micro-step encodes that same batch
+            cond = self._next_batch() if new else None
             if (not self.alternating_training) or st["encoder_input"]:
-                micro.append(("enc", self._next_batch(), image_noise(batch_size, m.G.image_size, device=self.device)))
+                batch2 = cond if new else self._next_batch()
+                micro.append(("enc", batch2, image_noise(batch_size, m.G.image_size, device=self.device), batch2))
                 st["encoder_input"] = False
             else:
                 st["latents_fn"] = mixed_list if random() < self.mixed_prob else noise_list
-                style = st["latents_fn"](batch_size, m.G.num_layers, m.G.latent_dim, device=self.device)
-                micro.append(("noise", style, image_noise(batch_size, m.G.image_size, device=self.device)))
+                style = st["latents_fn"](batch_size, m.G.num_layers, z_dim, device=self.device)
+                micro.append(("noise", style, image_noise(batch_size, m.G.image_size, device=self.device), cond))
                 if self.alternating_training:
                     st["encoder_input"] = True
             if fuse:
@@ -745,10 +779,11 @@ class Trainer:
         for _ in group:
             batch = self._next_batch()
             if (not self.alternating_training) or st["encoder_input"]:
-                micro.append(("enc", batch, image_noise(batch_size, m.G.image_size, device=self.device)))
+                micro.append(("enc", batch, image_noise(batch_size, m.G.image_size, device=self.device), batch))
             else:
-                style = st["latents_fn"](batch_size, m.G.num_layers, m.G.latent_dim, device=self.device)
-                micro.append(("noise", style, image_noise(batch_size, m.G.image_size, device=self.device)))
+                z_dim = m.G.latent_dim - (m.num_classes if self.new_architecture else 0)
+                style = st["latents_fn"](batch_size, m.G.num_layers, z_dim, device=self.device)
+                micro.append(("noise", style, image_noise(batch_size, m.G.image_size, device=self.device), batch))
             if fuse:
                 random()  # the AugWrapper draw of this micro-step (:1417)
                 if apply_pl:
@@ -763,15 +798,31 @@ class Trainer:
         m = self.StylEx
         aug = {"prob": self.aug_prob, "types": self.aug_types}
 
-        def D_call(images, detach=False):
-            if fuse:  # AugWrapper at prob 0 is D itself; its random() draw is issued where the reference draws it
-                return m.D(images.detach() if detach else images)
-            return m.D_aug(images, detach=detach, **aug)
+        new = self.new_architecture
 
+        def D_call(images, detach=False, probs=None):
+            if fuse:  # AugWrapper at prob 0 is D itself; its random() draw is issued where the reference draws it
+                images = images.detach() if detach else images
+                return m.D(images, probabilities=probs) if new else m.D(images)
+            return m.D_aug(images, detach=detach, probabilities=probs, **aug)
+
+        cond = None
         with torch.no_grad():  # the generator/encoder graph is never used in this phase (:1330-1331)
-            ws = [self._styles_from_encoder(e[1])[2] if e[0] == "enc" else self._styles_of(e) for e in micro]
+            ws, conds = [], []
+            for e in micro:
+                if e[0] == "enc":
+                    _, logits, w = self._styles_from_encoder(e[1])
+                    p_i = F.softmax(logits, dim=1) if new else None
+                else:
+                    # new architecture: probabilities of the micro-step's conditioning batch (:1332-1333, :1352)
+                    p_i = F.softmax(self._classify(e[3]), dim=1) if new else None
+                    w = self._styles_of(e, p_i)
+                ws.append(w)
+                conds.append(p_i)
+            if new:
+                cond = _cat(conds)
             ops.set_fast(True)
-            generated = m.G(_cat(ws), _cat([e[-1] for e in micro]))
+            generated = m.G(_cat(ws), _cat([e[2] for e in micro]))
         real = _cat(reals)
         n_fake = generated.shape[0]
         grad_norms = None
@@ -780,11 +831,11 @@ class Trainer:
 
             def fake_branch():
                 ops.set_fast(True)  # the fake branch is only ever differentiated once
-                return D_call(generated, detach=True)
+                return D_call(generated, detach=True, probs=cond)
 
             def real_branch():
                 ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
-                return D_call(real)
+                return D_call(real, probs=cond)
 
             # the two D passes of a penalty step are independent until the loss: two HIP streams when D_aug is
             # a pass-through (`fuse`; with augmentation the reference's fake-then-real draw order is kept)
@@ -798,11 +849,12 @@ class Trainer:
             # D(fake) and D(real) are one pass over the concatenated batch
             ops.set_fast(True)
             if fuse:
-                both = D_call(torch.cat((generated, real), dim=0), detach=True)
+                both = D_call(torch.cat((generated, real), dim=0), detach=True,
+                              probs=torch.cat((cond, cond), dim=0) if new else None)
                 fake_out, real_out = both[:n_fake], both[n_fake:]
             else:
-                fake_out = D_call(generated, detach=True)
-                real_out = D_call(real)
+                fake_out = D_call(generated, detach=True, probs=cond)
+                real_out = D_call(real, probs=cond)
         disc_loss, lo = 0, 0
         for r in reals:
             sl = slice(lo, lo + r.shape[0])
@@ -825,20 +877,29 @@ class Trainer:
         m = self.StylEx
         aug = {"prob": self.aug_prob, "types": self.aug_types}
 
-        def D_call(images):
-            return m.D(images) if fuse else m.D_aug(images, detach=False, **aug)
+        new = self.new_architecture
 
-        ws, encs = [], []
+        def D_call(images, probs=None):
+            if fuse:
+                return m.D(images, probabilities=probs) if new else m.D(images)
+            return m.D_aug(images, detach=False, probabilities=probs, **aug)
+
+        ws, encs, conds = [], [], []
         for e in micro:
             if e[0] == "enc":
                 enc_out, real_logits, w_styles = self._styles_from_encoder(e[1])
                 encs.append((e[1], enc_out, real_logits))
+                p_i = F.softmax(real_logits, dim=1) if new else None
             else:
-                w_styles = self._styles_of(e)
+                # new architecture: the classifier runs on the loader batch of EVERY micro-step (:1437-1438)
+                p_i = F.softmax(self._classify(e[3]), dim=1) if new else None
+                w_styles = self._styles_of(e, p_i)
                 encs.append(None)
             ws.append(w_styles)
+            conds.append(p_i)
+        cond = _cat(conds) if new else None
         w_all = _cat(ws)
-        generated_all = m.G(w_all, _cat([e[-1] for e in micro]))
+        generated_all = m.G(w_all, _cat([e[2] for e in micro]))
         pl_all = calc_pl_lengths(w_all, generated_all, _cat(pl_noises)) if (apply_pl and pl_noises) else None
         # four independent consumers of the generated batch: D, and per encoder micro-step the classifier,
         # the encoder and LPIPS — forked over HIP streams (see _fork)
@@ -846,7 +907,7 @@ class Trainer:
         for w_styles in ws:
             spans.append(slice(lo, lo + w_styles.shape[0]))
             lo += w_styles.shape[0]
-        branches, where = [lambda: D_call(generated_all)], []
+        branches, where = [lambda: D_call(generated_all, cond)], []
         for sl, enc in zip(spans, encs):
             if enc is not None:
                 gen_i, batch_i = generated_all[sl], enc[0]
@@ -873,9 +934,10 @@ class Trainer:
             if enc is not None:
                 batch, enc_out, real_logits = enc
                 gen_logits, gen_w, perceptual = outs[at:at + 3]
-                rec = 2 * self.rec_scaling * reconstruction_loss(batch, generated, gen_w, enc_out,
-                                                                 self.lpips_fn, perceptual=perceptual) / gae
-                kl = 2 * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
+                twice = 1 if new else 2  # the new architecture doubled the scalings once at construction (:1166-1171)
+                rec = twice * self.rec_scaling * reconstruction_loss(batch, generated, gen_w, enc_out,
+                                                                     self.lpips_fn, perceptual=perceptual) / gae
+                kl = twice * self.kl_scaling * classifier_kl_loss(real_logits, gen_logits) / gae
                 total = total + rec + kl  # one backward == the three backward calls of :1436-1438
                 acc["rec"] += rec.detach()
                 acc["kl"] += kl.detach()
@@ -946,7 +1008,7 @@ class Trainer:
         st = {"encoder_input": False, "latents_fn": None}
 
         self._calls = getattr(self, "_calls", 0) + 1
-        if self._graphs_enabled() and fuse and not apply_pl and self._calls > self.graph_warmup:
+        if self._graphs_enabled() and fuse and not apply_pl and not self.new_architecture and self._calls > self.graph_warmup:
             acc_host = self._train_graphed(groups[0], st, apply_gp, gae)
             has_gp = apply_gp
         else:
@@ -1031,7 +1093,8 @@ class Trainer:
 
     def _bind_micro(self, phase, i, e, layers):
         if e[0] == "enc":
-            return ("enc", self._bind((phase, i, "x"), e[1]), self._bind((phase, i, "n"), e[2]))
+            x = self._bind((phase, i, "x"), e[1])
+            return ("enc", x, self._bind((phase, i, "n"), e[2]), x)
         style = e[1]
         z1 = self._bind((phase, i, "z1"), style[0][0])
         z2 = self._bind((phase, i, "z2"), style[1][0] if len(style) > 1 else style[0][0])
@@ -1039,7 +1102,7 @@ class Trainer:
         if tt is None:
             tt = self._static[(phase, i, "tt")] = torch.zeros((), dtype=torch.int64, device=self.device)
         tt.fill_(style[0][1] if len(style) > 1 else layers)
-        return ("noise_static", z1, z2, tt, self._bind((phase, i, "n"), e[2]))
+        return ("noise_static", z1, z2, self._bind((phase, i, "n"), e[2]), tt)
 
     def _train_graphed(self, group, st, apply_gp, gae):
         m = self.StylEx

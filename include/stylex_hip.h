@@ -230,6 +230,10 @@ int stylex_torgb_bwd(const void* x, const void* gy, const float* s1, const float
 int stylex_timing_enable(int on);
 int stylex_timing_report(int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
                          double* total_bytes);
+/* Per-layer view of the same measurements, one row per (class, conv shape): meta[r][10] = {class, B, Hi, Wi, C, N, KH,
+ * stride, s2d_c, launches}, vals[r][3] = {total ms, total algorithmic FLOPs, total algorithmic bytes}.  Returns the
+ * number of rows written (<= cap).  bench.py builds the per-layer mixed (HBM / MFMA) roofline from it. */
+int stylex_timing_layers(int64_t* meta, double* vals, int64_t cap);
 
 #ifdef __cplusplus
 }

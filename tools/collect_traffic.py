@@ -43,7 +43,7 @@ def run_pass(counter, bench_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
     ap.add_argument("--precision", default="bf16")
     a = ap.parse_args()
     bench_args = ["--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--roofline-steps", "0", "--precision", a.precision]
@@ -59,7 +59,10 @@ def main():
     fam_bytes = sum(v["bytes_corrected"] for k, v in per_kernel.items() if any(w in k for w in WGRAD + WGRAD_AUX))
     fwd_disp = sum(v["dispatches"] for k, v in per_kernel.items() if any(w in k for w in FWD))
     fwd_bytes = sum(v["bytes_corrected"] for k, v in per_kernel.items() if any(w in k for w in FWD + FWD_AUX))
-    out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py " + " ".join(bench_args),
+    sys.path.insert(0, ROOT)
+    import bench  # csrc_sha16: bench.py only quotes a traffic file collected on the kernel sources it runs
+
+    out = {"csrc_sha16": bench.csrc_sha16(), "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py " + " ".join(bench_args),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
            "bwd_weight": {"launches": main_disp, "bytes_total": fam_bytes,
                           "bytes_per_launch": fam_bytes / max(1, main_disp)},
