@@ -18,7 +18,13 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from stylex_train import NanException, Trainer
+# Same switch as the reference (cli.py:16-22): False selects the conditional-discriminator architecture.
+USE_OLD_ARCHITECTURE = os.environ.get("STYLEX_NEW_ARCHITECTURE", "0") != "1"
+
+if USE_OLD_ARCHITECTURE:
+    from stylex_train import NanException, Trainer
+else:
+    from stylex_train_new import NanException, Trainer
 
 # flag -> default, in the reference's order (cli.py:84-171)
 DEFAULTS = dict(

@@ -1177,28 +1177,47 @@ class Trainer:
         m.eval()
         rows = self.num_image_tiles
         latent_dim, image_size, num_layers = m.G.latent_dim, m.G.image_size, m.G.num_layers
-        latents = noise_list(rows ** 2, num_layers, latent_dim, device=self.device)
+        new = self.new_architecture
+        z_dim = latent_dim - (m.num_classes if new else 0)
+        latents = noise_list(rows ** 2, num_layers, z_dim, device=self.device)
         n = image_noise(rows ** 2, image_size, device=self.device)
         tag = ""
-        image_batch = self._next_batch()
-        w = None
+        # default architecture: a loader batch is always drawn (:1526); the new one draws it only with encoder_input
+        # (stylex_train_new.py:1602-1607) and then has nothing to put next to the samples (it crashes there; here the
+        # grid simply holds the samples)
+        image_batch = self._next_batch() if (encoder_input or not new) else None
+        w, probs = None, None
         if encoder_input:
             tag = "from_encoder"
             logits = self.classifier.classify_images(image_batch)
-            w = [(torch.cat((m.encoder(image_batch), logits), dim=1), num_layers)]
+            if new:
+                probs = F.softmax(logits, dim=1)
+                w = [(m.encoder(image_batch), num_layers)]  # probabilities are appended in generate_truncated
+            else:
+                w = [(torch.cat((m.encoder(image_batch), logits), dim=1), num_layers)]
             rows = len(image_batch)
+        elif new:  # random class probabilities (stylex_train_new.py:1618-1620)
+            probs = torch.rand(rows ** 2, 2, device=self.device)
+            probs = probs / torch.sum(probs, dim=1, keepdim=True)
         out_dir = self.results_dir / self.name
-        imgs = self.generate_truncated(m.S, m.G, latents, n, w=w, trunc_psi=self.trunc_psi)
-        save_image_grid(torch.cat((image_batch, imgs)), str(out_dir / f"{num}-{tag}.png"), nrow=rows)
-        imgs = self.generate_truncated(m.SE, m.GE, latents, n, w=w, trunc_psi=self.trunc_psi)
-        save_image_grid(torch.cat((image_batch, imgs)), str(out_dir / f"{num}-{tag}-ema.png"), nrow=rows)
-        nn_ = noise(rows, latent_dim, device=self.device)
+
+        def grid(imgs, path):
+            save_image_grid(imgs if image_batch is None else torch.cat((image_batch, imgs)), path, nrow=rows)
+
+        imgs = self.generate_truncated(m.S, m.G, latents, n, w=w, trunc_psi=self.trunc_psi, probabilities=probs)
+        grid(imgs, str(out_dir / f"{num}-{tag}.png"))
+        imgs = self.generate_truncated(m.SE, m.GE, latents, n, w=w, trunc_psi=self.trunc_psi, probabilities=probs)
+        grid(imgs, str(out_dir / f"{num}-{tag}-ema.png"))
+        nn_ = noise(rows, z_dim, device=self.device)
         tiled = nn_.repeat_interleave(rows, dim=0)
         repeated = nn_.repeat(rows, 1)
         tt = int(num_layers / 2)
         mixed = [(tiled, tt), (repeated, num_layers - tt)]
-        imgs = self.generate_truncated(m.SE, m.GE, mixed, n, trunc_psi=self.trunc_psi)
-        save_image_grid(torch.cat((image_batch, imgs)), str(out_dir / f"{num}-{tag}-mr.png"), nrow=rows)
+        if new:
+            probs = torch.rand(rows ** 2, 2, device=self.device)
+            probs = probs / torch.sum(probs, dim=1, keepdim=True)
+        imgs = self.generate_truncated(m.SE, m.GE, mixed, n, trunc_psi=self.trunc_psi, probabilities=probs)
+        grid(imgs, str(out_dir / f"{num}-{tag}-mr.png"))
 
     @torch.no_grad()
     def calculate_fid(self, num_batches):
@@ -1208,7 +1227,7 @@ class Trainer:
     def truncate_style(self, tensor, trunc_psi=0.75):
         m = self.StylEx
         if not exists(self.av):
-            z = noise(2000, m.G.latent_dim, device=self.device)
+            z = noise(2000, m.G.latent_dim - (m.num_classes if self.new_architecture else 0), device=self.device)
             samples = evaluate_in_chunks(self.batch_size, m.S, z).cpu().numpy()
             self.av = np.expand_dims(np.mean(samples, axis=0), axis=0)
         av = torch.from_numpy(self.av).to(self.device)
@@ -1219,10 +1238,15 @@ class Trainer:
         return [(self.truncate_style(t, trunc_psi=trunc_psi), n) for t, n in w]
 
     @torch.no_grad()
-    def generate_truncated(self, S, G, style, noi, w=None, trunc_psi=0.75, num_image_tiles=8):
+    def generate_truncated(self, S, G, style, noi, w=None, trunc_psi=0.75, num_image_tiles=8, probabilities=None):
         if w is None:
             w = [(S(z), n) for z, n in style]
-        w_styles = styles_def_to_tensor(self.truncate_style_defs(w, trunc_psi=trunc_psi))
+        w_truncated = self.truncate_style_defs(w, trunc_psi=trunc_psi)
+        if self.new_architecture:
+            # stylex_train_new.py:1741-1745: only the FIRST truncated latent is used (a mixed pair loses its second
+            # half there) with the class probabilities appended, for all layers
+            w_truncated = [(torch.cat((w_truncated[0][0], probabilities), dim=1), self.StylEx.G.num_layers)]
+        w_styles = styles_def_to_tensor(w_truncated)
         return evaluate_in_chunks(self.batch_size, G, w_styles, noi).clamp_(0., 1.)
 
     @torch.no_grad()

@@ -3,7 +3,7 @@ container: it imports the reference (/root/reference) through ``ref_shim`` and
 writes input/expected-output vectors to ``tests/golden/*.npz``.  The vectors are
 data; no reference source travels.
 
-    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,diffaug,curve]
+    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,newarch,diffaug,curve]
 
 Conventions: every fixture stores the seeds needed to regenerate weights
 (``torch.manual_seed(seed)`` then construct ``StylEx(...)``), all inputs that are
@@ -318,6 +318,49 @@ def gen_cfg4(st):
          logits_batch0=logits)
 
 
+def gen_newarch(st):
+    """N4: the reference's second architecture (stylex/stylex_train_new.py, cli.py:17-22): init parity, conditional-D
+    forward, and Trainer.train() x 3 (GAE=2 alternating; step 0 carries the gradient penalty)."""
+    stn = ref_shim.import_reference_new()
+    size, cap, fmax, bs, gae, n = 32, 4, 64, 2, 2, 3
+    # init + nets
+    torch.manual_seed(432)
+    m = stn.StylEx(image_size=size, network_capacity=cap, fmap_max=fmax)
+    sd = m.state_dict()
+    out = {"seed": 432, "config": np.array([size, cap, fmax]), "keys": np.array(list(sd.keys())),
+           "shapes": np.array([",".join(map(str, v.shape)) for v in sd.values()]),
+           "stats": np.stack([stats(v) for v in sd.values()])}
+    g = torch.Generator().manual_seed(433)
+    x = torch.rand(3, 3, size, size, generator=g)
+    probs = torch.softmax(torch.randn(3, 2, generator=g), dim=1)
+    z = torch.randn(3, 512, generator=g)
+    out["x"], out["probs"], out["z"] = x, probs, z
+    out["d_cond"] = m.D(x, probabilities=probs)
+    out["enc_out"] = m.encoder(x)
+    w = stn.latent_to_w(m.S, [(z, m.G.num_layers)], probs)
+    out["w"] = w[0][0]
+    out["lr_groups"] = np.array([pg["lr"] for pg in m.G_opt.param_groups])
+    save("newarch_init", **out)
+    # steps
+    cls = ref_shim.TinyClassifier(seed=99)
+    gd = torch.Generator().manual_seed(7)
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    seed_all(42)
+    tr = ref_shim.make_reference_trainer(stn, tempfile.mkdtemp(), cls, batches, image_size=size, network_capacity=cap,
+                                         fmap_max=fmax, batch_size=bs, gradient_accumulate_every=gae,
+                                         alternating_training=True, lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1)
+    tr.init_StylEx()
+    rows = []
+    for i in range(n):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                     tr.last_gp_loss if tr.last_gp_loss is not None else np.nan, np.nan])
+        print("newarch", i, rows[-1])
+    names, pst = param_stats(tr.StylEx)
+    save("steps_newarch", config=np.array([size, cap, fmax, bs, gae, 1, n, 0]), pl_mean0=np.nan, data_seed=7, seed=42,
+         cls_seed=99, lpips_seed=4242, scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst)
+
+
 def gen_diffaug(st):
     """N2: DiffAugment (stylex/diff_augment.py) per augmentation type and through AugWrapper.forward (:558-571: the
     random() gate, random_hflip, DiffAugment) on a non-square batch; seeds recorded, CPU generator."""
@@ -378,7 +421,7 @@ def main():
     st = ref_shim.import_reference()
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
-                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("diffaug", gen_diffaug),
+                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
                      ("curve", gen_curve)):
         if name in todo:
             if name == "steps" and a.step_cases:

@@ -113,6 +113,30 @@ def _install_stubs():
 
 
 _ST = None
+_ST_NEW = None
+
+
+def import_reference_new():
+    """The reference's second architecture module ``stylex_train_new`` (cli.py:17-22 switch), imported on CPU with
+    the same stubs."""
+    global _ST_NEW
+    if _ST_NEW is not None:
+        return _ST_NEW
+    import_reference()  # stubs, .cuda() patches
+    real_avail = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    seed_state = torch.random.get_rng_state()
+    try:
+        torch.manual_seed(1234)
+        sys.path.insert(0, REF_STYLEX)
+        import stylex_train_new as stn  # noqa
+    finally:
+        torch.cuda.is_available = real_avail
+        torch.random.set_rng_state(seed_state)
+        if REF_STYLEX in sys.path:
+            sys.path.remove(REF_STYLEX)
+    _ST_NEW = stn
+    return stn
 
 
 def import_reference():

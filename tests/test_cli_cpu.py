@@ -67,3 +67,34 @@ def test_set_seed_reseeds_all_three_generators():
     cli.set_seed(123)
     b = (torch.rand(3), np.random.rand(3), random.random())
     assert torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_new_architecture_switch_and_evaluate(tmp_path, monkeypatch):
+    """reference cli.py:16-22: USE_OLD_ARCHITECTURE=False binds Trainer to stylex_train_new; its evaluate() writes the
+    three grids with class probabilities appended to W (stylex_train_new.py:1585-1661, 1738-1749)."""
+    import importlib
+
+    import stylex_train as st
+    import stylex_train_new as stn
+    from lpips_standin import LPIPSStandIn
+    from ref_shim import TinyClassifier
+
+    monkeypatch.setenv("STYLEX_NEW_ARCHITECTURE", "1")
+    try:
+        mod = importlib.reload(cli)
+        assert mod.Trainer is stn.Trainer and not mod.USE_OLD_ARCHITECTURE
+    finally:
+        monkeypatch.delenv("STYLEX_NEW_ARCHITECTURE")
+        importlib.reload(cli)
+    assert cli.Trainer is st.Trainer and cli.USE_OLD_ARCHITECTURE
+    tr = stn.Trainer(name="e", base_dir=str(tmp_path), image_size=32, network_capacity=2, fmap_max=16, batch_size=2,
+                     gradient_accumulate_every=2, classifier=TinyClassifier(seed=1), lpips_fn=LPIPSStandIn(seed=2),
+                     classifier_name="resnet", evaluate_every=10 ** 9, save_every=10 ** 9, num_image_tiles=2,
+                     device=torch.device("cpu"))
+    tr.loader = st.cycle([torch.rand(2, 3, 32, 32) for _ in range(4)])
+    tr.init_StylEx()
+    assert tr.StylEx.S.net[0].weight.shape == (512, 512) and tr.StylEx.D.fc.out_features == 2
+    tr.evaluate(encoder_input=False, num=5)
+    tr.evaluate(encoder_input=True, num=6)
+    assert sorted(os.listdir(tmp_path / "results" / "e")) == ["5--ema.png", "5--mr.png", "5-.png", "6-from_encoder-ema.png",
+                                                               "6-from_encoder-mr.png", "6-from_encoder.png"]

@@ -536,6 +536,22 @@ def test_config4_mobilenet_pl_step_parity_gpu(tmp_path):
     assert_param_stats(tr, g, head_atol=n * 3e-4)
 
 
+def test_newarch_on_hip(tmp_path):
+    """N4: the conditional-discriminator architecture (reference stylex_train_new.py) on the HIP path: init / conditional
+    D / W-with-probabilities parity and three Trainer.train() calls vs the reference's own module."""
+    import stylex_train_new as stn
+    from test_host_logic_cpu import check_newarch_init
+
+    check_newarch_init(torch.device(DEV))
+    g = load_golden("steps_newarch")
+    tr, n = make_trainer(g, tmp_path, device=torch.device(DEV), trainer_cls=stn.Trainer)
+    rows = run_steps(tr, n)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=2e-4, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=2e-3, atol=2e-3, equal_nan=True)
+    assert_param_stats(tr, g, head_atol=n * 3e-4)
+
+
 def test_block_level_goldens_on_hip():
     """GeneratorBlock (transposed noise, toRGB + upsample), DiscriminatorBlock and StyleVectorizer of tests/golden/
     ops.npz (captured from the reference's modules with their own weights) through the HIP modules."""

@@ -78,7 +78,7 @@ def test_losses_product():
     close(g["rec/lpips_value"], mine(st.lpips_normalize(i1), st.lpips_normalize(i2)).reshape(-1), 1e-6)
 
 
-def make_trainer(g, tmp_path, device=None):
+def make_trainer(g, tmp_path, device=None, trainer_cls=None):
     size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
     cls = TinyClassifier(seed=int(g["cls_seed"]))
     gd = torch.Generator().manual_seed(int(g["data_seed"]))
@@ -92,10 +92,11 @@ def make_trainer(g, tmp_path, device=None):
     np.random.seed(seed)
     random.seed(seed)
     aug = float(g["aug_prob"]) if "aug_prob" in g.files else 0.
-    tr = st.Trainer(name="t", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax,
-                    batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4,
-                    ttur_mult=1.5, rec_scaling=1, kl_scaling=1, classifier=cls, lpips_fn=lp, classifier_name="resnet",
-                    evaluate_every=10 ** 9, save_every=10 ** 9, device=device, aug_prob=aug)
+    tr = (trainer_cls or st.Trainer)(name="t", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax,
+                                     batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4,
+                                     ttur_mult=1.5, rec_scaling=1, kl_scaling=1, classifier=cls, lpips_fn=lp,
+                                     classifier_name="resnet", evaluate_every=10 ** 9, save_every=10 ** 9, device=device,
+                                     aug_prob=aug)
     tr.loader = st.cycle(batches)
     tr.dataset = list(range(1000))
     tr.save = lambda *a, **k: None
@@ -289,3 +290,45 @@ def test_product_fails_loudly_without_gpu():
 
     with pytest.raises(hip_backend.StylexHipError):
         ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3), None, 1, 1)
+
+
+def check_newarch_init(device=None):
+    """reference stylex_train_new.py: parameter names / shapes / init stream, conditional D, W with probabilities, the
+    encoder's own lr group."""
+    import stylex_train_new as stn
+
+    g = load_golden("newarch_init")
+    s, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["seed"]))
+    m = stn.StylEx(s, network_capacity=cap, fmap_max=fmax, rank=0 if device is not None else None)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    for i, (k, v) in enumerate(sd.items()):
+        assert ",".join(map(str, v.shape)) == str(g["shapes"][i]), k
+        assert_same_stats(g["stats"][i], stats(v.cpu()), k)
+    assert [pg["lr"] for pg in m.G_opt.param_groups] == list(g["lr_groups"])
+    dev = device or torch.device("cpu")
+    x, probs, z = (torch.from_numpy(g[n]).to(dev) for n in ("x", "probs", "z"))
+    tol = 2e-5
+    close(g["d_cond"], m.D(x, probabilities=probs).cpu(), tol)
+    close(g["enc_out"], m.encoder(x).cpu(), tol)
+    close(g["w"], stn.latent_to_w(m.S, [(z, m.G.num_layers)], probs)[0][0].cpu(), tol)
+
+
+def test_newarch_init_and_conditional_d_cpu():
+    check_newarch_init()
+
+
+def test_newarch_step_parity_cpu(tmp_path):
+    """Trainer.train() x 3 of the reference's stylex_train_new.py (conditional D, probabilities in W, encoder lr group,
+    single backward of gen + rec + kl)."""
+    import stylex_train_new as stn
+
+    g = load_golden("steps_newarch")
+    tr, n = make_trainer(g, tmp_path, trainer_cls=stn.Trainer)
+    assert tr.new_architecture and tr.rec_scaling == 2 and tr.kl_scaling == 2
+    rows = run_steps(tr, n)
+    gold = g["scalars"]
+    np.testing.assert_allclose(rows[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
+    np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
+    assert_param_stats(tr, g)
