@@ -962,9 +962,21 @@ int launch_igemm(const ConvKParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// Launches with 4096 <= M rows but at most 256 tiles of 128x128 (the 8x8 px 512->512 layers at B = 64..128) run 64x64
+// tiles: 4x the blocks at 37 KB of LDS each -> 4 resident per CU, so the K loop's load latency overlaps across blocks
+// (measured at B = 128: forward .165 -> .132 ms, data gradient .181 -> .143).  Below that (4x4 / 2x2 px) the 128x128
+// tile with split-K stays: the small tile measured 2x slower there (.054 -> .101 ms).  STYLEX_IGEMM_SMALL=0 disables.
+static bool igemm_small_tile(const ConvKParams& p) {
+    static const int mode = getenv("STYLEX_IGEMM_SMALL") ? atoi(getenv("STYLEX_IGEMM_SMALL")) : 1;
+    if (!mode || p.N <= 64 || p.N % 64 != 0) return false;
+    long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return (mode == 2 || p.M >= 4096) && blocks128 <= 256;
+}
+
 template <bool VEC4, bool BF16, int BKT, bool ABF = false>
 int dispatch_igemm(const ConvKParams& p, hipStream_t s) {
     // tile choice by output-channel count
+    if (ABF && BKT == 64 && igemm_small_tile(p)) return launch_igemm<2, 2, 1, 1, VEC4, BF16, BKT, ABF>(p, s);
     if (p.N > 64) return launch_igemm<2, 2, 2, 2, VEC4, BF16, BKT, ABF>(p, s);
     if (p.N > 32) return launch_igemm<4, 1, 2, 2, VEC4, BF16, BKT, ABF>(p, s);
     return launch_igemm<4, 1, 2, 1, VEC4, BF16, BKT, ABF>(p, s);
@@ -991,7 +1003,8 @@ int launch_wgrad(const ConvKParams& p, int blocks, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // tile geometry chosen by dispatch_igemm (must stay in sync with it)
 static void igemm_tile(const ConvKParams& p, int* bm, int* bn) {
-    if (p.N > 64) { *bm = 128; *bn = 128; }
+    if (p.act_bf16 && p.Ck % 8 == 0 && igemm_small_tile(p)) { *bm = 64; *bn = 64; }
+    else if (p.N > 64) { *bm = 128; *bn = 128; }
     else if (p.N > 32) { *bm = 256; *bn = 64; }
     else { *bm = 256; *bn = 32; }
 }

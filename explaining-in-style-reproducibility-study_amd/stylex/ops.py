@@ -523,6 +523,17 @@ class _DownS2DFast(torch.autograd.Function):
         return gx2, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None
 
 
+def _fork_side(t):
+    """Companion stream for the 1x1 residual path of a fused DiscriminatorBlock (networks._side_stream), or None."""
+    # off by default: measured 699 vs 700 images/s with / without it (the fused block leaves too little idle time for
+    # a second stream to fill); STYLEX_DBLOCK_SIDE=1 switches it on for experiments
+    if os.environ.get("STYLEX_DBLOCK_SIDE", "0") != "1":
+        return None
+    import networks
+
+    return networks._side_stream(t)
+
+
 class _DBlockFast(torch.autograd.Function):
     """A whole DiscriminatorBlock (reference :721-744) as ONE autograd node on the fused kernels:
 
@@ -547,23 +558,43 @@ class _DBlockFast(torch.autograd.Function):
             wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], x.shape[1] - 3, 1, 1)], dim=1)
         else:
             w1p, wrp = w1, w_res
-        xs = hb.subsample2_fwd(x) if downsample else x
-        res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
+        # the 1x1 residual path (even-pixel gather + small GEMM) is independent of the two 3x3 convs until the merge:
+        # companion HIP stream, joined before the kernel that merges
+        side = _fork_side(x)
+        if side is None:
+            xs = hb.subsample2_fwd(x) if downsample else x
+            res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
+        else:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                xs = hb.subsample2_fwd(x) if downsample else x
+                res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
+            x.record_stream(side)
         y1 = hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True)
         y2 = hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True)
         s2d, xb = False, None
+        def join():
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                res.record_stream(torch.cuda.current_stream())
+                xs.record_stream(torch.cuda.current_stream())
+
         if downsample:
             n, h, w = y2.shape[1], y2.shape[2], y2.shape[3]
             s2d = (_PRECISION != hb.F32 and n % 64 == 0 and h % 2 == 0 and w % 2 == 0 and w // 2 >= 16 and h // 2 >= 16)
             if s2d:
                 xb = hb.blur3x3_s2d_fwd(y2)
+                join()
                 wf2, _ = hb.pack_weight_s2d(w3)
                 out = hb.conv2d_fwd(xb, None, 1, 1, _PRECISION, bias=b3, residual=res, res_scale=c, packed=wf2,
                                     w_shape=(w3.shape[0], 4 * n, 3, 3), s2d_c=n)
             else:
                 xb = hb.blur3x3_fwd(y2)
+                join()
                 out = hb.conv2d_fwd(xb, w3, 2, 1, _PRECISION, bias=b3, residual=res, res_scale=c)
         else:
+            join()
             out = (y2 + res) * c
         ctx.save_for_backward(x, xs if downsample else None, y1, y2, xb, w_res, w1, w2, w3)
         ctx.cfg = (bool(downsample), s2d, cin, c)
@@ -597,6 +628,29 @@ class _DBlockFast(torch.autograd.Function):
             gsum3 = gz3.sum(dim=(0, 2, 3), dtype=torch.float32) if want_b else None
         wsc = c if alg else 1.0  # factor still owed by gradients computed from the unscaled gz3
         gb_res = gsum3  # the per-channel sum is the bias gradient of BOTH conv_res and the down conv
+        if cin == 3:  # x was saved padded; only the weights need padding again
+            extra = x.shape[1] - 3
+            w1p = torch.cat([w1, w1.new_zeros(w1.shape[0], extra, 3, 3)], dim=1)
+            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], extra, 1, 1)], dim=1)
+        else:
+            w1p, wrp = w1, w_res
+        # residual path (1x1 weight gradient + data gradient on the quarter-size tensor): companion stream, joined
+        # before its results are used at the end
+        side_bwd, side_out, main = _fork_side(g_out), None, torch.cuda.current_stream() if g_out.is_cuda else None
+        if side_bwd is not None:
+            side_bwd.wait_stream(main)
+            with torch.cuda.stream(side_bwd):
+                s_gw = s_gx = None
+                if want_w:
+                    s_gw = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec)
+                    if alg:
+                        s_gw = s_gw * wsc
+                if want_x:
+                    wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
+                    s_gx = hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+                side_out = (s_gw, s_gx)
+            gz3.record_stream(side_bwd)
+            xs.record_stream(side_bwd)
         if downsample:
             gb3 = gsum3
             n = y2.shape[1]
@@ -625,23 +679,28 @@ class _DBlockFast(torch.autograd.Function):
         gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1)  # + LeakyReLU derivative of y1
         if want_b:
             gb1 = _channel_sum(gz1)
-        if cin == 3:  # x was saved padded; only the weights need padding again
-            extra = x.shape[1] - 3
-            w1p = torch.cat([w1, w1.new_zeros(w1.shape[0], extra, 3, 3)], dim=1)
-            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], extra, 1, 1)], dim=1)
-        else:
-            w1p, wrp = w1, w_res
+        gxs = None
         if want_w:
             gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec)
-            gw_res = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec)
-            if alg:
-                gw_res = gw_res * wsc
-            if cin == 3:
-                gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
         if want_x:
             gx = hb.conv2d_bwd_data(gz1, w1p, tuple(x.shape), 1, 1, prec)
-            wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
-            gxs = hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+        if side_bwd is not None:  # join: the residual-path gradients were issued on the companion stream above
+            gw_res, gxs = side_out
+            main.wait_stream(side_bwd)
+            for t in (gw_res, gxs):
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            if want_w:
+                gw_res = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec)
+                if alg:
+                    gw_res = gw_res * wsc
+            if want_x:
+                wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
+                gxs = hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+        if want_w and cin == 3:
+            gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
+        if want_x:
             if downsample:
                 hb.add_at_even_(gx, gxs)  # adjoint of the even-pixel gather, summed in place
             else:

@@ -146,10 +146,17 @@ class _Staging:
                 slot[1].synchronize()
         return slot
 
+    DEVICE_RNG = os.environ.get("STYLEX_DEVICE_RNG", "0") == "1"
+
     @classmethod
     def upload(cls, shape, fill, device):
-        """fill(buf) draws in place on the CPU generator (same stream consumption as torch.randn/empty+fill)."""
+        """fill(buf) draws in place on the CPU generator (same stream consumption as torch.randn/empty+fill).
+        DEVICE_RNG (STYLEX_DEVICE_RNG=1 / Trainer(device_rng=True)): draw on the GPU generator instead — no 9 ms host
+        draw and no 8 MB upload per noise plane, but a different random stream than the reference's CPU one (the
+        parity default keeps the CPU draw order)."""
         device = _dev(device)
+        if device.type == "cuda" and cls.DEVICE_RNG:
+            return fill(torch.empty(shape, device=device))
         if device.type != "cuda":
             return fill(torch.empty(shape)).to(device)
         slot = cls.take(shape)
@@ -503,7 +510,8 @@ class Trainer:
                  classifier_name=None,
                  # --- extensions (defaults reproduce the reference) ---
                  classifier=None, lpips_fn=None, gp_every=4, pl_every=32, pl_after=5000, device=None,
-                 save_training_state=False, graphs=None, graph_warmup=4, new_architecture=False, *args, **kwargs):
+                 save_training_state=False, graphs=None, graph_warmup=4, new_architecture=False, device_pipeline=None,
+                 device_rng=None, *args, **kwargs):
         kl_rec_during_disc = kwargs.pop("kl_rec_during_disc", False)  # cli.py forwards it; only the new architecture reads it
         # new_architecture = the conditional-D variant the reference ships as stylex_train_new.py (cli.py:17-22)
         self.new_architecture = bool(new_architecture)
@@ -570,6 +578,11 @@ class Trainer:
         self.graph_warmup = graph_warmup
         self._static, self._graph_cache, self._graph_pool, self._calls = {}, {}, None, 0
         self._nan_hook = os.environ.get("STYLEX_NAN_HOOK", "0") == "1"
+        # N2 (input_pipeline.py): decode-only workers + prefetch thread + on-device resize / crop / scaling
+        self.device_pipeline = (os.environ.get("STYLEX_DEVICE_PIPELINE", "0") == "1") if device_pipeline is None \
+            else bool(device_pipeline)
+        if device_rng is not None:
+            _Staging.DEVICE_RNG = bool(device_rng)
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
         if classifier is not None:
@@ -645,14 +658,24 @@ class Trainer:
     def set_data_src(self, folder="./", dataset_name=None):
         if dataset_name == "MNIST":
             self.dataset = MNIST_1vA(digit=8)
-        self.dataset = Dataset(folder, self.image_size, transparent=self.transparent, aug_prob=self.dataset_aug_prob)
         num_workers = default(self.num_workers, NUM_CORES if not self.is_ddp else 0)
-        sampler = DistributedSampler(self.dataset, rank=self.rank, num_replicas=self.world_size,
-                                     shuffle=True) if self.is_ddp else None
-        loader = data.DataLoader(self.dataset, num_workers=num_workers,
-                                 batch_size=math.ceil(self.batch_size / self.world_size), sampler=sampler,
-                                 shuffle=not self.is_ddp, drop_last=True, pin_memory=torch.cuda.is_available())
-        self.loader = cycle(loader)
+        if self.device_pipeline:
+            import input_pipeline
+
+            probe = input_pipeline.RawImageFolder(folder, self.image_size, transparent=self.transparent)
+            sampler = DistributedSampler(probe, rank=self.rank, num_replicas=self.world_size,
+                                         shuffle=True) if self.is_ddp else None
+            self.loader, self.dataset = input_pipeline.make_device_loader(
+                folder, self.image_size, math.ceil(self.batch_size / self.world_size), self.device,
+                num_workers=num_workers, transparent=self.transparent, sampler=sampler, shuffle=not self.is_ddp)
+        else:
+            self.dataset = Dataset(folder, self.image_size, transparent=self.transparent, aug_prob=self.dataset_aug_prob)
+            sampler = DistributedSampler(self.dataset, rank=self.rank, num_replicas=self.world_size,
+                                         shuffle=True) if self.is_ddp else None
+            loader = data.DataLoader(self.dataset, num_workers=num_workers,
+                                     batch_size=math.ceil(self.batch_size / self.world_size), sampler=sampler,
+                                     shuffle=not self.is_ddp, drop_last=True, pin_memory=torch.cuda.is_available())
+            self.loader = cycle(loader)
         num_samples = len(self.dataset)
         if not exists(self.aug_prob) and num_samples < 1e5:
             self.aug_prob = min(0.5, (1e5 - num_samples) * 3e-6)

@@ -25,3 +25,18 @@ def test_two_runs_are_bit_identical_with_streams_on():
         os.chdir(cwd)
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert runs[0][1] == runs[1][1]
+
+
+def test_two_runs_are_bit_identical_without_per_step_sync():
+    """Same check with the host running ahead (no loss is read until the end): the configuration real training and
+    bench.py run in, where a missing cross-stream dependency has the most room to show."""
+    import determinism_check
+
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        runs = determinism_check.run(steps=6, image_size=128, batch=16, lazy=True)
+    finally:
+        os.chdir(cwd)
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1]
