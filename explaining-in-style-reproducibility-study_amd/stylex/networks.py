@@ -29,7 +29,6 @@ def exists(v):
 
 
 _SIDE = {}
-CAPTURE_ORIGIN = None  # raw handle of the stream a HIP-graph capture started on (set by Trainer._capture)
 atexit.register(_SIDE.clear)  # streams are released before the interpreter (and the HIP runtime) shut down
 
 
@@ -41,11 +40,11 @@ def _side_stream(t, which=0):
 
     if not t.is_cuda or os.environ.get("STYLEX_STREAMS", "1") == "0":
         return None
-    if torch.cuda.is_current_stream_capturing() and torch.cuda.current_stream().cuda_stream != CAPTURE_ORIGIN:
-        # Under HIP-graph capture only ONE level of fork/join is used: a side stream forked from a stream that is
-        # itself a fork of the capturing stream makes hipStreamEndCapture crash (ROCm 7.2; every single-level
-        # pattern captures fine — tools/graph_stage_probe.py).  The Trainer-level branches keep their streams,
-        # the per-block fork inside such a branch runs inline.
+    if torch.cuda.is_current_stream_capturing():
+        # Under HIP-graph capture only the Trainer-level branch forks are used.  A block-level fork that is open at
+        # the same time as a Trainer-level one (the gradient-penalty step: D(real) with its per-block companion
+        # stream on the capturing stream while D(fake) runs on a Trainer side stream), or one nested inside a Trainer
+        # branch, makes hipStreamEndCapture crash (ROCm 7.2; tools/graph_stage_probe.py) — the block runs inline.
         return None
     key = (t.device, torch.cuda.current_stream().cuda_stream, which)
     if key not in _SIDE:

@@ -34,7 +34,6 @@ from torch.optim import Adam
 from torch.utils import data
 from torch.utils.data.distributed import DistributedSampler  # noqa: F401  (re-exported for the notebook)
 
-import networks
 import ops
 import parallel
 from lpips_alex import LPIPS
@@ -576,7 +575,7 @@ class Trainer:
         # both step shapes, MIOpen's algorithm search and the allocator have been exercised before the capture
         self.graphs = (os.environ.get("STYLEX_GRAPHS", "0") == "1") if graphs is None else bool(graphs)
         self.graph_warmup = graph_warmup
-        self._static, self._graph_cache, self._graph_pool, self._calls = {}, {}, None, 0
+        self._static, self._graph_cache, self._graph_pool, self._calls, self._graph_warm = {}, {}, None, 0, set()
         self._nan_hook = os.environ.get("STYLEX_NAN_HOOK", "0") == "1"
         # N2 (input_pipeline.py): decode-only workers + prefetch thread + on-device resize / crop / scaling
         self.device_pipeline = (os.environ.get("STYLEX_DEVICE_PIPELINE", "0") == "1") if device_pipeline is None \
@@ -622,7 +621,7 @@ class Trainer:
                              attn_layers=self.attn_layers, no_const=self.no_const, rank=self.device,
                              classifier_labels=self.num_classes, capturable=self.graphs,
                              conditional=self.new_architecture, *args, **kwargs)
-        self._graph_cache, self._static = {}, {}  # graphs captured for a previous model instance are void
+        self._graph_cache, self._static, self._graph_warm = {}, {}, set()  # graphs of a previous model instance are void
         if self.is_ddp:
             m = self.StylEx
             parallel.broadcast_parameters(m)
@@ -753,12 +752,12 @@ class Trainer:
 
     def _styles_of(self, entry, probs=None):
         """[B, L, latent] style tensor of a noise micro-step: ('noise', [(z, n_layers), ...], inoise) as drawn by
-        noise_list / mixed_list, or the graph form ('noise_static', z1, z2, inoise, tt) whose layer split `tt` is a
+        noise_list / mixed_list, or the graph form ('noise_static', (z1, z2, tt), inoise, None) whose layer split `tt` is a
         device scalar, so that one captured graph serves every split (pure selection: identical values)."""
         m = self.StylEx
         if entry[0] == "noise":
             return styles_def_to_tensor(latent_to_w(m.S, entry[1], probs))
-        _, z1, z2, _, tt = entry
+        z1, z2, tt = entry[1]
         w1, w2 = m.S(z1), m.S(z2)
         first = torch.arange(m.G.num_layers, device=z1.device) < tt
         return torch.where(first[None, :, None], w1[:, None, :], w2[:, None, :])
@@ -922,7 +921,12 @@ class Trainer:
             conds.append(p_i)
         cond = _cat(conds) if new else None
         w_all = _cat(ws)
+        # path-length regularisation differentiates the GENERATOR twice (d images / d styles, then the loss on it):
+        # only G runs on the composable double-differentiable ops; the encoder above and D / encoder / classifier /
+        # LPIPS below are differentiated once and keep the fused path
+        ops.set_fast(not apply_pl)
         generated_all = m.G(w_all, _cat([e[2] for e in micro]))
+        ops.set_fast(True)
         pl_all = calc_pl_lengths(w_all, generated_all, _cat(pl_noises)) if (apply_pl and pl_noises) else None
         # four independent consumers of the generated batch: D, and per encoder micro-step the classifier,
         # the encoder and LPIPS — forked over HIP streams (see _fork)
@@ -987,7 +991,7 @@ class Trainer:
 
     def _g_phase(self, groups, inputs, apply_pl, gae, fuse, acc, st=None):
         m = self.StylEx
-        ops.set_fast(not apply_pl)  # path-length regularisation is the only double backward of this phase
+        ops.set_fast(True)  # first-order everywhere except the generator of a path-length step (see _g_compute)
         self._zero_grad("G")
         set_requires_grad(m.D, False)  # D weight-gradients of this phase are discarded by :1297 anyway
         try:
@@ -1125,7 +1129,7 @@ class Trainer:
         if tt is None:
             tt = self._static[(phase, i, "tt")] = torch.zeros((), dtype=torch.int64, device=self.device)
         tt.fill_(style[0][1] if len(style) > 1 else layers)
-        return ("noise_static", z1, z2, self._bind((phase, i, "n"), e[2]), tt)
+        return ("noise_static", (z1, z2, tt), self._bind((phase, i, "n"), e[2]), None)
 
     def _train_graphed(self, group, st, apply_gp, gae):
         m = self.StylEx
@@ -1139,15 +1143,37 @@ class Trainer:
         reals = [self._bind(("d", i, "real"), r) for i, r in enumerate(reals)]
         micro_d = [self._bind_micro("d", i, e, layers) for i, e in enumerate(micro_d)]
         micro_g = [self._bind_micro("g", i, e, layers) for i, e in enumerate(micro_g)]
-        self._resolve_losses()
         entry = self._graph_cache.get(apply_gp)
+        if entry is None:
+            self._resolve_losses()
+        if entry is None and apply_gp not in self._graph_warm:
+            # first eligible call of this step shape: run the exact code path of the capture (static input buffers,
+            # device-side layer split) EAGERLY once — every kernel it launches must have been loaded before a capture
+            # starts (a first-time kernel load inside a capture is not capturable)
+            self._graph_warm.add(apply_gp)
+            acc = self._new_acc()
+            self._d_phase([group], [(reals, micro_d)], apply_gp, gae, True, acc)
+            if self.is_ddp:
+                self._d_sync.all_reduce()
+            m.D_opt.step()
+            self._g_phase([group], [(micro_g, [])], False, gae, True, acc)
+            if self.is_ddp:
+                self._g_sync.all_reduce()
+            m.G_opt.step()
+            self._bump_packs()
+            return self._loss_stack(acc)
         if entry is None:
             entry = self._capture(apply_gp, gae, [group], [(reals, micro_d)], [(micro_g, [])])
             self._graph_cache[apply_gp] = entry
+        resolve = self._pending is not None
         graphs, out = entry
         syncs = [self._d_sync.all_reduce, self._g_sync.all_reduce, None] if self.is_ddp else [None, None, None]
-        for g, sync in zip(graphs, syncs):
+        for gi, (g, sync) in enumerate(zip(graphs, syncs)):
             g.replay()
+            if gi == 0 and resolve:
+                # previous step's scalars, read where the eager path reads them: AFTER this step's discriminator phase
+                # is queued, so the GPU never runs dry while the host waits for that copy
+                self._resolve_losses()
             if sync is not None:
                 sync()
         self._bump_packs()
@@ -1175,19 +1201,24 @@ class Trainer:
         # branch streams on crashes hipStreamEndCapture (ROCm 7.2, tools/graph_stage_probe.py stage "step")
         segments = [[seg_d], [seg_g], [seg_tail]]
         torch.cuda.synchronize()
-        if self._graph_pool is None:
+        dbg = os.environ.get("STYLEX_GRAPH_DEBUG", "0") == "1"
+        share_pool = os.environ.get("STYLEX_GRAPH_POOL", "1") == "1"
+        mode = os.environ.get("STYLEX_GRAPH_MODE", "thread_local")
+        if self._graph_pool is None and share_pool:
             self._graph_pool = torch.cuda.graph_pool_handle()
         graphs = []
-        for fns in segments:
+        for si, fns in enumerate(segments):
             self._bump_packs()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
-                networks.CAPTURE_ORIGIN = torch.cuda.current_stream().cuda_stream
-                try:
-                    for fn in fns:
-                        fn()
-                finally:
-                    networks.CAPTURE_ORIGIN = None
+            if dbg:
+                print("capture: gp=%s segment %d begin" % (apply_gp, si), flush=True)
+            with torch.cuda.graph(g, pool=self._graph_pool if share_pool else None, capture_error_mode=mode):
+                for fn in fns:
+                    fn()
+                if dbg:
+                    print("capture: segment %d body recorded, ending capture" % si, flush=True)
+            if dbg:
+                print("capture: segment %d done" % si, flush=True)
             graphs.append(g)
         self._bump_packs()
         return graphs, acc["out"]

@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd")
 for p in (os.path.join(PKG, "stylex"), PKG, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 
-STAGES = ["d_phase_gp", "g_phase", "step"]
+STAGES = ["step"]
 
 
 def capture(fn, warm=3, mode="thread_local"):
@@ -211,7 +211,7 @@ def run_stage(name):
         if name == "step_nostreams":
             os.environ["STYLEX_STREAMS"] = "0"
         tr = trainer()
-        for i in range(12):
+        for i in range(16):
             tr.train()
             print("step", i, "captured", sorted(tr._graph_cache), flush=True)
         print("losses", tr.d_loss, tr.g_loss, flush=True)
@@ -222,9 +222,16 @@ def main():
     if len(sys.argv) > 1:
         run_stage(sys.argv[1])
         return
-    for s in STAGES:
+    variants = [("", {})]
+    if os.environ.get("PROBE_VARIANTS") == "1":
+        variants = [("default", {}), ("nopool", {"STYLEX_GRAPH_POOL": "0"}), ("global", {"STYLEX_GRAPH_MODE": "global"}),
+                    ("relaxed", {"STYLEX_GRAPH_MODE": "relaxed"}), ("nodblock", {"STYLEX_DBLOCK": "0"}),
+                    ("nostreams", {"STYLEX_STREAMS": "0"})]
+    for s, (vname, venv) in [(s, v) for s in STAGES for v in variants]:
+        env = dict(os.environ, STYLEX_GRAPH_DEBUG="1", **venv)
         p = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__), s], capture_output=True,
-                           text=True, timeout=600)
+                           text=True, timeout=600, env=env)
+        s = s + ":" + vname
         ok = "STAGE_OK" in p.stdout
         print("=== %-12s rc=%d %s" % (s, p.returncode, "OK" if ok else "FAILED"), flush=True)
         if not ok:
