@@ -310,13 +310,14 @@ def main():
     if rank == 0:
         gf = algorithmic_gflop_per_image(args.gae)
         line = {
-            "metric": "StylEx G+D+enc train-step images/sec @256px", "value": round(value, 2), "unit": "images/sec",
+            "metric": "StylEx G+D+enc train-step images/sec @%dpx" % args.image_size, "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (torch.rand 256x256 batches resident in HBM, random-init weights, seeded "
                     "random-weight ResNet-18 classifier and LPIPS-AlexNet)",
-            "config": {"workload": "FFHQ 256x256 StylEx, batch 32/GPU, GAE=%d (noise+encoder micro-steps), GP every "
-                                   "4th step, ResNet-18 classifier" % args.gae,
+            "config": {"workload": "FFHQ-shaped %dx%d StylEx, batch %d/GPU, GAE=%d (noise+encoder micro-steps), GP every "
+                                   "4th step, %s classifier" % (args.image_size, args.image_size, args.batch, args.gae,
+                                                                "ResNet-18" if args.classifier == "resnet" else "MobileNetV2"),
                        "image_size": args.image_size, "batch_per_gpu": args.batch,
                        "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
                        "parallelism": "dp%d" % world,

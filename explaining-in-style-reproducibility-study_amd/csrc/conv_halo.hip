@@ -243,14 +243,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                // natural-order noise plane: the 4 accumulator rows r = 4q .. 4q+3 are 4 consecutive pixels of one image
+                // row -> one aligned 16-byte load each (the transposed plane needs 16 strided 4-byte loads)
+                float nz[16];
+                if (EPIX && (p.flags & STYLEX_EPI_NOISE) && (p.flags & STYLEX_EPI_NOISE_NAT)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pix0 = wave * 64 + i * 32 + 8 * q + 4 * lh;
+                        const int ph = pix0 / TW, pw = pix0 - ph * TW;
+                        const int y = min(y0 + ph, p.noise_stride - 1), x = min(x0 + pw, p.noise_stride - 4);
+                        const float4 t = *reinterpret_cast<const float4*>(p.noise + ((long)b * p.noise_stride + y) * p.noise_stride + x);
+                        nz[4 * q] = t.x;
+                        nz[4 * q + 1] = t.y;
+                        nz[4 * q + 2] = t.z;
+                        nz[4 * q + 3] = t.w;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pix = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float v = acc[i][j][r] * osc + bias;
+                    if (EPIX && (p.flags & STYLEX_EPI_NOISE) && (p.flags & STYLEX_EPI_NOISE_NAT)) v += nz[r] * nw + nb;
                     if (EPIX && (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE))) {
                         const int ph = pix / TW, pw = pix - ph * TW;
                         const int y = min(y0 + ph, H - 1), x = min(x0 + pw, W - 1);
-                        if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
+                        if ((p.flags & STYLEX_EPI_NOISE) && !(p.flags & STYLEX_EPI_NOISE_NAT))
+                            v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
                         if ((p.flags & STYLEX_EPI_RESIDUAL) && nok)
                             v = (v + act_ld1(p.residual, ((long)(b * H + y) * W + x) * p.N + n, p.act_bf16)) * p.res_scale;
                         if ((p.flags & STYLEX_EPI_GATE) && nok)
@@ -302,7 +320,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 long o = ((long)(b * H + y) * W + x) * p.N + n;
                 float v = acc[i][j][r] * osc;
                 if (p.flags & STYLEX_EPI_BIAS) v += bias;
-                if (p.flags & STYLEX_EPI_NOISE) v += p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y] * nw + nb;
+                if (p.flags & STYLEX_EPI_NOISE)
+                    v += ((p.flags & STYLEX_EPI_NOISE_NAT) ? p.noise[((long)b * p.noise_stride + y) * p.noise_stride + x]
+                                                           : p.noise[((long)b * p.noise_stride + x) * p.noise_stride + y]) * nw + nb;
                 if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
                 if (p.flags & STYLEX_EPI_GATE) v = act_ld1(p.residual, o, p.act_bf16) > 0.f ? v : p.res_scale * v;
                 if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
@@ -339,7 +359,9 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return STYLEX_NOT_APPLICABLE;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return STYLEX_NOT_APPLICABLE;
     {
-        int rc = stylex_launch_halo_dma(p, s);
+        int rc = stylex_launch_ws(p, s);
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+        rc = stylex_launch_halo_dma(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
     const bool wide = p.Wo >= 32;

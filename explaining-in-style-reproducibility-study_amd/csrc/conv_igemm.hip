@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvKParams p) {
                 if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)rp.b * p.N + n];
                 if (p.flags & STYLEX_EPI_BIAS) v += bias[j];
                 if (p.flags & STYLEX_EPI_NOISE)
-                    v += p.noise[((long)rp.b * p.noise_stride + rp.ow) * p.noise_stride + rp.oh] * nw[j] + nb[j];
+                    v += ((p.flags & STYLEX_EPI_NOISE_NAT) ? p.noise[((long)rp.b * p.noise_stride + rp.oh) * p.noise_stride + rp.ow]
+                                                           : p.noise[((long)rp.b * p.noise_stride + rp.ow) * p.noise_stride + rp.oh]) * nw[j] + nb[j];
                 if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
                 if (p.flags & STYLEX_EPI_GATE) v = act_ld1(p.residual, o, p.act_bf16) > 0.f ? v : p.res_scale * v;
                 if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);
@@ -839,7 +840,8 @@ __device__ __forceinline__ float splitk_finish(const ConvKParams& p, float v, lo
     if (p.flags & STYLEX_EPI_OSCALE) v *= p.out_scale[(long)b * p.N + n];
     if (p.flags & STYLEX_EPI_BIAS) v += p.bias[n];
     if (p.flags & STYLEX_EPI_NOISE)
-        v += p.noise[((long)b * p.noise_stride + ow) * p.noise_stride + oh] * p.noise_w[n] + p.noise_b[n];
+        v += ((p.flags & STYLEX_EPI_NOISE_NAT) ? p.noise[((long)b * p.noise_stride + oh) * p.noise_stride + ow]
+                                               : p.noise[((long)b * p.noise_stride + ow) * p.noise_stride + oh]) * p.noise_w[n] + p.noise_b[n];
     if (p.flags & STYLEX_EPI_RESIDUAL) v = (v + act_ld1(p.residual, o, p.act_bf16)) * p.res_scale;
     if (p.flags & STYLEX_EPI_GATE) v = act_ld1(p.residual, o, p.act_bf16) > 0.f ? v : p.res_scale * v;
     if (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) v = v > 0.f ? v : ((p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f * v);

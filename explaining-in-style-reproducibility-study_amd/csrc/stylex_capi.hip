@@ -236,6 +236,9 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
     }
     if ((flags & STYLEX_EPI_BIAS) && !p.bias) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
+    if ((flags & STYLEX_EPI_NOISE_NAT) && (!(flags & STYLEX_EPI_NOISE) || (reinterpret_cast<uintptr_t>(p.noise) & 15) ||
+                                           p.noise_stride % 4 != 0))
+        return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_NOISE) && (!p.noise || !p.noise_w || !p.noise_b || p.noise_stride < p.Ho || p.noise_stride < p.Wo))
         return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_RESIDUAL) && !p.residual) return STYLEX_EINVAL;

@@ -51,6 +51,9 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s);
 // LDS-DMA variant of the halo kernel for the >= 128-channel unscaled layers (conv_halo_dma.hip)
 int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s);
 
+// weights-stationary persistent streaming kernel for the C, N <= 64 layers at >= 128^2 (conv_ws.hip)
+int stylex_launch_ws(const ConvKParams& p, hipStream_t s);
+
 // 3x3/s1/p1 bf16 weight gradient with resident halo + LDS transpose reads (conv_wgrad_halo.hip)
 bool stylex_wgrad_halo_applicable(const ConvKParams& p);
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylex_hip.so")
 
 F32, BF16, BF16_ACT = 0, 1, 2  # BF16_ACT: bf16 MFMA + bf16 activation tensors in HBM
-EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL, EPI_RELU, EPI_GATE = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL, EPI_RELU, EPI_GATE, EPI_NOISE_NAT = 1, 2, 4, 8, 16, 32, 64, 128
 
 _c_f = ctypes.c_void_p  # device pointers travel as void*
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -295,7 +295,8 @@ def _split_workspace(lib, shp, which, precision, like):
 
 
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
-               noise_w=None, noise_b=None, residual=None, res_scale=1.0, packed=None, w_shape=None, s2d_c=0):
+               noise_w=None, noise_b=None, residual=None, res_scale=1.0, packed=None, w_shape=None, s2d_c=0,
+               noise_natural=False):
     """x: channels_last [B,C,H,W] in the precision's activation dtype; w: OIHW parameter.
     Returns channels_last [B,N,Ho,Wo] of the same dtype."""
     lib = _ensure_device(x)
@@ -327,7 +328,7 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
     if noise is not None:
         noise, noise_w, noise_b = _f32(noise), _f32(noise_w), _f32(noise_b)
         keep += [noise, noise_w, noise_b]
-        flags |= EPI_NOISE
+        flags |= EPI_NOISE | (EPI_NOISE_NAT if noise_natural else 0)
         epi.noise = noise.data_ptr()
         epi.noise_stride = noise.shape[1]
         epi.noise_w = noise_w.data_ptr()

@@ -54,6 +54,9 @@ extern "C" {
 #define STYLEX_EPI_NOISE 8     /* + noise[b][w][h] * noise_w[n] + noise_b[n] (sic: transposed) */
 #define STYLEX_EPI_RESIDUAL 16 /* (acc + residual[m][n]) * res_scale                 */
 #define STYLEX_EPI_RELU 32     /* max(v, 0) last (instead of LRELU; frozen ResNet blocks) */
+#define STYLEX_EPI_NOISE_NAT 128 /* with STYLEX_EPI_NOISE: the noise plane is in NATURAL order, value used at (h,w) is
+                                 * noise[b][h][w] (the caller transposed the reference's plane once per generator
+                                 * forward): the epilogue then reads 4 consecutive pixels with one 16-byte load */
 #define STYLEX_EPI_GATE 64     /* bwd_data only: dx *= (gate[m][c] > 0 ? 1 : res_scale) — the derivative of the
                                 * (Leaky)ReLU that produced this conv's input, applied while dx is written; the gate
                                 * tensor (= that input, [B][Hi][Wi][C], activation dtype) travels in epi->residual */

@@ -808,3 +808,72 @@ def test_graph_replay_matches_eager(tmp_path):
     assert np.isfinite(b).all()
     np.testing.assert_allclose(b[:4], a[:4], rtol=1e-4, atol=1e-5)  # eager + warm passes: same arithmetic
     np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("cn", [(64, 64), (64, 32), (32, 32), (32, 64)])
+def test_streaming_ws_kernel_matches_tile_kernels(cn):
+    """conv_ws.hip (weights-stationary persistent streaming kernel for the C, N <= 64 layers at >= 128^2; opt-in with
+    STYLEX_CONV_WS=1 — it measured slower, see the file header) against the per-tile kernels on the same inputs: forward with bias + LeakyReLU, plain data
+    gradient, data gradient with the activation gate, and the modulated data gradient (demodulation folded into the
+    staged weights, modulation as out_scale).  Same accumulation order -> bit-identical where no scale is folded."""
+    import os
+
+    C, N = cn
+    B, S = 8, 256  # 1024 tiles of 16x32 px: the streaming regime
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(21)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, dy, gate = mk(B, C, S, S), mk(B, N, S, S), mk(B, C, S, S)
+    w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    d = torch.rand(B, N, device=DEV, generator=g) + 0.5
+    s1 = torch.randn(B, C, device=DEV, generator=g) * 0.5 + 1.0
+
+    def run():
+        return (hb.conv2d_fwd(x, w, 1, 1, P, bias=bias, lrelu=True),
+                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, 1, P),
+                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, 1, P, gate=gate),
+                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, 1, P, in_scale=d, out_scale=s1))
+
+    ref = run()  # default: the per-tile kernels
+    os.environ["STYLEX_CONV_WS"] = "1"
+    try:
+        got = run()
+    finally:
+        os.environ.pop("STYLEX_CONV_WS", None)
+    names = ("fwd bias+lrelu", "dgrad", "dgrad+gate", "modulated dgrad")
+    for nm, a, b in zip(names, ref, got):
+        if nm == "modulated dgrad":
+            close(a.float(), b.float(), 2e-2, nm)  # scale folded into bf16 weights vs into bf16 activations
+        elif (C, N) == (64, 64):  # replaces the LDS-DMA kernel: same chunking and tap order -> bit-identical
+            assert torch.equal(a, b), "%s: max diff %g" % (nm, float((a.float() - b.float()).abs().max()))
+        else:  # replaces the register-staged kernel (32-channel chunks): summation order differs
+            close(a.float(), b.float(), 1e-2, nm)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 64, 32, 64, 64), (2, 32, 64, 32, 32), (2, 64, 64, 16, 16), (3, 16, 24, 8, 8)])
+def test_natural_order_noise_plane_epilogue(case, prec):
+    """STYLEX_EPI_NOISE_NAT (noise plane pre-transposed once per generator forward, 16-byte loads in the epilogue) gives
+    bit-identical results to the reference-order plane on every kernel family (LDS-halo wide / narrow, implicit GEMM)."""
+    B, C, N, H, W = case
+    ops.set_precision(prec)
+    P = {"fp32": hb.F32, "bf16": hb.BF16_ACT}[prec]
+    adt = hb.act_dtype(P)
+    g = torch.Generator(device=DEV).manual_seed(31)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g).to(adt).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
+    s1, d = torch.rand(B, C, device=DEV, generator=g) + 0.5, torch.rand(B, N, device=DEV, generator=g) + 0.5
+    inoise = torch.rand(B, 64, 64, 1, device=DEV, generator=g)
+    nw, nb = torch.randn(N, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g)
+    plane = inoise[:, :, :, 0]
+    ref = hb.conv2d_fwd(x, w, 1, 1, P, in_scale=s1, out_scale=d, noise=plane, noise_w=nw, noise_b=nb, lrelu=True)
+    nat = ops._natural_noise(inoise)
+    got = hb.conv2d_fwd(x, w, 1, 1, P, in_scale=s1, out_scale=d, noise=nat, noise_w=nw, noise_b=nb, lrelu=True, noise_natural=True)
+    assert torch.equal(ref, got), float((ref.float() - got.float()).abs().max())
+    # and against the definition: value at (h, w) is inoise[b, w, h]
+    want = F.leaky_relu(F.conv2d(x.float() * s1[:, :, None, None], w, padding=1) * d[:, :, None, None]
+                        + plane[:, :W, :H].transpose(1, 2)[:, None] * nw[None, :, None, None] + nb[None, :, None, None], 0.2)
+    close(want, got.float(), 1e-4 if prec == "fp32" else 3e-2, "noise epilogue vs definition")
