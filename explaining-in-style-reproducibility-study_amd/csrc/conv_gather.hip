@@ -1,0 +1,224 @@
+// conv_gather.hip — implicit-GEMM convolution for the SMALL-SPATIAL layers (<= 8x8 px, 512 -> 512 channels: blocks 5-7
+// and final_conv of the discriminator / encoder, initial_conv and blocks 0-1 of the generator; 3x3/s1/p1 and 1x1/s1),
+// bf16 NHWC, forward and data gradient.
+//
+// Those launches are a few GFLOP each; on the generic kernel (conv_igemm.hip: register-staged, ONE K-tile in flight)
+// they take 40-130 us whatever their size because the K loop (72 K-tiles for 3x3x512) is a chain of load latencies.
+// Here every operand row is fetched by LDS-DMA straight into the MFMA layout — the per-lane global address of a DMA
+// piece is free, so the im2col gather (pixel + tap offset, zero page for padding) costs nothing — through a 4-stage
+// LDS ring with THREE stages (96 KiB) in flight per block: the K loop runs at the MFMA rate once the pipe is primed.
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k],  m = (b, oh, ow), k = (tap, c),  A gathered from x[b, oh +- (kh-p), ow +- (kw-p), c]
+//
+// Block tile 128 (m) x 128 (n), 4 waves of 64 x 64 (2 x 2 MFMA 32x32x16 tiles).  A K stage = 64 channels of one tap = 4
+// groups of 16 channels; LDS image of a group: 128 A rows then 128 W rows of 32 bytes (halves swapped by bit 3 of the
+// row, as in conv_halo_dma.hip).  Launches that cannot fill the chip are split along K; every launch writes fp32
+// partials [ksplit][M][N] and the existing deterministic split-K epilogue kernel (conv_igemm.hip) applies the fused
+// epilogue (scales, bias, noise, residual, gate, activation) and the bf16 rounding.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "stylex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ uint4 g_zero_page_g[4];
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(1))) const void* gl_void_ptr;
+
+constexpr int GBM = 128, GBN = 128, ROW = 32;
+constexpr int GROUP_BYTES = (GBM + GBN) * ROW;   // 8 KiB: one 16-channel group of A and W rows
+constexpr int STAGE_BYTES = 4 * GROUP_BYTES;     // 32 KiB: 64 channels
+constexpr int RING = 4;
+constexpr int PIECES_PER_WAVE = 8;               // 32 pieces of 1 KiB per stage, 4 waves
+constexpr int SMEM_BYTES = RING * STAGE_BYTES;   // 128 KiB -> one block per CU
+
+struct GatherParams {
+    const unsigned short* x;   // [B][H][W][C] bf16
+    const unsigned short* w;   // [N][T][C] bf16 (forward pack, or data-gradient pack)
+    float* partial;            // [ksplit][M][N]
+    int B, H, W, C, N, KH, pad, sign;  // sign +1: forward gather oh + kh - p;  -1: data gradient oh + p - kh
+    int M, stages, ksplit, stages_per_split;
+};
+
+__global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (p.N + GBN - 1) / GBN;
+    const int m0 = (int)(blockIdx.x / n_tiles) * GBM, n0 = (int)(blockIdx.x % n_tiles) * GBN;
+    const int ks = blockIdx.y;
+    const int s_begin = ks * p.stages_per_split;
+    const int s_end = min(s_begin + p.stages_per_split, p.stages);
+    const int nst = s_end - s_begin;
+    const int cpt = p.C >> 6;  // stages per tap
+    const int T = p.KH * p.KH, K = T * p.C;
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page_g);
+
+    // this lane's rows: DMA piece q of a group = rows q*32 + lr of the A panel (q < 4) or of the W panel (q >= 4)
+    const int lr = lane >> 1, pslot = lane & 1;
+    const int slot = pslot ^ ((lr >> 3) & 1);  // logical 8-channel half this lane fetches
+    // a wave issues pieces (wave + 4*it): it even -> group (it/2)... piece index pi = wave + 4*it in [0, 32): group = pi >> 3,
+    // q = pi & 7.  For a fixed wave, q takes the two values wave and wave + 4: one A panel slice and one W panel slice.
+    const int a_rowl = wave * 32 + lr;          // A row (0..127) this lane stages
+    const int w_rowl = wave * 32 + lr;          // W row (0..127) this lane stages
+    // pixel of the A row
+    const int m = m0 + a_rowl;
+    const bool m_ok = m < p.M;
+    const int hw = p.H * p.W;
+    const int b = m_ok ? m / hw : 0;
+    const int q_ = m_ok ? m - b * hw : 0;
+    const int oh = q_ / p.W, ow = q_ - oh * p.W;
+    const long pix_base = ((long)(b * p.H + oh) * p.W + ow) * p.C;
+    const int n_row = n0 + w_rowl;
+    const bool n_ok = n_row < p.N;
+    const long w_base = (long)n_row * K;
+
+    auto issue_stage = [&](int s, int rs) {
+        const int tap = s / cpt, c0 = (s - tap * cpt) << 6;
+        const int kh = tap / p.KH, kw = tap - kh * p.KH;
+        const int dy = p.sign * (kh - p.pad), dx = p.sign * (kw - p.pad);
+        const int ih = oh + dy, iw = ow + dx;
+        const bool a_ok = m_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const unsigned short* asrc = p.x + pix_base + ((long)dy * p.W + dx) * p.C + c0 + slot * 8;
+        const unsigned short* wsrc = p.w + w_base + (long)tap * p.C + c0 + slot * 8;
+        char* base = smem + rs * STAGE_BYTES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_global_load_lds((gl_void_ptr)(a_ok ? asrc + g * 16 : zero),
+                                             (lds_void_ptr)(base + g * GROUP_BYTES + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gl_void_ptr)(n_ok ? wsrc + g * 16 : zero),
+                                             (lds_void_ptr)(base + g * GROUP_BYTES + GBM * ROW + wave * 1024), 16, 0, 0);
+        }
+    };
+
+    // MFMA operand rows: wave (wm, wn) owns rows wm*64 .. +63 of A and wn*64 .. +63 of W
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    const int swz = (((li >> 3) ^ lk) & 1) << 4;
+    const int a_off = (wm * 64 + li) * ROW + swz;              // + i*32*ROW + g*GROUP_BYTES
+    const int b_off = GBM * ROW + (wn * 64 + li) * ROW + swz;  // + j*32*ROW + g*GROUP_BYTES
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // prologue: three stages in flight
+    for (int s = 0; s < 3 && s < nst; ++s) issue_stage(s_begin + s, s);
+    for (int s = 0; s < nst; ++s) {
+        // stage s must have landed; loads complete in order, so allowing the 8 DMA instructions of each younger stage
+        // in flight proves it
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES_PER_WAVE) : "memory");
+        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // everyone's pieces of stage s are visible; everyone is done with ring slot (s + 3) % RING
+        if (s + 3 < nst) issue_stage(s_begin + s + 3, (s + 3) % RING);
+        const char* base = smem + (s % RING) * STAGE_BYTES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(base + g * GROUP_BYTES + a_off + i * 32 * ROW);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(base + g * GROUP_BYTES + b_off + j * 32 * ROW);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // raw fp32 partials: D[row = m][col = n], col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* out = p.partial + (long)ks * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (mm < p.M && n < p.N) out[(long)mm * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+}  // namespace
+
+// Plan: K stages of 64 channels; split along K until ~256 blocks exist, at least 4 stages per slice.
+static bool gather_applicable(const ConvKParams& p) {
+    const char* env = getenv("STYLEX_CONV_GATHER");
+    if (env && env[0] == '0') return false;
+    if (!p.act_bf16 || p.a_scale || p.s2d_c || p.phase_major) return false;
+    if (p.stride != 1 || p.KH != p.KW || !((p.KH == 3 && p.pad == 1) || (p.KH == 1 && p.pad == 0))) return false;
+    if (p.Hi != p.Ho || p.Wi != p.Wo || p.Ho * p.Wo > 64) return false;
+    if (p.Ck % 64 != 0 || p.N % 8 != 0 || p.N < 64) return false;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return false;
+    return true;
+}
+
+static void gather_plan(const ConvKParams& p, int* ksplit, int* per) {
+    const int stages = p.KH * p.KW * (p.Ck / 64);
+    const long tiles = (long)((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
+    int ks = (int)((256 + tiles - 1) / tiles);
+    if (ks > stages / 4) ks = stages / 4;
+    if (ks < 1) ks = 1;
+    int pp = (stages + ks - 1) / ks;
+    *per = pp;
+    *ksplit = (stages + pp - 1) / pp;
+}
+
+int64_t stylex_gather_workspace_bytes(const ConvKParams& p) {
+    if (!gather_applicable(p)) return 0;
+    int ks, per;
+    gather_plan(p, &ks, &per);
+    return (int64_t)ks * p.M * p.N * (int64_t)sizeof(float);
+}
+
+// Fills p.ksplit / p.partial for the split-K epilogue the caller launches afterwards.  STYLEX_NOT_APPLICABLE when the
+// shape is not covered or the workspace is too small.
+int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    if (!gather_applicable(p) || !workspace) return STYLEX_NOT_APPLICABLE;
+    int ks, per;
+    gather_plan(p, &ks, &per);
+    if (workspace_bytes < (int64_t)ks * p.M * p.N * (int64_t)sizeof(float)) return STYLEX_NOT_APPLICABLE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return STYLEX_NOT_APPLICABLE;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    GatherParams g;
+    g.x = reinterpret_cast<const unsigned short*>(p.a);
+    g.w = reinterpret_cast<const unsigned short*>(p.w);
+    g.partial = (float*)workspace;
+    g.B = p.B;
+    g.H = p.Ho;
+    g.W = p.Wo;
+    g.C = p.Ck;
+    g.N = p.N;
+    g.KH = p.KH;
+    g.pad = p.pad;
+    g.sign = p.transposed ? -1 : 1;
+    g.M = p.M;
+    g.stages = p.KH * p.KW * (p.Ck / 64);
+    g.ksplit = ks;
+    g.stages_per_split = per;
+    const long tiles = (long)((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
+    hipLaunchKernelGGL(conv_gather_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), SMEM_BYTES, s, g);
+    p.ksplit = ks;
+    p.kt_per_split = per;
+    p.partial = (float*)workspace;
+    return (int)hipGetLastError();
+}

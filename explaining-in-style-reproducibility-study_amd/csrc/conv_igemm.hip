@@ -1060,7 +1060,22 @@ static bool igemm_vec_ok(const ConvKParams& p) {
 int64_t stylex_igemm_workspace_bytes(const ConvKParams& p, int precision) {
     int ks, per;
     igemm_splitk_plan(p, p.Ck % 4 == 0, precision == STYLEX_F32 ? STYLEX_F32 : STYLEX_BF16, &ks, &per);
-    return ks > 1 ? (int64_t)ks * p.M * p.N * (int64_t)sizeof(float) : 0;
+    int64_t own = ks > 1 ? (int64_t)ks * p.M * p.N * (int64_t)sizeof(float) : 0;
+    int64_t gather = precision == STYLEX_F32 ? 0 : stylex_gather_workspace_bytes(p);
+    return own > gather ? own : gather;
+}
+
+static int launch_splitk_epilogue(const ConvKParams& p, hipStream_t s) {
+    long total = (long)p.M * p.N;
+    const bool vec4 = p.N % 4 == 0 && total < (1L << 31) && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0;
+    int blocks = (int)(((vec4 ? total / 4 : total) + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (vec4)
+        hipLaunchKernelGGL(splitk_epilogue_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(splitk_epilogue_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
 }
 
 int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s) {
@@ -1072,6 +1087,11 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
     p.ksplit = 1;
     p.kt_per_split = 0;
     p.partial = nullptr;
+    if (precision == STYLEX_BF16) {  // <= 8x8 px layers: LDS-DMA implicit GEMM + the split-K epilogue kernel
+        int rc = stylex_launch_gather(p, workspace, workspace_bytes, s);
+        if (rc == 0) return launch_splitk_epilogue(p, s);
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+    }
     if (workspace) {
         int ks, per;
         igemm_splitk_plan(p, vec, precision, &ks, &per);
@@ -1091,16 +1111,7 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
         rc = vec ? dispatch_igemm<true, false, 32>(p, s) : dispatch_igemm<false, false, 32>(p, s);
     }
     if (rc || p.ksplit <= 1) return rc;
-    long total = (long)p.M * p.N;
-    const bool vec4 = p.N % 4 == 0 && total < (1L << 31) && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
-                      (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0;
-    int blocks = (int)(((vec4 ? total / 4 : total) + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (vec4)
-        hipLaunchKernelGGL(splitk_epilogue_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(splitk_epilogue_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
-    return (int)hipGetLastError();
+    return launch_splitk_epilogue(p, s);
 }
 
 void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len) {

@@ -54,6 +54,11 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s);
 // weights-stationary persistent streaming kernel for the C, N <= 64 layers at >= 128^2 (conv_ws.hip)
 int stylex_launch_ws(const ConvKParams& p, hipStream_t s);
 
+// LDS-DMA implicit GEMM for the <= 8x8 px layers (conv_gather.hip): writes fp32 partials and fills p.ksplit / p.partial
+// for the split-K epilogue kernel
+int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_bytes, hipStream_t s);
+int64_t stylex_gather_workspace_bytes(const ConvKParams& p);
+
 // 3x3/s1/p1 bf16 weight gradient with resident halo + LDS transpose reads (conv_wgrad_halo.hip)
 bool stylex_wgrad_halo_applicable(const ConvKParams& p);
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);

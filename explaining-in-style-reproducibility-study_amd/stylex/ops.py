@@ -417,11 +417,20 @@ class _ModConvFast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, s1, d, w, noise, nw, nb, pad, lrelu, noise_nat=None):
         x = _cl(x)
-        if noise_nat is not None and noise_nat.shape[1] % 4 == 0:
-            y = hb.conv2d_fwd(x, w, 1, pad, _PRECISION, in_scale=s1, out_scale=d, noise=noise_nat, noise_w=nw, noise_b=nb,
-                              lrelu=lrelu, noise_natural=True)
+        # <= 8x8 px layers: the modulation is applied to the (tiny) input tensor up front, so that the launch can take
+        # the LDS-DMA implicit-GEMM kernel (conv_gather.hip: a DMA cannot scale in flight); same rounding as the
+        # in-kernel staging (product rounded to bf16 once)
+        pre = _PRECISION == hb.BF16_ACT and s1 is not None and x.shape[2] * x.shape[3] <= 64 and x.shape[1] % 64 == 0
+        ctx.pre = pre
+        if pre:
+            x_in, s_in = (x.float() * s1[:, :, None, None]).to(x.dtype).contiguous(memory_format=torch.channels_last), None
         else:
-            y = hb.conv2d_fwd(x, w, 1, pad, _PRECISION, in_scale=s1, out_scale=d, noise=noise, noise_w=nw, noise_b=nb,
+            x_in, s_in = x, s1
+        if noise_nat is not None and noise_nat.shape[1] % 4 == 0:
+            y = hb.conv2d_fwd(x_in, w, 1, pad, _PRECISION, in_scale=s_in, out_scale=d, noise=noise_nat, noise_w=nw,
+                              noise_b=nb, lrelu=lrelu, noise_natural=True)
+        else:
+            y = hb.conv2d_fwd(x_in, w, 1, pad, _PRECISION, in_scale=s_in, out_scale=d, noise=noise, noise_w=nw, noise_b=nb,
                               lrelu=lrelu)
         ctx.save_for_backward(x, s1, d, w, noise, nw, nb, y if (lrelu or d is not None or noise is not None) else None)
         ctx.cfg = (pad, lrelu)
@@ -446,7 +455,11 @@ class _ModConvFast(torch.autograd.Function):
             gz = gy
         gx = gs1 = gw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            t = hb.conv2d_bwd_data(gz, w, tuple(x.shape), 1, pad, _PRECISION, in_scale=d)
+            if ctx.pre and d is not None:  # small layer: demodulation applied to the (tiny) gradient tensor up front
+                gzd = (gz.float() * d[:, :, None, None]).to(gz.dtype).contiguous(memory_format=torch.channels_last)
+                t = hb.conv2d_bwd_data(gzd, w, tuple(x.shape), 1, pad, _PRECISION)
+            else:
+                t = hb.conv2d_bwd_data(gz, w, tuple(x.shape), 1, pad, _PRECISION, in_scale=d)
             if _reducible(x.shape[1]):
                 gx, gs1 = hb.scale_reduce(x, t, s1, want_gx=ctx.needs_input_grad[0])
             else:

@@ -877,3 +877,41 @@ def test_natural_order_noise_plane_epilogue(case, prec):
     want = F.leaky_relu(F.conv2d(x.float() * s1[:, :, None, None], w, padding=1) * d[:, :, None, None]
                         + plane[:, :W, :H].transpose(1, 2)[:, None] * nw[None, :, None, None] + nb[None, :, None, None], 0.2)
     close(want, got.float(), 1e-4 if prec == "fp32" else 3e-2, "noise epilogue vs definition")
+
+
+@pytest.mark.parametrize("case", [(32, 512, 512, 8, 3), (64, 512, 512, 4, 3), (128, 512, 512, 2, 3), (5, 128, 192, 8, 3),
+                                  (64, 512, 512, 8, 1), (128, 512, 512, 2, 1), (3, 64, 64, 4, 3)])
+def test_small_spatial_gather_kernel(case):
+    """conv_gather.hip (LDS-DMA implicit GEMM for the <= 8x8 px layers, 3x3/s1/p1 and 1x1) against an fp64 evaluation
+    of the definition and against the generic kernel it replaces (STYLEX_CONV_GATHER=0): forward with bias + LeakyReLU,
+    data gradient plain and with the activation gate.  Partial tiles (M, N not multiples of 128) included."""
+    import os
+
+    B, C, N, S, k = case
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(41)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, dy, gate = mk(B, C, S, S), mk(B, N, S, S), mk(B, C, S, S)
+    w = torch.randn(N, C, k, k, device=DEV, generator=g) / (k * k * C) ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    pad = (k - 1) // 2
+
+    def run():
+        return (hb.conv2d_fwd(x, w, 1, pad, P, bias=bias, lrelu=True),
+                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, pad, P),
+                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, pad, P, gate=gate))
+
+    got = run()
+    os.environ["STYLEX_CONV_GATHER"] = "0"
+    try:
+        ref = run()
+    finally:
+        os.environ.pop("STYLEX_CONV_GATHER", None)
+    for nm, a, b in zip(("fwd", "dgrad", "dgrad+gate"), ref, got):
+        close(a.float(), b.float(), 1e-2, nm + " vs generic kernel")
+    wb = w.to(torch.bfloat16).double()
+    want = F.leaky_relu(F.conv2d(x.double(), wb, bias.double(), padding=pad), 0.2)
+    close(want, got[0].double(), 1e-2, "fwd vs fp64 definition")
+    want_dx = torch.nn.grad.conv2d_input((B, C, S, S), wb, dy.double(), padding=pad)
+    close(want_dx, got[1].double(), 1e-2, "dgrad vs fp64 definition")
