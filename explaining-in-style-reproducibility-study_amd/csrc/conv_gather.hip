@@ -78,22 +78,29 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
     const bool n_ok = n_row < p.N;
     const long w_base = (long)n_row * K;
 
-    auto issue_stage = [&](int s, int rs) {
+    // source pointers of one stage (computed once per stage), and the two DMA instructions of one 16-channel group
+    const unsigned short *asrc = zero, *wsrc = zero;
+    bool a_ok = false;
+    auto stage_setup = [&](int s) {
         const int tap = s / cpt, c0 = (s - tap * cpt) << 6;
         const int kh = tap / p.KH, kw = tap - kh * p.KH;
         const int dy = p.sign * (kh - p.pad), dx = p.sign * (kw - p.pad);
         const int ih = oh + dy, iw = ow + dx;
-        const bool a_ok = m_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        const unsigned short* asrc = p.x + pix_base + ((long)dy * p.W + dx) * p.C + c0 + slot * 8;
-        const unsigned short* wsrc = p.w + w_base + (long)tap * p.C + c0 + slot * 8;
+        a_ok = m_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        asrc = p.x + pix_base + ((long)dy * p.W + dx) * p.C + c0 + slot * 8;
+        wsrc = p.w + w_base + (long)tap * p.C + c0 + slot * 8;
+    };
+    auto issue_group = [&](int rs, int g) {
         char* base = smem + rs * STAGE_BYTES;
+        __builtin_amdgcn_global_load_lds((gl_void_ptr)(a_ok ? asrc + g * 16 : zero),
+                                         (lds_void_ptr)(base + g * GROUP_BYTES + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gl_void_ptr)(n_ok ? wsrc + g * 16 : zero),
+                                         (lds_void_ptr)(base + g * GROUP_BYTES + GBM * ROW + wave * 1024), 16, 0, 0);
+    };
+    auto issue_stage = [&](int s, int rs) {
+        stage_setup(s);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_global_load_lds((gl_void_ptr)(a_ok ? asrc + g * 16 : zero),
-                                             (lds_void_ptr)(base + g * GROUP_BYTES + wave * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gl_void_ptr)(n_ok ? wsrc + g * 16 : zero),
-                                             (lds_void_ptr)(base + g * GROUP_BYTES + GBM * ROW + wave * 1024), 16, 0, 0);
-        }
+        for (int g = 0; g < 4; ++g) issue_group(rs, g);
     };
 
     // MFMA operand rows: wave (wm, wn) owns rows wm*64 .. +63 of A and wn*64 .. +63 of W
@@ -120,10 +127,14 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
         else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // everyone's pieces of stage s are visible; everyone is done with ring slot (s + 3) % RING
-        if (s + 3 < nst) issue_stage(s_begin + s + 3, (s + 3) % RING);
+        const bool more = s + 3 < nst;
+        if (more) stage_setup(s_begin + s + 3);
         const char* base = smem + (s % RING) * STAGE_BYTES;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            // the 8 DMA instructions of stage s+3 go out two per group, in the shadow of this group's 4 MFMAs (a burst at
+            // the top of the stage leaves the matrix pipe idle while it is issued)
+            if (more) issue_group((s + 3) % RING, g);
             bf16x8 av[2], bv[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(base + g * GROUP_BYTES + a_off + i * 32 * ROW);
