@@ -235,9 +235,10 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
     if cacheable:
         key = (w.data_ptr(), w._version, tuple(w.shape), precision, scale)
         hit = _cache_hit(key, w)
-        if hit is not None:
+        if hit is not None and (hit[0] is not None or not want_fwd) and (hit[1] is not None or not want_bwd):
             return hit
-        want_fwd = want_bwd = True
+        if scale is None:
+            want_fwd = want_bwd = True  # both operand layouts in one launch; a scaled pack is only ever used one way
     w_param = w
     w = w.contiguous()
     if w.dtype != torch.float32:
