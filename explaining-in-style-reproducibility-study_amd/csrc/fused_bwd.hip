@@ -125,7 +125,8 @@ __global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const void* __rest
                                                              const float* __restrict__ noise, int ns,
                                                              const float* __restrict__ nw, const float* __restrict__ nb,
                                                              void* __restrict__ gz, float* __restrict__ partial, int H,
-                                                             int W, int C, int nchunks, int lrelu, int bf) {
+                                                             int W, int C, int nchunks, int lrelu, int bf,
+                                                             const float* __restrict__ gz_scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W;
     Geo g = make_geo(HW, C, nchunks);
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const void* __rest
             w4 = ldp4(nw + c);
             b4 = ldp4(nb + c);
         }
+        float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (gz_scale) d4 = ldp4(gz_scale + (long)g.b * C + c);
         const long base = (long)g.b * HW;
         for (long p = g.p_begin + g.prow; p < g.p_end; p += g.rpp) {
             const long o = (base + p) * C + c;
@@ -155,7 +158,11 @@ __global__ __launch_bounds__(NT) void modconv_bwd_prep_kernel(const void* __rest
                 gv.z = yv.z > 0.f ? gv.z : 0.2f * gv.z; t.z = yv.z > 0.f ? yv.z : 5.f * yv.z;
                 gv.w = yv.w > 0.f ? gv.w : 0.2f * gv.w; t.w = yv.w > 0.f ? yv.w : 5.f * yv.w;
             }
-            st4(gz, o, gv, bf);
+            // the STORED gradient optionally carries the demodulation coefficient d[b][c] (both consumers — the data
+            // gradient and the weight gradient — want gz * d; folding it here makes their operands scale-free, so the
+            // data gradient can take the LDS-DMA kernel); the sums below use the unscaled value
+            if (gz_scale) st4(gz, o, make_float4(gv.x * d4.x, gv.y * d4.y, gv.z * d4.z, gv.w * d4.w), bf);
+            else st4(gz, o, gv, bf);
             a.v[0].x += gv.x * (t.x - (nz * w4.x + b4.x));
             a.v[0].y += gv.y * (t.y - (nz * w4.y + b4.y));
             a.v[0].z += gv.z * (t.z - (nz * w4.z + b4.z));
@@ -231,16 +238,35 @@ int stylex_act_bwd_reduce(const void* dy, const void* y, void* dx, float* partia
     return (int)hipGetLastError();
 }
 
+static int modconv_bwd_prep_impl(const void* gy, const void* y, const float* noise, int64_t noise_stride,
+                                 const float* noise_w, const float* noise_b, void* gz, float* partial, const int64_t* sh,
+                                 int nchunks, int lrelu, int act_dtype, const float* gz_scale, void* stream);
+
 int stylex_modconv_bwd_prep(const void* gy, const void* y, const float* noise, int64_t noise_stride,
                             const float* noise_w, const float* noise_b, void* gz, float* partial, const int64_t* sh,
                             int nchunks, int lrelu, int act_dtype, void* stream) {
+    return modconv_bwd_prep_impl(gy, y, noise, noise_stride, noise_w, noise_b, gz, partial, sh, nchunks, lrelu, act_dtype,
+                                 nullptr, stream);
+}
+
+int stylex_modconv_bwd_prep_scaled(const void* gy, const void* y, const float* noise, int64_t noise_stride,
+                                   const float* noise_w, const float* noise_b, const float* gz_scale, void* gz,
+                                   float* partial, const int64_t* sh, int nchunks, int lrelu, int act_dtype, void* stream) {
+    if (!gz_scale || (reinterpret_cast<uintptr_t>(gz_scale) & 15)) return STYLEX_EINVAL;
+    return modconv_bwd_prep_impl(gy, y, noise, noise_stride, noise_w, noise_b, gz, partial, sh, nchunks, lrelu, act_dtype,
+                                 gz_scale, stream);
+}
+
+static int modconv_bwd_prep_impl(const void* gy, const void* y, const float* noise, int64_t noise_stride,
+                                 const float* noise_w, const float* noise_b, void* gz, float* partial, const int64_t* sh,
+                                 int nchunks, int lrelu, int act_dtype, const float* gz_scale, void* stream) {
     if (act_dtype != 0 && act_dtype != 1) return STYLEX_EINVAL;
     if (!gy || !y || !gz || !partial || !ok_shape(sh, nchunks)) return STYLEX_EINVAL;
     if (noise && (!noise_w || !noise_b || noise_stride < sh[1] || noise_stride < sh[2])) return STYLEX_EINVAL;
     int C = (int)sh[3];
     hipLaunchKernelGGL(modconv_bwd_prep_kernel, dim3(nchunks, (unsigned)sh[0]), dim3(NT), reduce_smem(C, 3),
                        (hipStream_t)stream, gy, y, noise, (int)noise_stride, noise_w, noise_b, gz, partial, (int)sh[1],
-                       (int)sh[2], C, nchunks, lrelu, act_dtype);
+                       (int)sh[2], C, nchunks, lrelu, act_dtype, gz_scale);
     return (int)hipGetLastError();
 }
 

@@ -71,6 +71,8 @@ SIGNATURES = {
                                              ctypes.c_int, ctypes.c_void_p]),
     "stylex_modconv_bwd_prep": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _c_f, _i64p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_modconv_bwd_prep_scaled": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _c_f, _c_f, _i64p,
+                                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
     "stylex_torgb_chunks": (ctypes.c_int, [_i64p]),
@@ -529,8 +531,9 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True):
     return dx, (partial.sum(dim=(0, 1)) if want_sum else None)
 
 
-def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu):
-    """gz = gy*lrelu'(y); returns gz and S[3][B][C] = per-image sums (gz*(d*z), gz*noise, gz)."""
+def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu, gz_scale=None):
+    """gz = gy*lrelu'(y); returns gz and S[3][B][C] = per-image sums (gz*(d*z), gz*noise, gz).  With gz_scale [B,C]
+    (the demodulation coefficient) the returned tensor is gz * gz_scale (the sums stay those of gz)."""
     lib = _ensure_device(gy)
     assert is_cl(gy) and is_cl(y) and gy.dtype == y.dtype
     b, c, h, w = gy.shape
@@ -542,9 +545,15 @@ def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu):
     noise, noise_w, noise_b = _f32(noise), _f32(noise_w), _f32(noise_b)
     if noise is not None:
         ns = noise.shape[1]
-    _check(lib.stylex_modconv_bwd_prep(_ptr(gy), _ptr(y), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(gz),
-                                       _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)), _adt(gy), _stream()),
-           "stylex_modconv_bwd_prep")
+    lr = 2 if lrelu == "relu" else int(bool(lrelu))
+    if gz_scale is None:
+        _check(lib.stylex_modconv_bwd_prep(_ptr(gy), _ptr(y), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b), _ptr(gz),
+                                           _ptr(partial), shp, nch, lr, _adt(gy), _stream()), "stylex_modconv_bwd_prep")
+    else:
+        gz_scale = _f32(gz_scale)
+        _check(lib.stylex_modconv_bwd_prep_scaled(_ptr(gy), _ptr(y), _ptr(noise), ns, _ptr(noise_w), _ptr(noise_b),
+                                                  _ptr(gz_scale), _ptr(gz), _ptr(partial), shp, nch, lr, _adt(gy), _stream()),
+               "stylex_modconv_bwd_prep_scaled")
     return gz, partial.sum(dim=1)  # [B, 3, C]
 
 

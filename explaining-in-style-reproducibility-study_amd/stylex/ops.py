@@ -443,8 +443,11 @@ class _ModConvFast(torch.autograd.Function):
         pad, lrelu = ctx.cfg
         gy = _cl(gy)
         gd = gnw = gnb = None
+        folded = False  # gz already carries the demodulation coefficient d
         if y is not None and _reducible(gy.shape[1]):
-            gz, sums = hb.modconv_bwd_prep(gy, y, noise, nw, nb, lrelu)
+            fold = d is not None and _PRECISION != hb.F32 and os.environ.get("STYLEX_FOLD_D", "1") != "0"
+            gz, sums = hb.modconv_bwd_prep(gy, y, noise, nw, nb, lrelu, gz_scale=d if fold else None)
+            folded = fold
             if d is not None:
                 gd = sums[:, 0] / d
             if noise is not None:
@@ -455,7 +458,9 @@ class _ModConvFast(torch.autograd.Function):
             gz = gy
         gx = gs1 = gw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            if ctx.pre and d is not None:  # small layer: demodulation applied to the (tiny) gradient tensor up front
+            if folded:  # scale-free operand: eligible for the LDS-DMA kernels (halo / small-spatial gather)
+                t = hb.conv2d_bwd_data(gz, w, tuple(x.shape), 1, pad, _PRECISION)
+            elif ctx.pre and d is not None:  # small layer: demodulation applied to the (tiny) gradient tensor up front
                 gzd = (gz.float() * d[:, :, None, None]).to(gz.dtype).contiguous(memory_format=torch.channels_last)
                 t = hb.conv2d_bwd_data(gzd, w, tuple(x.shape), 1, pad, _PRECISION)
             else:
@@ -466,7 +471,7 @@ class _ModConvFast(torch.autograd.Function):
                 gs1 = (x.float() * t.float()).sum(dim=(2, 3))
                 gx = (t.float() * s1[:, :, None, None]).to(t.dtype)
         if ctx.needs_input_grad[3]:
-            gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), 1, pad, _PRECISION, x_scale=s1, dy_scale=d)
+            gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), 1, pad, _PRECISION, x_scale=s1, dy_scale=None if folded else d)
         return gx, gs1, gd, gw, None, gnw, gnb, None, None, None
 
 

@@ -208,6 +208,13 @@ int stylex_act_bwd_reduce(const void* dy, const void* y, void* dx, float* partia
 int stylex_modconv_bwd_prep(const void* gy, const void* y, const float* noise, int64_t noise_stride,
                             const float* noise_w, const float* noise_b, void* gz, float* partial,
                             const int64_t* shape, int nchunks, int lrelu, int act_dtype, void* stream);
+/* Same, and the STORED gradient is gz * gz_scale[b][c] (gz_scale = the demodulation coefficient d [B][C]): both consumers
+ * of gz (data gradient and weight gradient of the modulated conv) want gz * d, so their operands become scale-free
+ * and the data gradient can take the LDS-DMA kernels.  The three sums are those of the unscaled gz. */
+int stylex_modconv_bwd_prep_scaled(const void* gy, const void* y, const float* noise, int64_t noise_stride,
+                                   const float* noise_w, const float* noise_b, const float* gz_scale, void* gz,
+                                   float* partial, const int64_t* shape, int nchunks, int lrelu, int act_dtype,
+                                   void* stream);
 int stylex_scale_reduce(const void* x, const void* t, const float* s, void* gx, float* partial, const int64_t* shape,
                         int nchunks, int act_dtype, void* stream);
 
