@@ -374,12 +374,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKPar
     float* out = p.y + (long)split * N * 9 * C;
     const int c = c0 + wc * 32 + lj;
     if (c < C) {
+        // modulated layer: the whole split lies in sample t_begin / tiles_img (plan), its x scale is a factor of the sum
+        const float xsc = (p.a_scale && t_begin < t_end) ? p.a_scale[(long)(t_begin / tiles_img) * C + c] : 1.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n < N) out[((long)n * 9 + t) * C + c] = acc[t][r];
+                if (n < N) out[((long)n * 9 + t) * C + c] = acc[t][r] * xsc;
             }
     }
 }
@@ -407,7 +409,11 @@ static void tile_dims(const ConvKParams& p, int* tw, int* th) {
 static bool wgrad_dma_eligible(const ConvKParams& p) {
     static const bool off = getenv("STYLEX_WGRAD_DMA") && getenv("STYLEX_WGRAD_DMA")[0] == '0';
     if (off) return false;
-    if (!p.act_bf16 || p.Ck % 8 != 0 || p.N % 8 != 0 || p.Wo < 32 || p.a_scale || p.a2_scale) return false;
+    // a per-sample scale of x (the modulation s[b][c] of a generator layer) is applied to the ACCUMULATORS when a split
+    // ends (dW = sum_b s[b][c] * sum_p dy x: linear, and a split never crosses a sample — see the plan); a scale of dy
+    // cannot be factored that way (the modulated backward hands in dy with the demodulation already folded in)
+    if (!p.act_bf16 || p.Ck % 8 != 0 || p.N % 8 != 0 || p.Wo < 32 || p.a2_scale) return false;
+    if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 3)) return false;
     if (p.s2d_c) return false;  // space-to-depth tiles do 1-4 taps per staged tile: 2 blocks per CU hide that better
     static const long max_otiles = getenv("STYLEX_WGRAD_DMA_OT") ? atol(getenv("STYLEX_WGRAD_DMA_OT")) : 16;
     long otiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64);
@@ -424,6 +430,11 @@ void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_sp
         if (want > tiles) want = tiles;
         if (want < 1) want = 1;
         long tps = (tiles + want - 1) / want;
+        if (p.a_scale) {  // splits must not cross a sample: the largest divisor of tiles-per-image that is <= tps
+            const long tiles_img = tiles / p.B;
+            if (tps > tiles_img) tps = tiles_img;
+            while (tiles_img % tps) --tps;
+        }
         *tiles_per_split = (int)tps;
         *splits = (int)((tiles + tps - 1) / tps);
         return;

@@ -915,3 +915,25 @@ def test_small_spatial_gather_kernel(case):
     close(want, got[0].double(), 1e-2, "fwd vs fp64 definition")
     want_dx = torch.nn.grad.conv2d_input((B, C, S, S), wb, dy.double(), padding=pad)
     close(want_dx, got[1].double(), 1e-2, "dgrad vs fp64 definition")
+
+
+@pytest.mark.parametrize("case", [(8, 64, 32, 256), (16, 128, 128, 64), (64, 256, 256, 32), (4, 64, 64, 128)])
+def test_modulated_wgrad_scale_in_epilogue(case):
+    """Weight gradient of a modulated layer on the LDS-DMA kernel: the per-sample modulation s[b][c] of x is a factor of
+    each sample's partial sum (splits never cross a sample) and is applied to the accumulators when a split ends —
+    against the register-staged kernel that scales x while staging (STYLEX_WGRAD_DMA=0 is read once per process, so the
+    reference here is the fp32 definition)."""
+    B, C, N, S = case
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(61)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, dy = mk(B, C, S, S), mk(B, N, S, S)
+    s1 = torch.randn(B, C, device=DEV, generator=g) * 0.5 + 1.0
+    got = hb.conv2d_bwd_weight(x, dy, (N, C, 3, 3), 1, 1, P, x_scale=s1)
+    xs = (x.float() * s1[:, :, None, None])
+    want = torch.nn.grad.conv2d_weight(xs.double(), (N, C, 3, 3), dy.double(), padding=1)
+    close(want, got.double(), 2e-2, "modulated wgrad")
+    plain = hb.conv2d_bwd_weight(x, dy, (N, C, 3, 3), 1, 1, P)
+    want0 = torch.nn.grad.conv2d_weight(x.double(), (N, C, 3, 3), dy.double(), padding=1)
+    close(want0, plain.double(), 2e-2, "plain wgrad")
