@@ -1188,10 +1188,14 @@ class Trainer:
         def seg_d():
             acc.update(self._new_acc())
             self._d_phase(groups, d_in, apply_gp, gae, True, acc)
+            if self.is_ddp:
+                self._d_sync.pack_all()  # captured: every replay refills the flat buckets the collectives run on
 
         def seg_g():
             m.D_opt.step()
             self._g_phase(groups, g_in, False, gae, True, acc)
+            if self.is_ddp:
+                self._g_sync.pack_all()
 
         def seg_tail():
             m.G_opt.step()
