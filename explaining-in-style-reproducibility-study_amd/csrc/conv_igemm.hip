@@ -1081,7 +1081,9 @@ static int launch_splitk_epilogue(const ConvKParams& p, hipStream_t s) {
 int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s) {
     bool vec = igemm_vec_ok(p);
     if (precision == STYLEX_BF16 && !p.transposed) {
-        int rc = stylex_launch_halo(p, s);
+        int rc = stylex_launch_rgb(p, s);
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+        rc = stylex_launch_halo(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
     p.ksplit = 1;

@@ -51,6 +51,9 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s);
 // LDS-DMA variant of the halo kernel for the >= 128-channel unscaled layers (conv_halo_dma.hip)
 int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s);
 
+// first layer of D / encoder: 3x3 over the padded RGB slot (C = 8) to 64 channels, forward (conv_rgb.hip)
+int stylex_launch_rgb(const ConvKParams& p, hipStream_t s);
+
 // weights-stationary persistent streaming kernel for the C, N <= 64 layers at >= 128^2 (conv_ws.hip)
 int stylex_launch_ws(const ConvKParams& p, hipStream_t s);
 

@@ -394,6 +394,9 @@ class _ConvBiasActDD(torch.autograd.Function):
 
 
 _NAT_NOISE = {}
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_NAT_NOISE.clear)  # device tensors are released before the interpreter / HIP runtime shut down
 
 
 def _natural_noise(inoise):
@@ -402,12 +405,14 @@ def _natural_noise(inoise):
     14 noise layers of a forward share the plane, each cropping its top-left h x w corner) so that the conv epilogues
     read 4 consecutive pixels with one 16-byte load instead of 16 strided 4-byte loads: measured on the modulated convs
     with noise, 64->32 @256^2 .60 -> .31 ms and 32->32 @256^2 .49 -> .19 ms per launch (tools/bench_modconv.py)."""
-    key = (inoise.data_ptr(), inoise._version, tuple(inoise.shape))
+    # one entry, keyed by the tensor OBJECT (held alive by the entry, so its address cannot be recycled by another
+    # noise tensor) and its version counter (static graph input buffers are refilled in place)
     hit = _NAT_NOISE.get("k")
-    if hit is not None and hit[0] == key and not (inoise.is_cuda and torch.cuda.is_current_stream_capturing()):
-        return hit[1]
+    if (hit is not None and hit[0] is inoise and hit[1] == inoise._version
+            and not (inoise.is_cuda and torch.cuda.is_current_stream_capturing())):
+        return hit[2]
     nat = inoise[:, :, :, 0].transpose(1, 2).contiguous().float()
-    _NAT_NOISE["k"] = (key, nat)
+    _NAT_NOISE["k"] = (inoise, inoise._version, nat)
     return nat
 
 

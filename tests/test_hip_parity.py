@@ -873,6 +873,15 @@ def test_natural_order_noise_plane_epilogue(case, prec):
     nat = ops._natural_noise(inoise)
     got = hb.conv2d_fwd(x, w, 1, 1, P, in_scale=s1, out_scale=d, noise=nat, noise_w=nw, noise_b=nb, lrelu=True, noise_natural=True)
     assert torch.equal(ref, got), float((ref.float() - got.float()).abs().max())
+    # the one-entry cache is keyed by tensor identity + version: another noise tensor (possibly at a recycled address)
+    # or an in-place refill (static graph input buffer) must never see a stale plane
+    other = torch.rand_like(inoise)
+    assert torch.equal(ops._natural_noise(other), other[:, :, :, 0].transpose(1, 2))
+    inoise2 = inoise.clone()
+    first = ops._natural_noise(inoise2)
+    assert ops._natural_noise(inoise2) is first
+    inoise2.copy_(other)
+    assert torch.equal(ops._natural_noise(inoise2), other[:, :, :, 0].transpose(1, 2))
     # and against the definition: value at (h, w) is inoise[b, w, h]
     want = F.leaky_relu(F.conv2d(x.float() * s1[:, :, None, None], w, padding=1) * d[:, :, None, None]
                         + plane[:, :W, :H].transpose(1, 2)[:, None] * nw[None, :, None, None] + nb[None, :, None, None], 0.2)
@@ -937,3 +946,27 @@ def test_modulated_wgrad_scale_in_epilogue(case):
     plain = hb.conv2d_bwd_weight(x, dy, (N, C, 3, 3), 1, 1, P)
     want0 = torch.nn.grad.conv2d_weight(x.double(), (N, C, 3, 3), dy.double(), padding=1)
     close(want0, plain.double(), 2e-2, "plain wgrad")
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64), (2, 40, 72), (3, 256, 256)])
+def test_first_layer_rgb_kernel(case):
+    """conv_rgb.hip (3x3 over the padded RGB slot to 64 channels, bias + LeakyReLU: the first conv of every
+    DiscriminatorBlock chain) against the generic kernel (STYLEX_CONV_RGB=0) and the fp64 definition; partial tiles."""
+    import os
+
+    B, H, W = case
+    ops.set_precision("bf16")
+    g = torch.Generator(device=DEV).manual_seed(71)
+    x = torch.rand(B, 3, H, W, device=DEV, generator=g)
+    w = torch.randn(64, 3, 3, 3, device=DEV, generator=g) / 27 ** 0.5
+    bias = torch.randn(64, device=DEV, generator=g)
+    with torch.no_grad():
+        got = ops.conv2d(x, w, bias, 1, 1, lrelu=True)
+        os.environ["STYLEX_CONV_RGB"] = "0"
+        try:
+            ref = ops.conv2d(x, w, bias, 1, 1, lrelu=True)
+        finally:
+            os.environ.pop("STYLEX_CONV_RGB", None)
+    close(ref.float(), got.float(), 1e-2, "rgb kernel vs generic")
+    want = F.leaky_relu(F.conv2d(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), bias.double(), padding=1), 0.2)
+    close(want, got.double(), 1e-2, "rgb kernel vs fp64 definition")
