@@ -42,20 +42,48 @@ struct GatherParams {
     const unsigned short* x;   // [B][H][W][C] bf16
     const unsigned short* w;   // [N][T][C] bf16 (forward pack, or data-gradient pack)
     float* partial;            // [ksplit][M][N]
-    int B, H, W, C, N, KH, pad, sign;  // sign +1: forward gather oh + kh - p;  -1: data gradient oh + p - kh
+    unsigned short* y;         // != nullptr: ksplit == 1 and no epilogue — store bf16 [M][N] directly, no partials
+    int B, H, W, C, N, KH, pad, sign;  // H, W: output grid.  sign +1: forward gather ih = oh*stride + kh - p;
+                                       // -1: data gradient ih = (oh + p - kh) / stride
+    int Hs, Ws, stride;                // source grid; stride 1, or 2 (the 3x3/p1 down conv of a DiscriminatorBlock)
+    int m_tiles;                       // M tiles of the launch (stride-2 data gradient: 4 parity classes x tiles of a class)
     int M, stages, ksplit, stages_per_split;
 };
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short f2bf_rne(float f) {  // v_cvt_pk_bf16_f32, as the split-K epilogue rounds
+    f32x2_t v = {f, 0.f};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return (unsigned short)(*reinterpret_cast<unsigned*>(&r) & 0xffffu);
+}
 
 __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = (p.N + GBN - 1) / GBN;
-    const int m0 = (int)(blockIdx.x / n_tiles) * GBM, n0 = (int)(blockIdx.x % n_tiles) * GBN;
+    const int n0 = (int)(blockIdx.x % n_tiles) * GBN;
+    int mt = (int)(blockIdx.x / n_tiles);
+    // Stride-2 data gradient: rows are grouped by the parity class (py, px) of the output pixel, so that a tile shares
+    // its live taps — kh = 1 for even oh, kh in {0, 2} for odd oh (same along w): 1, 2 or 4 taps instead of 9 with
+    // three quarters of the gathered rows zero.  Row r of a class = (b, qh, qw) over the SOURCE grid; output pixel
+    // (2 qh + py, 2 qw + px).
+    const bool phased = p.sign < 0 && p.stride == 2;
+    int py = 0, px = 0;
+    if (phased) {
+        const int tpp = p.m_tiles >> 2;
+        const int ph = mt / tpp;
+        mt -= ph * tpp;
+        py = ph >> 1;
+        px = ph & 1;
+    }
+    const int m0 = mt * GBM;
+    const int rows = phased ? p.B * p.Hs * p.Ws : p.M;  // rows of this tile's index space
+    const int cpt = p.C >> 6;  // stages per tap
     const int ks = blockIdx.y;
     const int s_begin = ks * p.stages_per_split;
-    const int s_end = min(s_begin + p.stages_per_split, p.stages);
-    const int nst = s_end - s_begin;
-    const int cpt = p.C >> 6;  // stages per tap
+    const int s_end = min(s_begin + p.stages_per_split, phased ? (1 + py) * (1 + px) * cpt : p.stages);
+    const int nst = max(s_end - s_begin, 0);
     const int T = p.KH * p.KH, K = T * p.C;
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page_g);
 
@@ -68,12 +96,13 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
     const int w_rowl = wave * 32 + lr;          // W row (0..127) this lane stages
     // pixel of the A row
     const int m = m0 + a_rowl;
-    const bool m_ok = m < p.M;
-    const int hw = p.H * p.W;
+    const bool m_ok = m < rows;
+    const int gw = phased ? p.Ws : p.W;                  // grid the row index runs over
+    const int hw = phased ? p.Hs * p.Ws : p.H * p.W;
     const int b = m_ok ? m / hw : 0;
     const int q_ = m_ok ? m - b * hw : 0;
-    const int oh = q_ / p.W, ow = q_ - oh * p.W;
-    const long pix_base = ((long)(b * p.H + oh) * p.W + ow) * p.C;
+    const int oh = q_ / gw, ow = q_ - oh * gw;           // phased: (qh, qw)
+    const long img_base = (long)b * p.Hs * p.Ws * p.C;
     const int n_row = n0 + w_rowl;
     const bool n_ok = n_row < p.N;
     const long w_base = (long)n_row * K;
@@ -82,12 +111,23 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
     const unsigned short *asrc = zero, *wsrc = zero;
     bool a_ok = false;
     auto stage_setup = [&](int s) {
-        const int tap = s / cpt, c0 = (s - tap * cpt) << 6;
-        const int kh = tap / p.KH, kw = tap - kh * p.KH;
-        const int dy = p.sign * (kh - p.pad), dx = p.sign * (kw - p.pad);
-        const int ih = oh + dy, iw = ow + dx;
-        a_ok = m_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        asrc = p.x + pix_base + ((long)dy * p.W + dx) * p.C + c0 + slot * 8;
+        int tap = s / cpt;
+        const int c0 = (s - tap * cpt) << 6;
+        int ih, iw;
+        if (phased) {  // tap = index into the class's live taps; (2q + py + 1 - kh) / 2 = q + (py && kh == 0)
+            const int nkw = 1 + px;
+            const int a = tap / nkw, bq = tap - a * nkw;
+            const int kh = py ? 2 * a : 1, kw = px ? 2 * bq : 1;
+            ih = oh + (py && kh == 0);
+            iw = ow + (px && kw == 0);
+            tap = kh * 3 + kw;
+        } else {
+            const int kh = tap / p.KH, kw = tap - kh * p.KH;
+            ih = p.sign > 0 ? oh * p.stride + kh - p.pad : oh + p.pad - kh;
+            iw = p.sign > 0 ? ow * p.stride + kw - p.pad : ow + p.pad - kw;
+        }
+        a_ok = m_ok && ih >= 0 && ih < p.Hs && iw >= 0 && iw < p.Ws;
+        asrc = p.x + img_base + ((long)ih * p.Ws + iw) * p.C + c0 + slot * 8;
         wsrc = p.w + w_base + (long)tap * p.C + c0 + slot * 8;
     };
     auto issue_group = [&](int rs, int g) {
@@ -157,8 +197,15 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
             const int n = n0 + wn * 64 + j * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (mm < p.M && n < p.N) out[(long)mm * p.N + n] = acc[i][j][r];
+                int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const bool ok = mm < rows && n < p.N;
+                if (phased && ok) {  // class row -> natural (b, oh, ow) order of the partial buffer
+                    const int bb = mm / hw, qq = mm - bb * hw;
+                    const int qh = qq / p.Ws, qw = qq - qh * p.Ws;
+                    mm = (bb * p.H + 2 * qh + py) * p.W + 2 * qw + px;
+                }
+                if (ok && p.y) p.y[(long)mm * p.N + n] = f2bf_rne(acc[i][j][r]);
+                else if (ok) out[(long)mm * p.N + n] = acc[i][j][r];
             }
         }
 }
@@ -169,17 +216,34 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
 static bool gather_applicable(const ConvKParams& p) {
     const char* env = getenv("STYLEX_CONV_GATHER");
     if (env && env[0] == '0') return false;
-    if (!p.act_bf16 || p.a_scale || p.s2d_c || p.phase_major) return false;
-    if (p.stride != 1 || p.KH != p.KW || !((p.KH == 3 && p.pad == 1) || (p.KH == 1 && p.pad == 0))) return false;
-    if (p.Hi != p.Ho || p.Wi != p.Wo || p.Ho * p.Wo > 64) return false;
+    if (env && env[0] == 's' && p.stride != 1) return false;  // "s1": stride-1 layers only (A/B of the stride-2 mode)
+    if (!p.act_bf16 || p.a_scale || p.s2d_c) return false;
+    if (p.KH != p.KW || !((p.KH == 3 && p.pad == 1) || (p.KH == 1 && p.pad == 0))) return false;
+    if (p.stride == 1) {
+        if (p.Hi != p.Ho || p.Wi != p.Wo || p.phase_major) return false;
+    } else {  // 3x3/s2/p1: forward Hi = 2 Ho; data gradient (ConvKParams names the dy grid Hi, the dx grid Ho) Ho = 2 Hi
+        if (p.stride != 2 || p.KH != 3) return false;
+        if (p.transposed ? (p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi) : (p.Hi != 2 * p.Ho || p.Wi != 2 * p.Wo)) return false;
+    }
+    if ((p.transposed && p.stride == 2 ? p.Hi * p.Wi : p.Ho * p.Wo) > 64) return false;
     if (p.Ck % 64 != 0 || p.N % 8 != 0 || p.N < 64) return false;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return false;
     return true;
 }
 
+static int gather_m_tiles(const ConvKParams& p) {
+    if (p.transposed && p.stride == 2) return 4 * ((p.B * p.Hi * p.Wi + GBM - 1) / GBM);
+    return (p.M + GBM - 1) / GBM;
+}
+
+// K stages of the longest tile (stride-2 data gradient: the 4-tap parity class)
+static int gather_stages(const ConvKParams& p) {
+    return (p.transposed && p.stride == 2 ? 4 : p.KH * p.KW) * (p.Ck / 64);
+}
+
 static void gather_plan(const ConvKParams& p, int* ksplit, int* per) {
-    const int stages = p.KH * p.KW * (p.Ck / 64);
-    const long tiles = (long)((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
+    const int stages = gather_stages(p);
+    const long tiles = (long)gather_m_tiles(p) * ((p.N + GBN - 1) / GBN);
     int ks = (int)((256 + tiles - 1) / tiles);
     if (ks > stages / 4) ks = stages / 4;
     if (ks < 1) ks = 1;
@@ -214,6 +278,9 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
     g.x = reinterpret_cast<const unsigned short*>(p.a);
     g.w = reinterpret_cast<const unsigned short*>(p.w);
     g.partial = (float*)workspace;
+    // one K slice and nothing to fuse (a plain data gradient): the kernel rounds and stores the result itself
+    const bool direct = ks == 1 && p.flags == 0 && !p.out_scale && !p.bias;
+    g.y = direct ? reinterpret_cast<unsigned short*>(p.y) : nullptr;
     g.B = p.B;
     g.H = p.Ho;
     g.W = p.Wo;
@@ -222,13 +289,17 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
     g.KH = p.KH;
     g.pad = p.pad;
     g.sign = p.transposed ? -1 : 1;
+    g.Hs = p.Hi;
+    g.Ws = p.Wi;
+    g.stride = p.stride;
+    g.m_tiles = gather_m_tiles(p);
     g.M = p.M;
-    g.stages = p.KH * p.KW * (p.Ck / 64);
+    g.stages = gather_stages(p);
     g.ksplit = ks;
     g.stages_per_split = per;
-    const long tiles = (long)((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
+    const long tiles = (long)g.m_tiles * ((p.N + GBN - 1) / GBN);
     hipLaunchKernelGGL(conv_gather_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), SMEM_BYTES, s, g);
-    p.ksplit = ks;
+    p.ksplit = direct ? 0 : ks;  // 0: output complete, the caller skips the split-K epilogue
     p.kt_per_split = per;
     p.partial = (float*)workspace;
     return (int)hipGetLastError();

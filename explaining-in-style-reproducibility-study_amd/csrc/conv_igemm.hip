@@ -1091,7 +1091,7 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
     p.partial = nullptr;
     if (precision == STYLEX_BF16) {  // <= 8x8 px layers: LDS-DMA implicit GEMM + the split-K epilogue kernel
         int rc = stylex_launch_gather(p, workspace, workspace_bytes, s);
-        if (rc == 0) return launch_splitk_epilogue(p, s);
+        if (rc == 0) return p.ksplit ? launch_splitk_epilogue(p, s) : 0;
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
     if (workspace) {

@@ -926,6 +926,43 @@ def test_small_spatial_gather_kernel(case):
     close(want_dx, got[1].double(), 1e-2, "dgrad vs fp64 definition")
 
 
+@pytest.mark.parametrize("case", [(64, 512, 512, 16, 16), (32, 512, 512, 8, 8), (64, 512, 512, 4, 4), (5, 128, 192, 16, 8),
+                                  (3, 64, 64, 4, 12), (130, 64, 64, 2, 2)])
+def test_small_spatial_gather_kernel_stride2(case):
+    """conv_gather.hip on the 3x3/s2/p1 down conv of the small DiscriminatorBlocks (output <= 8x8 px): forward with bias +
+    residual merge, and the data gradient, whose rows are grouped by output-pixel parity so that every tile gathers its
+    1, 2 or 4 live taps only — against the generic kernel (STYLEX_CONV_GATHER=0) and an fp64 evaluation of the
+    definition.  Ragged tiles and non-square grids included."""
+    import os
+
+    B, C, N, H, W = case
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(43)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, dy, res = mk(B, C, H, W), mk(B, N, H // 2, W // 2), mk(B, N, H // 2, W // 2)
+    w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+
+    def run():
+        return (hb.conv2d_fwd(x, w, 2, 1, P, bias=bias, residual=res, res_scale=0.7),
+                hb.conv2d_bwd_data(dy, w, (B, C, H, W), 2, 1, P))
+
+    got = run()
+    os.environ["STYLEX_CONV_GATHER"] = "0"
+    try:
+        ref = run()
+    finally:
+        os.environ.pop("STYLEX_CONV_GATHER", None)
+    for nm, a, b in zip(("fwd", "dgrad"), ref, got):
+        close(a.float(), b.float(), 1e-2, nm + " vs generic kernel")
+    wb = w.to(torch.bfloat16).double()
+    want = (F.conv2d(x.double(), wb, bias.double(), stride=2, padding=1) + res.double()) * 0.7
+    close(want, got[0].double(), 1e-2, "fwd vs fp64 definition")
+    want_dx = torch.nn.grad.conv2d_input((B, C, H, W), wb, dy.double(), stride=2, padding=1)
+    close(want_dx, got[1].double(), 1e-2, "dgrad vs fp64 definition")
+
+
 @pytest.mark.parametrize("case", [(8, 64, 32, 256), (16, 128, 128, 64), (64, 256, 256, 32), (4, 64, 64, 128)])
 def test_modulated_wgrad_scale_in_epilogue(case):
     """Weight gradient of a modulated layer on the LDS-DMA kernel: the per-sample modulation s[b][c] of x is a factor of
