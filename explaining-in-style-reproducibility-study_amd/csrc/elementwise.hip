@@ -157,6 +157,86 @@ __global__ void upsample2x_bwd_kernel(const void* __restrict__ dy, void* __restr
 // ---- 3x3 binomial blur, reflect border: index rule -1 -> 1, n -> n-2 -------------------------
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
+// ---- RGB skip path of a GeneratorBlock in one pass: out = blur3x3_reflect(upsample2x(rgb + prev)) ------------------
+// (RGBBlock.forward, reference stylex_train.py:618-629: skip add :622-623, nn.Upsample :614 + Blur :615 as
+// self.upsample :625-626).  Both resamplers are separable and linear, so the chain is one 3x3 stencil over the
+// LOW-resolution sum whose row / column weights depend on the output parity and on the borders:
+//   ub_coef(o, i, n) = sum_{d=-1..1} (1,2,1)[d]/4 * up_coef(reflect1(o + d, 2n), i, n),  non-zero for i in {k-1, k, k+1},
+// k = o >> 1.  The adjoint gathers the 6x6 outputs whose stencils cover an input pixel.
+__device__ __forceinline__ float ub_coef(int o, int i, int n) {
+    const int n2 = 2 * n;
+    return 0.25f * up_coef(reflect1(o - 1, n2), i, n) + 0.5f * up_coef(o, i, n) + 0.25f * up_coef(reflect1(o + 1, n2), i, n);
+}
+
+template <int V>
+__global__ void rgb_up_blur_add_fwd_kernel(const void* __restrict__ rgb, const void* __restrict__ prev, void* __restrict__ y,
+                                           int B, int H, int W, int C, int bf) {
+    const int cv = C / V;
+    const long total = (long)B * 2 * H * 2 * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cq, ow, oh, b;
+        const long pix = decomp_index(i, cv, 2 * W, 2 * H, cq, ow, oh, b);
+        const int c = cq * V, kh = oh >> 1, kw = ow >> 1;
+        const long base = (long)b * H * W * C + c;
+        float cw[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int iw = kw - 1 + e;
+            cw[e] = (iw >= 0 && iw < W) ? ub_coef(ow, iw, W) : 0.f;
+        }
+        typename Vec<V>::T acc = Vec<V>::zero();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int ih = kh - 1 + a;
+            if (ih < 0 || ih >= H) continue;
+            const float ch = ub_coef(oh, ih, H);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (cw[e] == 0.f) continue;
+                const long off = base + ((long)ih * W + (kw - 1 + e)) * C;
+                typename Vec<V>::T t = Vec<V>::ld(rgb, off, bf);
+                if (prev) Vec<V>::fma(t, 1.f, Vec<V>::ld(prev, off, bf));
+                Vec<V>::fma(acc, ch * cw[e], t);
+            }
+        }
+        Vec<V>::st(y, pix * C + c, acc, bf);
+    }
+}
+
+template <int V>
+__global__ void rgb_up_blur_add_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int H, int W, int C,
+                                           int bf) {
+    const int cv = C / V;
+    const long total = (long)B * H * W * cv;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cq, iw, ih, b;
+        const long pix = decomp_index(i, cv, W, H, cq, iw, ih, b);
+        const int c = cq * V;
+        const long base = (long)b * 4 * H * W * C + c;
+        float cw[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int ow = 2 * iw - 2 + e;
+            cw[e] = (ow >= 0 && ow < 2 * W) ? ub_coef(ow, iw, W) : 0.f;
+        }
+        typename Vec<V>::T acc = Vec<V>::zero();
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const int oh = 2 * ih - 2 + a;
+            if (oh < 0 || oh >= 2 * H) continue;
+            const float ch = ub_coef(oh, ih, H);
+            if (ch == 0.f) continue;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                if (cw[e] == 0.f) continue;
+                Vec<V>::fma(acc, ch * cw[e], Vec<V>::ld(dy, base + ((long)oh * 2 * W + (2 * iw - 2 + e)) * C, bf));
+            }
+        }
+        Vec<V>::st(dx, pix * C + c, acc, bf);
+    }
+}
+
+
 // space-to-depth address of element (b, h, w, c) of a [B,H,W,C] tensor stored as [B,H/2,W/2,4C]
 __device__ __forceinline__ long s2d_off(int b, int h, int w, int c, int H, int W, int C) {
     return (((long)b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * (4L * C) + (((h & 1) * 2 + (w & 1)) * C) + c;
@@ -491,6 +571,26 @@ int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
     LAUNCH_EW(upsample2x_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
+}
+int stylex_rgb_up_blur_add_fwd(const void* rgb, const void* prev, void* y, EW_ARGS) {
+    EW_UNPACK
+    if (!rgb || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    const void* al = prev ? prev : rgb;
+    if (bf && (C % 8 == 0) && vec_ok(C, rgb, y) && vec_ok(C, al, y))
+        hipLaunchKernelGGL(rgb_up_blur_add_fwd_kernel<8>, dim3(grid_for((long)B * 4 * H * W * C / 8)), dim3(256), 0, s, rgb, prev,
+                           y, B, H, W, C, bf);
+    else if (vec_ok(C, rgb, y) && vec_ok(C, al, y))
+        hipLaunchKernelGGL(rgb_up_blur_add_fwd_kernel<4>, dim3(grid_for((long)B * 4 * H * W * C / 4)), dim3(256), 0, s, rgb, prev,
+                           y, B, H, W, C, bf);
+    else
+        hipLaunchKernelGGL(rgb_up_blur_add_fwd_kernel<1>, dim3(grid_for((long)B * 4 * H * W * C)), dim3(256), 0, s, rgb, prev, y,
+                           B, H, W, C, bf);
+    return (int)hipGetLastError();
+}
+int stylex_rgb_up_blur_add_bwd(const void* dy, void* dx, EW_ARGS) {
+    EW_UNPACK
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
+    LAUNCH_EW(rgb_up_blur_add_bwd_kernel, (long)B * H * W * C, dy, dx, dy, dx, B, H, W, C, bf);
 }
 int stylex_blur3x3_reflect_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK

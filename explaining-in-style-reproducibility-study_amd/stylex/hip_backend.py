@@ -60,6 +60,8 @@ SIGNATURES = {
     "stylex_fold_weight_grad_s2d": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_rgb_up_blur_add_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_rgb_up_blur_add_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_reflect_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_reflect_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_bias_act_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, _c_f, _c_f, _c_f, _i64p, ctypes.c_int,
@@ -414,6 +416,23 @@ def upsample2x_fwd(x):
 def upsample2x_bwd(dy):
     b, c, h2, w2 = dy.shape
     return _ew("stylex_upsample2x_bilinear_bwd", dy, (b, c, h2 // 2, w2 // 2), (b, c, h2 // 2, w2 // 2))
+
+
+def rgb_up_blur_add_fwd(rgb, prev=None):
+    """blur3x3_reflect(upsample2x(rgb + prev)) in one pass (RGBBlock.forward :622-626); prev may be None."""
+    lib = _ensure_device(rgb)
+    assert is_cl(rgb) and rgb.dtype in (torch.float32, torch.bfloat16)
+    assert prev is None or (is_cl(prev) and prev.dtype == rgb.dtype and prev.shape == rgb.shape)
+    b, c, h, w = rgb.shape
+    y = empty_cl((b, c, 2 * h, 2 * w), rgb)
+    _check(lib.stylex_rgb_up_blur_add_fwd(_ptr(rgb), _ptr(prev), _ptr(y), _shape(b, h, w, c), _adt(rgb), _stream()),
+           "stylex_rgb_up_blur_add_fwd")
+    return y
+
+
+def rgb_up_blur_add_bwd(dy):
+    b, c, h2, w2 = dy.shape
+    return _ew("stylex_rgb_up_blur_add_bwd", dy, (b, c, h2 // 2, w2 // 2), (b, c, h2 // 2, w2 // 2))
 
 
 def blur3x3_fwd(x):

@@ -145,8 +145,17 @@ class RGBBlock(nn.Module):  # reference :604-629
         self.conv = Conv2DMod(input_channel, 4 if rgba else 3, 1, demod=False)
         self.upsample = nn.Sequential(Upsample2x(), Blur()) if upsample else None
 
-    def forward(self, x, prev_rgb, istyle, style=None):
-        x = self.conv(x, self.to_style(istyle) if style is None else style)
+    def forward(self, x, prev_rgb, istyle, style=None, padded=False):
+        """`padded`: the caller (Generator.forward) chains the blocks on the 4-channel storage of the fused RGB path
+        (channel 3 zero) and slices once at the end; otherwise the reference's 3-channel tensor is returned."""
+        style = self.to_style(istyle) if style is None else style
+        if padded and not self.conv.demod:
+            fused = ops.rgb_block(x, prev_rgb, style, self.conv.weight, exists(self.upsample))
+            if fused is not None:
+                return fused
+        if exists(prev_rgb) and prev_rgb.shape[1] == 4 and self.conv.weight.shape[0] == 3:
+            prev_rgb = prev_rgb[:, :3]  # an earlier block took the fused path
+        x = self.conv(x, style)
         if exists(prev_rgb):
             x = x + prev_rgb
         if exists(self.upsample):
@@ -272,7 +281,7 @@ class Generator(nn.Module):  # reference :747-825
             for li, block in enumerate(self.blocks):
                 x, sc = block.forward_main(x, styles[:, li], input_noise)
                 coords.append(sc)
-                rgb = block.to_rgb(x, rgb, styles[:, li])
+                rgb = block.to_rgb(x, rgb, styles[:, li], padded=True)
         else:
             main = torch.cuda.current_stream()
             # (measured and dropped: evaluating all blocks' style affines / demod coefficients ahead on a second
@@ -285,9 +294,11 @@ class Generator(nn.Module):  # reference :747-825
                 x.record_stream(side)
                 rgb_style.record_stream(side)
                 with torch.cuda.stream(side):
-                    rgb = block.to_rgb(x, rgb, None, style=rgb_style)
+                    rgb = block.to_rgb(x, rgb, None, style=rgb_style, padded=True)
             main.wait_stream(side)
             rgb.record_stream(main)
+        if rgb.shape[1] == 4 and self.blocks[0].to_rgb.conv.filters == 3:
+            rgb = rgb[:, :3]  # fused RGB path: 4-channel storage, channel 3 is zero
         rgb = rgb.float()  # activations may be stored in bf16; the module API returns fp32 images
         if get_style_coords:
             return rgb, torch.cat(coords, dim=1)

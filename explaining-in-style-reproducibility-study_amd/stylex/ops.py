@@ -503,6 +503,21 @@ class _ToRGBFast(torch.autograd.Function):
         return gx, gs1, gw
 
 
+class _RGBTailFast(torch.autograd.Function):
+    """blur(upsample2x(rgb + prev)) of RGBBlock.forward (reference :622-626) as one kernel each way (4-channel NHWC
+    storage of the RGB chain; once-differentiable: the composable chain serves steps that differentiate twice)."""
+
+    @staticmethod
+    def forward(ctx, rgb, prev):
+        return hb.rgb_up_blur_add_fwd(_cl(rgb), _cl(prev) if prev is not None else None)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        g = hb.rgb_up_blur_add_bwd(_cl(gy))
+        return g, (g if ctx.needs_input_grad[1] else None)
+
+
 class _BlurS2D(torch.autograd.Function):
     """blur3x3 whose output is stored space-to-depth ([B,4C,H/2,W/2]) for the stride-2 conv that follows."""
 
@@ -884,6 +899,23 @@ class HipOps:
                              res_scale=res_scale)
 
     @staticmethod
+    def rgb_block(x, prev_rgb, style, weight, upsample):
+        """Whole RGBBlock (reference :618-629) on the streaming kernels: to-RGB (1x1 modulated conv, no demodulation),
+        skip add, bilinear x2 and blur — two launches per direction.  The chain keeps the 4-channel storage of the
+        to-RGB kernel (channel 3 is zero); returns None when the composable path must run."""
+        if not fast_enabled() or os.environ.get("STYLEX_RGB_TAIL", "1") == "0":
+            return None
+        x = _act(x)
+        if tuple(weight.shape[2:]) != (1, 1) or weight.shape[0] != 3 or not hb.torgb_ok(x):
+            return None
+        if prev_rgb is not None and (prev_rgb.shape[1] != 4 or prev_rgb.dtype != x.dtype):
+            return None
+        rgb = _ToRGBFast.apply(x, style + 1, weight)
+        if upsample:
+            return _RGBTailFast.apply(rgb, prev_rgb)
+        return rgb if prev_rgb is None else rgb + prev_rgb
+
+    @staticmethod
     def residual_merge(x, res):
         return (x + res) * (1 / math.sqrt(2))
 
@@ -957,6 +989,11 @@ def blur3x3(x):
 
 def blur_down(*a, **k):
     return _IMPL.blur_down(*a, **k)
+
+
+def rgb_block(*a, **k):
+    fn = getattr(_IMPL, "rgb_block", None)
+    return fn(*a, **k) if fn is not None else None
 
 
 def residual_merge(x, res):

@@ -146,6 +146,16 @@ int stylex_upsample2x_bilinear_bwd(const void* dy, void* dx, const int64_t* shap
 int stylex_blur3x3_reflect_fwd(const void* x, void* y, const int64_t* shape, int act_dtype, void* stream);
 int stylex_blur3x3_reflect_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
 
+/* The RGB skip path of a GeneratorBlock in ONE pass (RGBBlock.forward, stylex_train.py:618-629: skip add :622-623,
+ * then self.upsample = nn.Sequential(nn.Upsample(x2, bilinear), Blur()) :613-616, :625-626):
+ *   out[B,2H,2W,C] = blur3x3_reflect(upsample2x_bilinear(rgb + prev)),   prev may be NULL (first block).
+ * shape = {B, H, W, C} of the LOW-resolution tensors.  Both resamplers are separable and linear: the kernel applies
+ * their composition as one 3x3 stencil over (rgb + prev) with exact border rules (clamp of the upsample, reflect of the
+ * blur) and rounds once.  _bwd is the adjoint: dx[B,H,W,C] from dy[B,2H,2W,C] (the gradient of rgb AND of prev). */
+int stylex_rgb_up_blur_add_fwd(const void* rgb, const void* prev, void* out, const int64_t* shape, int act_dtype,
+                               void* stream);
+int stylex_rgb_up_blur_add_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
+
 /* Space-to-depth pipeline for the blur + stride-2 conv of DiscriminatorBlock (stylex_train.py:733-742):
  * the blur writes its [B,H,W,C] result as [B,H/2,W/2,4C] (channel = ((h&1)*2+(w&1))*C + c), which turns the
  * 3x3/s2/p1 conv into a 3x3/s1/p1 conv over 4C channels whose weights (stylex_pack_weight_s2d, bf16,

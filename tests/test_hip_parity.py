@@ -926,6 +926,69 @@ def test_small_spatial_gather_kernel(case):
     close(want_dx, got[1].double(), 1e-2, "dgrad vs fp64 definition")
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 4, 4), (2, 4, 8, 16), (2, 3, 5, 7), (1, 8, 1, 1), (2, 4, 64, 64)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_rgb_up_blur_add_kernel(shape, prec):
+    """stylex_rgb_up_blur_add_fwd/_bwd == Blur(Upsample2x(rgb + prev)) of RGBBlock.forward (reference :622-626) and its
+    adjoint, against the oracle's float64 composition (clamped bilinear x2, then the reflect 3x3 blur), with and
+    without the skip input, odd sizes and the 1x1 image included."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(71)
+    rgb0, prev0 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    dy0 = torch.randn(B, C, 2 * H, 2 * W, generator=g)
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = 1e-5 if prec == "fp32" else 1.2e-2
+    for with_prev in (True, False):
+        r, pv = rgb0.to(dt).double().requires_grad_(), prev0.to(dt).double().requires_grad_()
+        t = r + pv if with_prev else r
+        want = so.blur3x3_reflect(F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False))
+        want.backward(dy0.to(dt).double())
+        got = hb.rgb_up_blur_add_fwd(cl(rgb0).to(dt), cl(prev0).to(dt) if with_prev else None)
+        close(want, got, tol, "rgb tail fwd prev=%s" % with_prev)
+        gin = hb.rgb_up_blur_add_bwd(cl(dy0).to(dt))
+        close(r.grad, gin, tol, "rgb tail adjoint prev=%s" % with_prev)
+
+
+def test_fused_rgb_path_matches_composable_chain():
+    """Generator forward / backward with the fused RGB skip path (to-RGB + _RGBTailFast on the 4-channel storage) against
+    the composable chain (STYLEX_RGB_TAIL=0: to-RGB, add, Upsample2x, Blur as separate nodes), bf16 speed mode: image and
+    every parameter gradient."""
+    import os
+
+    from networks import Generator
+
+    ops.set_precision("bf16")
+    torch.manual_seed(5)
+    G = Generator(64, 32, network_capacity=8).to(DEV)
+    styles = torch.randn(3, G.num_layers, 32, device=DEV)
+    noise = torch.rand(3, 64, 64, 1, device=DEV)
+    gout = torch.randn(3, 3, 64, 64, device=DEV)
+
+    def run():
+        G.zero_grad(set_to_none=True)
+        st = styles.clone().requires_grad_()
+        img = G(st, noise)
+        img.backward(gout)
+        return img.detach(), st.grad, {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None}
+
+    prev = ops.set_fast(True)
+    try:
+        img_f, gs_f, gp_f = run()
+        os.environ["STYLEX_RGB_TAIL"] = "0"
+        try:
+            img_c, gs_c, gp_c = run()
+        finally:
+            os.environ.pop("STYLEX_RGB_TAIL", None)
+    finally:
+        ops.set_fast(prev)
+    assert img_f.shape == (3, 3, 64, 64)
+    close(img_c, img_f, 2e-2, "image")
+    close(gs_c, gs_f, 4e-2, "style grad")
+    assert gp_f.keys() == gp_c.keys()
+    for n in gp_c:
+        close(gp_c[n], gp_f[n], 4e-2, "grad " + n)
+
+
 @pytest.mark.parametrize("case", [(64, 512, 512, 16, 16), (32, 512, 512, 8, 8), (64, 512, 512, 4, 4), (5, 128, 192, 16, 8),
                                   (3, 64, 64, 4, 12), (130, 64, 64, 2, 2)])
 def test_small_spatial_gather_kernel_stride2(case):

@@ -1,0 +1,61 @@
+"""Which source lines of the train step launch the small ATen kernels (count and device time per call site)?
+GPU box: python tools/op_sites.py [--top 60]"""
+import argparse
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--top", type=int, default=60)
+args = ap.parse_args()
+sys.argv = ["bench.py"]
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+import bench  # noqa: E402
+
+a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir="/tmp/sb", precision="bf16")
+sys.path[:0] = [os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd", "stylex")]
+import hip_backend as hb  # noqa: E402
+import ops  # noqa: E402
+
+hb.load_library()
+ops.set_precision("bf16")
+tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
+for i in range(6):
+    tr.train()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+    tr.train()
+    torch.cuda.synchronize()
+
+PKG = "explaining-in-style-reproducibility-study_amd"
+site_t = collections.Counter()
+site_n = collections.Counter()
+for e in prof.events():
+    if not e.name.startswith("aten::"):
+        continue
+    if e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::"):
+        continue
+    dt = sum(k.duration for k in e.kernels) if hasattr(e, "kernels") else 0.0
+    if dt <= 0:
+        dt = getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)
+    site = "?"
+    frames = [fr for fr in (e.stack or []) if PKG in fr]
+    if frames:  # innermost package frame + its caller
+        site = " <- ".join(fr.split(PKG + "/stylex/")[-1][:48] for fr in frames[:2])
+    elif e.stack:
+        site = "[autograd/other] " + e.stack[0][-70:]
+    site_t[(site, e.name)] += dt
+    site_n[(site, e.name)] += 1
+tot = sum(site_t.values())
+print("device time of top-level aten ops: %.2f ms/step over %d calls" % (tot / 1e3, sum(site_n.values())))
+SKIP = ("aten::conv2d", "aten::convolution_backward", "aten::batch_norm", "aten::native_batch_norm_backward")
+for (site, name), t in site_t.most_common(args.top + 8):
+    if name in SKIP:
+        continue
+    print("%8.1f us %5d  %-26s %s" % (t, site_n[(site, name)], name, site))
