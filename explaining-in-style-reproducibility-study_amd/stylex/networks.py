@@ -278,10 +278,13 @@ class Generator(nn.Module):  # reference :747-825
         # until it is, the chain stays on the caller's stream.
         side = _side_stream(x) if os.environ.get("STYLEX_G_SIDE", "0") == "1" else None
         if side is None:
+            # one UnbindBackward (a stack) instead of num_layers SelectBackwards (a zero-filled [B, L, D] tensor each,
+            # summed pairwise by the engine): ~20 fewer launches per generator backward
+            per_layer = styles.unbind(1)
             for li, block in enumerate(self.blocks):
-                x, sc = block.forward_main(x, styles[:, li], input_noise)
+                x, sc = block.forward_main(x, per_layer[li], input_noise)
                 coords.append(sc)
-                rgb = block.to_rgb(x, rgb, styles[:, li], padded=True)
+                rgb = block.to_rgb(x, rgb, per_layer[li], padded=True)
         else:
             main = torch.cuda.current_stream()
             # (measured and dropped: evaluating all blocks' style affines / demod coefficients ahead on a second

@@ -34,6 +34,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 
 PKG = "explaining-in-style-reproducibility-study_amd"
+OURS = set(f for f in os.listdir(os.path.join(ROOT, PKG, "stylex")) if f.endswith(".py")) | {"bench.py"}
 site_t = collections.Counter()
 site_n = collections.Counter()
 for e in prof.events():
@@ -45,11 +46,11 @@ for e in prof.events():
     if dt <= 0:
         dt = getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0)
     site = "?"
-    frames = [fr for fr in (e.stack or []) if PKG in fr]
-    if frames:  # innermost package frame + its caller
-        site = " <- ".join(fr.split(PKG + "/stylex/")[-1][:48] for fr in frames[:2])
+    frames = [fr for fr in (e.stack or []) if fr.split("(")[0] in OURS]
+    if frames:  # innermost package frames
+        site = " <- ".join(fr[:44] for fr in frames[:3])
     elif e.stack:
-        site = "[autograd/other] " + e.stack[0][-70:]
+        site = "[autograd engine / other] " + e.stack[0][-60:]
     site_t[(site, e.name)] += dt
     site_n[(site, e.name)] += 1
 tot = sum(site_t.values())
