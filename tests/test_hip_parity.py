@@ -782,6 +782,11 @@ def test_graph_replay_matches_eager(tmp_path):
     instead of expand) and nothing else, so the bound is the 5-step bound of the golden tests."""
     g = load_golden("steps_gae2_alt")
     rows = {}
+    # the frozen classifier / LPIPS run on MIOpen: pin its algorithm choice, which otherwise depends on what the process
+    # ran before (find cache) and on whether a capture is open — logits then differ at 1e-7 between the two paths and
+    # the untrained GAN amplifies that past any bound within a few steps (same pin as tests/test_hip_determinism_gpu.py)
+    prev_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
     for graphs in (False, True):
         tr, _ = make_trainer(g, tmp_path, device=torch.device(DEV))
         tr2 = st.Trainer(name="g%d" % graphs, base_dir=str(tmp_path), image_size=tr.image_size,
@@ -803,6 +808,7 @@ def test_graph_replay_matches_eager(tmp_path):
         rows[graphs] = run_steps(tr2, 8)
         if graphs:
             assert sorted(tr2._graph_cache) == [False, True], tr2._graph_cache.keys()
+    torch.backends.cudnn.deterministic = prev_det
     a, b = rows[False][:, :5], rows[True][:, :5]
     print("eager\\n", a, "\\ngraph\\n", b)
     assert np.isfinite(b).all()
