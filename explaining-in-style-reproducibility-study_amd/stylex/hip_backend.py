@@ -179,8 +179,39 @@ def conv_shape(x_shape, w_shape, stride, pad):
     return (b, h, w, c, n, kh, kw, stride, pad, ho, wo)
 
 
+# Debug aid (STYLEX_POISON=1): every output / workspace this module allocates is filled with NaN before the kernel that
+# is supposed to write it runs, so an element a kernel leaves unwritten — which the caching allocator otherwise fills
+# with whatever the block held before — shows up as a NaN downstream instead of as run-to-run noise.
+_POISON = os.environ.get("STYLEX_POISON", "0") != "0"
+
+
+_GUARD = 8192 if os.environ.get("STYLEX_POISON", "0") == "2" else 0  # elements of NaN guard band on either side
+
+
+def _empty(*shape_args, **kw):
+    """torch.empty, or under STYLEX_POISON a NaN-filled tensor; STYLEX_POISON=2 additionally surrounds the tensor with
+    NaN guard bands (a read a few elements before / past a tensor then poisons the result instead of returning whatever
+    the neighbouring allocation holds)."""
+    if not _POISON:
+        return torch.empty(*shape_args, **kw)
+    fmt = kw.pop("memory_format", torch.contiguous_format)
+    shape = shape_args[0] if len(shape_args) == 1 and not isinstance(shape_args[0], int) else shape_args
+    shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+    if not _GUARD or kw.get("dtype", torch.float32) not in (torch.float32, torch.bfloat16):
+        t = torch.empty(shape, memory_format=fmt, **kw)
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
+    numel = 1
+    for v in shape:
+        numel *= v
+    flat = torch.full((numel + 2 * _GUARD,), float("nan"), **kw)
+    strides = torch.empty(shape, device="meta", memory_format=fmt).stride()
+    return flat.as_strided(shape, strides, _GUARD)
+
+
 def empty_cl(shape, like, dtype=None):
-    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device, memory_format=torch.channels_last)
+    return _empty(shape, dtype=dtype or like.dtype, device=like.device, memory_format=torch.channels_last)
 
 
 _PACK_CACHE = {}
@@ -205,10 +236,13 @@ def _release_at_exit():
 atexit.register(_release_at_exit)
 
 
+_CACHE_ON = os.environ.get("STYLEX_PACK_CACHE", "1") != "0"  # probe switch: 0 = repack on every use
+
+
 def _cache_hit(key, w):
     """Cached packs may have been produced on another HIP stream (the Trainer forks independent branches over
     side streams): make the consumer stream wait for the producing kernel and keep the block alive for it."""
-    hit = _PACK_CACHE.get(key)
+    hit = _PACK_CACHE.get(key) if _CACHE_ON else None
     if hit is None or hit[0]() is not w:  # same live Parameter object (its address cannot be recycled)
         return None
     cur = torch.cuda.current_stream()
@@ -251,8 +285,8 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
         w = w.detach() * scale
     n, c, kh, kw = w.shape
     dt = torch.float32 if precision == F32 else torch.bfloat16
-    wf = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_fwd else None
-    wb = torch.empty(n * kh * kw * c, dtype=dt, device=w.device) if want_bwd else None
+    wf = _empty(n * kh * kw * c, dtype=dt, device=w.device) if want_fwd else None
+    wb = _empty(n * kh * kw * c, dtype=dt, device=w.device) if want_bwd else None
     _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
            "stylex_pack_weight")
     if key is not None:
@@ -274,8 +308,8 @@ def pack_weight_s2d(w, scale=None):
         wc = wc.detach() * scale
     n, c, kh, kw = wc.shape
     assert kh == 3 and kw == 3
-    wf = torch.empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
-    wb = torch.empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
+    wf = _empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
+    wb = _empty(n * 36 * c, dtype=torch.bfloat16, device=w.device)
     _check(lib.stylex_pack_weight_s2d(_ptr(wc), _ptr(wf), _ptr(wb), _shape(n, c, 3, 3), _stream()),
            "stylex_pack_weight_s2d")
     if key is not None:
@@ -286,7 +320,7 @@ def pack_weight_s2d(w, scale=None):
 def fold_weight_grad_s2d(dw2, w_shape):
     lib = _ensure_device(dw2)
     n, c = w_shape[0], w_shape[1]
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dw2.device)
+    dw = _empty(tuple(w_shape), dtype=torch.float32, device=dw2.device)
     _check(lib.stylex_fold_weight_grad_s2d(_ptr(dw2.contiguous()), _ptr(dw), _shape(n, c, 3, 3), _stream()),
            "stylex_fold_weight_grad_s2d")
     return dw
@@ -296,7 +330,7 @@ def _split_workspace(lib, shp, which, precision, like):
     nbytes = lib.stylex_conv2d_workspace_bytes(shp, which, precision)
     if nbytes <= 0:
         return None, 0
-    return torch.empty(nbytes // 4, dtype=torch.float32, device=like.device), nbytes
+    return _empty(nbytes // 4, dtype=torch.float32, device=like.device), nbytes
 
 
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
@@ -391,8 +425,8 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
     nbytes = lib.stylex_conv2d_bwd_weight_workspace_bytes(shp)
     if nbytes < 0:
         raise StylexHipError("bad wgrad shape %r" % (sh,))
-    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    ws = _empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    dw = _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     x_scale, dy_scale = _f32(x_scale), _f32(dy_scale)
     _check(lib.stylex_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, _ptr(x_scale),
                                         _ptr(dy_scale), int(s2d_c), precision, _stream()), "stylex_conv2d_bwd_weight")
@@ -530,7 +564,7 @@ def bias_act_bwd(dy, y):
 def rowwise_sumsq(x2d):
     lib = _ensure_device(x2d)
     x2d = x2d.float().contiguous()
-    out = torch.empty(x2d.shape[0], dtype=torch.float32, device=x2d.device)
+    out = _empty(x2d.shape[0], dtype=torch.float32, device=x2d.device)
     _check(lib.stylex_rowwise_sumsq(_ptr(x2d), _ptr(out), _shape(x2d.shape[0], x2d.shape[1]), _stream()),
            "stylex_rowwise_sumsq")
     return out
@@ -543,7 +577,7 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True):
     b, c, h, w = dy.shape
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
-    partial = torch.empty((b, nch, c), dtype=torch.float32, device=dy.device)
+    partial = _empty((b, nch, c), dtype=torch.float32, device=dy.device)
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
     _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)),
                                      float(scale), _adt(dy), _stream()), "stylex_act_bwd_reduce")
@@ -558,7 +592,7 @@ def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu, gz_scale=None):
     b, c, h, w = gy.shape
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
-    partial = torch.empty((b, nch, 3, c), dtype=torch.float32, device=gy.device)
+    partial = _empty((b, nch, 3, c), dtype=torch.float32, device=gy.device)
     gz = empty_cl(tuple(gy.shape), gy)
     ns = 0
     noise, noise_w, noise_b = _f32(noise), _f32(noise_w), _f32(noise_b)
@@ -583,7 +617,7 @@ def scale_reduce(x, t, s, want_gx=True):
     b, c, h, w = x.shape
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
-    partial = torch.empty((b, nch, c), dtype=torch.float32, device=x.device)
+    partial = _empty((b, nch, c), dtype=torch.float32, device=x.device)
     gx = empty_cl(tuple(x.shape), x) if want_gx else None
     s = _f32(s)
     _check(lib.stylex_scale_reduce(_ptr(x), _ptr(t), _ptr(s), _ptr(gx), _ptr(partial), shp, nch, _adt(x), _stream()),
@@ -618,7 +652,7 @@ def torgb_bwd(x, gy, s1, w, want_gx=True):
     b, c, h, wd = x.shape
     shp = _shape(b, h, wd, c)
     nch = lib.stylex_torgb_chunks(shp)
-    partial = torch.empty((b, nch, 3, c), dtype=torch.float32, device=x.device)
+    partial = _empty((b, nch, 3, c), dtype=torch.float32, device=x.device)
     gx = empty_cl(tuple(x.shape), x) if want_gx else None
     s1, w = _f32(s1), _f32(w)
     _check(lib.stylex_torgb_bwd(_ptr(x), _ptr(gy), _ptr(s1), _ptr(w), _ptr(gx), _ptr(partial), shp, _stream()),

@@ -276,7 +276,9 @@ class Generator(nn.Module):  # reference :747-825
         # reproducible under concurrency, tools/probes/torgb_concurrency_probe.py, and the autograd engine's
         # cross-stream hand-off checks out in isolation, tools/probes/engine_stream_probe.py).  Root cause not found;
         # until it is, the chain stays on the caller's stream.
-        side = _side_stream(x) if os.environ.get("STYLEX_G_SIDE", "0") == "1" else None
+        g_side = os.environ.get("STYLEX_G_SIDE", "0")  # 1: always; 2 / 3 (probes): only without / only with autograd recording
+        use_side = g_side == "1" or (g_side == "2" and not torch.is_grad_enabled()) or (g_side == "3" and torch.is_grad_enabled())
+        side = _side_stream(x) if use_side else None
         if side is None:
             # one UnbindBackward (a stack) instead of num_layers SelectBackwards (a zero-filled [B, L, D] tensor each,
             # summed pairwise by the engine): ~20 fewer launches per generator backward

@@ -59,7 +59,7 @@ def test_train_from_folder_cpu(tmp_path):
 
 
 def test_set_seed_reseeds_all_three_generators():
-    """reference cli.py:35-40 (the cudnn flags it also sets are opt-in here, see cli.set_seed)."""
+    """reference cli.py:35-40, including the cudnn flags (:37-38)."""
     import random
 
     cli.set_seed(123)
@@ -67,6 +67,7 @@ def test_set_seed_reseeds_all_three_generators():
     cli.set_seed(123)
     b = (torch.rand(3), np.random.rand(3), random.random())
     assert torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert torch.backends.cudnn.deterministic is True and torch.backends.cudnn.benchmark is False
 
 
 def test_new_architecture_switch_and_evaluate(tmp_path, monkeypatch):

@@ -13,7 +13,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run(steps=5, image_size=256, batch=32, lazy=False):
+def run(steps=5, image_size=256, batch=32, lazy=False, trainers=2):
     """lazy=True: no loss scalar is read until the last step (reading one waits for the step's device->host copy), so
     the host runs ahead of the GPU by whole steps exactly as it does in real training / bench.py."""
     import torch
@@ -35,7 +35,21 @@ def run(steps=5, image_size=256, batch=32, lazy=False):
                            precision="bf16")
     runs = []
     try:
-        for _ in range(2):
+        if os.environ.get("DET_WARM", "1") != "0":
+            # A throw-away Trainer first.  The FIRST Trainer of a process differs from every later one deterministically
+            # (same value in every process; later Trainers agree with each other bit for bit): the autograd engine orders
+            # ready nodes by per-thread sequence numbers, and the nodes the double backward of a penalty step creates on
+            # the engine's worker thread start from that thread's counter, so in a fresh process they interleave
+            # differently with the main thread's nodes — a different accumulation ORDER of the parameter gradients that
+            # receive several contributions (tools/probes/first_diff_probe.py: the call sequences differ; every kernel
+            # output agrees until they do).  Not a race: the check is about run-to-run noise in steady state.
+            bench.seed_all(42)
+            tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
+            tr.train()
+            torch.cuda.synchronize()
+            del tr
+            torch.cuda.empty_cache()
+        for _ in range(trainers):
             bench.seed_all(42)
             tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
             rows = []
@@ -57,7 +71,9 @@ if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     os.chdir(ROOT)
-    r = run(steps, size)
+    r = run(steps, size, trainers=int(os.environ.get("DET_TRAINERS", "2")))
+    if len(r) > 2:
+        print("all parameter checksums", [x[1] for x in r])
     for i, (x, y) in enumerate(zip(r[0][0], r[1][0])):
         print(i, "OK  " if x == y else "DIFF", x, y if x != y else "")
     print("parameter checksum", r[0][1], r[1][1])
