@@ -364,6 +364,7 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
         rc = stylex_launch_halo_dma(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
+    if (p.mask || p.gate_mask || p.dry) return STYLEX_NOT_APPLICABLE;  // bit masks: LDS-DMA / RGB kernels only
     const bool wide = p.Wo >= 32;
     const bool epix = (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE)) != 0;
     if (p.act_bf16) {

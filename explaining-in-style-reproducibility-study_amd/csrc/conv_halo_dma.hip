@@ -279,6 +279,12 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
     unsigned short* yout = reinterpret_cast<unsigned short*>(p.y);
     const unsigned short* gate = (!S2D && (p.flags & STYLEX_EPI_GATE)) ? reinterpret_cast<const unsigned short*>(p.residual) : nullptr;
     const float gslope = p.res_scale;
+    const unsigned char* gmask = S2D ? nullptr : p.gate_mask;  // STYLEX_EPI_GATE_MASK: the gate as one bit per element
+    unsigned char* mask_out = S2D ? nullptr : p.mask;          // STYLEX_EPI_MASK_OUT
+    auto gatem = [&](unsigned u, unsigned bits) -> unsigned {  // two bf16 of dx, gate bits (element > 0) in bits 0 and 1
+        const float a0 = __uint_as_float(u << 16), c0 = __uint_as_float(u & 0xffff0000u);
+        return (unsigned)to_bf16((bits & 1u) ? a0 : gslope * a0) | ((unsigned)to_bf16((bits & 2u) ? c0 : gslope * c0) << 16);
+    };
     auto gate2 = [&](unsigned u, unsigned g) -> unsigned {  // two bf16 of dx times the LeakyReLU derivative at the gate
         const float a0 = __uint_as_float(u << 16), c0 = __uint_as_float(u & 0xffff0000u);
         const float ga = __uint_as_float(g << 16), gc = __uint_as_float(g & 0xffff0000u);
@@ -350,8 +356,15 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
                             v.y = gate2(v.y, gv.y);
                             v.z = gate2(v.z, gv.z);
                             v.w = gate2(v.w, gv.w);
+                        } else if (gmask) {
+                            const unsigned m = gmask[o >> 3];
+                            v.x = gatem(v.x, m);
+                            v.y = gatem(v.y, m >> 2);
+                            v.z = gatem(v.z, m >> 4);
+                            v.w = gatem(v.w, m >> 6);
                         }
                         *reinterpret_cast<uint4*>(yout + o) = v;
+                        if (mask_out) mask_out[o >> 3] = (unsigned char)stylex_sign_bits8(v);
                     }
                 }
             }
@@ -385,8 +398,10 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
     static const bool on_s2d = !(getenv("STYLEX_HALO_DMA_S2D") && getenv("STYLEX_HALO_DMA_S2D")[0] == '0');
     if (!on) return STYLEX_NOT_APPLICABLE;
     if (!p.act_bf16 || p.a_scale) return STYLEX_NOT_APPLICABLE;
-    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | (p.s2d_c ? STYLEX_EPI_RESIDUAL : STYLEX_EPI_GATE)))
+    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU |
+                    (p.s2d_c ? STYLEX_EPI_RESIDUAL : (STYLEX_EPI_GATE | STYLEX_EPI_GATE_MASK | STYLEX_EPI_MASK_OUT))))
         return STYLEX_NOT_APPLICABLE;
+    if (p.s2d_c && (p.mask || p.gate_mask)) return STYLEX_NOT_APPLICABLE;
     if ((p.flags & STYLEX_EPI_GATE) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15))) return STYLEX_NOT_APPLICABLE;
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
@@ -405,14 +420,14 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
             if ((p.flags & STYLEX_EPI_RESIDUAL) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15)))
                 return STYLEX_NOT_APPLICABLE;
         }
-        return launch_dma<2, true>(p, s);
+        return p.dry ? 0 : launch_dma<2, true>(p, s);
     }
     // Measured at B = 64 (fwd / dgrad ms, 128-channel tiles at one block per CU -> 64-channel tiles at two):
     // 128->128 @128^2 .361/.351 -> .313/.311, 128->256 @64^2 .176 -> .149, 256->256 @64^2 .284/.281 -> .264/.273,
     // 512->512 @32^2 .259/.264 -> .257/.263, 64->64 @256^2 (register-staged kernel) .430/.425 -> .377/.384: the second
     // resident block hides more than the wider tile saves in LDS reads, so the 64-channel variant is the default and
     // the 128-channel one serves output widths that are not a multiple of 64.
-    if (on64 && p.Ck >= 64 && p.N % 64 == 0) return launch_dma<2>(p, s);
-    if (p.N >= 128 && p.Ck >= 128) return launch_dma<4>(p, s);
+    if (on64 && p.Ck >= 64 && p.N % 64 == 0) return p.dry ? 0 : launch_dma<2>(p, s);
+    if (p.N >= 128 && p.Ck >= 128) return p.dry ? 0 : launch_dma<4>(p, s);
     return STYLEX_NOT_APPLICABLE;
 }

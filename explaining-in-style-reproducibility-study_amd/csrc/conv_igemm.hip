@@ -1086,6 +1086,7 @@ int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t w
         rc = stylex_launch_halo(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
+    if (p.mask || p.gate_mask) return STYLEX_EINVAL;  // the caller did not ask stylex_conv_mask_supported()
     p.ksplit = 1;
     p.kt_per_split = 0;
     p.partial = nullptr;

@@ -119,9 +119,12 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_kernel(ConvKParams p) {
             const int id = lane + 64 * k;  // 32 px x 8 slots of 8 channels
             const int px = id >> 3, q = id & 7;
             const int x = x0 + px;
-            if (y < H && x < W && q * 8 < p.N)
-                *reinterpret_cast<uint4*>(yout + ((long)(b * H + y) * W + x) * p.N + q * 8) =
-                    *reinterpret_cast<const uint4*>(scr + px * 128 + q * 16);
+            if (y < H && x < W && q * 8 < p.N) {
+                const uint4 v = *reinterpret_cast<const uint4*>(scr + px * 128 + q * 16);
+                const long o = ((long)(b * H + y) * W + x) * p.N + q * 8;
+                *reinterpret_cast<uint4*>(yout + o) = v;
+                if (p.mask) p.mask[o >> 3] = (unsigned char)stylex_sign_bits8(v);  // STYLEX_EPI_MASK_OUT
+            }
         }
     }
 }
@@ -135,9 +138,11 @@ int stylex_launch_rgb(const ConvKParams& p, hipStream_t s) {
     if (!p.act_bf16 || p.a_scale || p.s2d_c || p.flip_taps || p.transposed) return STYLEX_NOT_APPLICABLE;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return STYLEX_NOT_APPLICABLE;
     if (p.Ck != 8 || p.N != 64 || p.Wo < 32 || p.Ho < 8) return STYLEX_NOT_APPLICABLE;
-    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU)) return STYLEX_NOT_APPLICABLE;
+    if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_MASK_OUT)) return STYLEX_NOT_APPLICABLE;
+    if (p.gate_mask) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (reinterpret_cast<uintptr_t>(p.y) & 15))
         return STYLEX_NOT_APPLICABLE;
+    if (p.dry) return 0;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_rgb_kernel),

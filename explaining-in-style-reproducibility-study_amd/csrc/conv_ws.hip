@@ -287,7 +287,7 @@ int stylex_launch_ws(const ConvKParams& p, hipStream_t s) {
     // can be in flight per CU, against ~76 KiB for two resident blocks of the LDS-DMA kernel: by Little's law the
     // stream tops out near 2 TB/s.  Kept as a correct, tested reference point for that experiment.
     const char* env = getenv("STYLEX_CONV_WS");  // read per launch: the A/B test toggles it in-process
-    if (!env || env[0] != '1') return STYLEX_NOT_APPLICABLE;
+    if (!env || env[0] != '1' || p.mask || p.gate_mask || p.dry) return STYLEX_NOT_APPLICABLE;
     if (!p.act_bf16 || p.s2d_c) return STYLEX_NOT_APPLICABLE;
     if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | STYLEX_EPI_GATE | STYLEX_EPI_OSCALE))
         return STYLEX_NOT_APPLICABLE;

@@ -389,7 +389,8 @@ __device__ __forceinline__ void blur_tap(int pos, int d, int n, int& idx, float&
 template <bool ADJ, int ROWS>
 __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short* __restrict__ in,
                                                             unsigned short* __restrict__ out, int B, int H, int W, int C,
-                                                            int s2d, const unsigned short* __restrict__ gate, float gslope) {
+                                                            int s2d, const unsigned short* __restrict__ gate, float gslope,
+                                                            const unsigned char* __restrict__ gmask) {
     const int cv = C >> 3;
     const int strips = (H + ROWS - 1) / ROWS;
     const long total = (long)B * strips * W * cv;
@@ -437,6 +438,13 @@ __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short
                 *reinterpret_cast<F8*>(g) = Vec<8>::ld(gate, o, 1);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] = g[e] > 0.f ? a[e] : gslope * a[e];
+                acc = *reinterpret_cast<F8*>(a);
+            } else if (ADJ && gmask) {  // the gate as one bit per element (STYLEX_EPI_MASK_OUT of the forward conv)
+                float a[8];
+                *reinterpret_cast<F8*>(a) = acc;
+                const unsigned m = gmask[o >> 3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = ((m >> e) & 1u) ? a[e] : gslope * a[e];
                 acc = *reinterpret_cast<F8*>(a);
             }
             Vec<8>::st(out, o, acc, 1);
@@ -542,14 +550,14 @@ static bool blur_strip_ok(int bf, int H, int C, const void* a, const void* b) {
 }
 template <bool ADJ>
 static int launch_blur_strip(const void* in, void* out, int B, int H, int W, int C, int s2d, hipStream_t s,
-                             const void* gate = nullptr, float gslope = 0.f) {
+                             const void* gate = nullptr, float gslope = 0.f, const void* gmask = nullptr) {
     constexpr int ROWS = 8;
     long work = (long)B * ((H + ROWS - 1) / ROWS) * W * (C / 8);
     long blocks = (work + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((blur3x3_strip_kernel<ADJ, ROWS>), dim3((unsigned)blocks), dim3(256), 0, s,
                        (const unsigned short*)in, (unsigned short*)out, B, H, W, C, s2d, (const unsigned short*)gate,
-                       gslope);
+                       gslope, (const unsigned char*)gmask);
     return (int)hipGetLastError();
 }
 
@@ -618,6 +626,12 @@ int stylex_blur3x3_reflect_bwd_gate(const void* dy, const void* gate, float slop
 int stylex_blur3x3_s2d_bwd_gate(const void* dy, const void* gate, float slope, void* dx, EW_ARGS) {
     if (!gate) return STYLEX_EINVAL;
     return blur_bwd_impl(dy, gate, slope, dx, 1, sh, act_dtype, stream);
+}
+int stylex_blur3x3_s2d_bwd_gate_mask(const void* dy, const void* mask, float slope, void* dx, EW_ARGS) {
+    EW_UNPACK
+    if (!dy || !mask || !dx || B <= 0 || H < 2 || W < 2 || C <= 0 || (H & 1) || (W & 1)) return STYLEX_EINVAL;
+    if (!blur_strip_ok(bf, H, C, dy, dx)) return STYLEX_EINVAL;  // the strip kernel is the only reader of masks
+    return launch_blur_strip<true>(dy, dx, B, H, W, C, 1, s, nullptr, slope, mask);
 }
 int stylex_blur3x3_s2d_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK

@@ -209,6 +209,34 @@ int64_t stylex_conv2d_workspace_bytes(const int64_t* sh, int which, int precisio
     return stylex_igemm_workspace_bytes(p, precision);
 }
 
+int stylex_conv_mask_supported(const int64_t* sh, int which, int flags, int precision) {
+    if (!conv_shape_ok(sh) || precision != STYLEX_BF16_ACT || (which != 0 && which != 1)) return 0;
+    // the same applicability checks the launchers run, on 16-byte aligned stand-in pointers, launching nothing
+    static const uintptr_t fake = 4096;
+    ConvKParams p;
+    if (which == 0) {
+        if (!(flags & STYLEX_EPI_MASK_OUT) || !(flags & STYLEX_EPI_LRELU)) return 0;
+        fwd_params(p, sh);
+        if (p.N % 8 != 0) return 0;
+        p.mask = (unsigned char*)fake;
+    } else {
+        if (!(flags & STYLEX_EPI_GATE_MASK) || (flags & ~(STYLEX_EPI_GATE_MASK))) return 0;
+        bwd_data_params(p, sh);
+        if (p.KH != 3 || p.stride != 1 || p.pad != 1) return 0;
+        p.flip_taps = 1;
+        p.gate_mask = (const unsigned char*)fake;
+    }
+    p.a = (const float*)fake;
+    p.w = (const void*)fake;
+    p.y = (float*)fake;
+    p.bias = (const float*)fake;
+    p.flags = flags;
+    p.act_bf16 = 1;
+    p.dry = 1;
+    if (which == 0 && stylex_launch_rgb(p, nullptr) == 0) return 1;
+    return stylex_launch_halo(p, nullptr) == 0 ? 1 : 0;
+}
+
 int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* sh, int flags,
                       const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                       void* stream) {
@@ -234,6 +262,11 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
         p.res_scale = epi->res_scale;
         p.s2d_c = (int)epi->s2d_c;
     }
+    if (flags & STYLEX_EPI_GATE_MASK) return STYLEX_EINVAL;  // data gradient only
+    if (flags & STYLEX_EPI_MASK_OUT) {
+        if (!epi || !epi->mask || !(flags & STYLEX_EPI_LRELU) || !p.act_bf16 || p.N % 8 != 0) return STYLEX_EINVAL;
+        p.mask = (unsigned char*)epi->mask;
+    }
     if ((flags & STYLEX_EPI_BIAS) && !p.bias) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_OSCALE) && !p.out_scale) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_NOISE_NAT) && (!(flags & STYLEX_EPI_NOISE) || (reinterpret_cast<uintptr_t>(p.noise) & 15) ||
@@ -253,8 +286,10 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
                            void* stream) {
     if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
-    if (flags & ~(STYLEX_EPI_OSCALE | STYLEX_EPI_GATE)) return STYLEX_EINVAL;
+    if (flags & ~(STYLEX_EPI_OSCALE | STYLEX_EPI_GATE | STYLEX_EPI_GATE_MASK)) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_GATE) && (!epi || !epi->residual)) return STYLEX_EINVAL;
+    if ((flags & STYLEX_EPI_GATE_MASK) && ((flags & STYLEX_EPI_GATE) || !epi || !epi->mask || precision != STYLEX_BF16_ACT))
+        return STYLEX_EINVAL;
     ConvKParams p;
     bwd_data_params(p, sh);
     p.a = (const float*)dy;
@@ -273,6 +308,7 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
             q.residual = (const float*)epi->residual;  // gate tensor (STYLEX_EPI_GATE)
             q.res_scale = epi->res_scale;
             q.s2d_c = (int)epi->s2d_c;
+            if (flags & STYLEX_EPI_GATE_MASK) q.gate_mask = (const unsigned char*)epi->mask;
             if (q.s2d_c && (q.N != 4 * q.s2d_c || q.s2d_c % 64)) return STYLEX_EINVAL;
         }
         if (!((flags & STYLEX_EPI_OSCALE) && !q.out_scale)) {
@@ -287,6 +323,7 @@ int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const in
             }
         }
     }
+    if (flags & STYLEX_EPI_GATE_MASK) return STYLEX_EINVAL;  // only the LDS-DMA kernel reads masks (stylex_conv_mask_supported)
     p.transposed = 1;
     p.phase_major = (p.stride == 2 && (p.Ho % 2 == 0) && (p.Wo % 2 == 0)) ? 1 : 0;
     p.flags = flags;

@@ -36,6 +36,9 @@ struct ConvKParams {
     int ksplit;       // igemm split-K: number of K slices (1 = none)
     int kt_per_split; // igemm split-K: K-tiles per slice
     float* partial;   // igemm split-K: [ksplit][B*Ho*Wo*N] raw accumulators
+    unsigned char* mask;            // STYLEX_EPI_MASK_OUT: sign bits of the stored output, [M][N/8] bytes
+    const unsigned char* gate_mask; // STYLEX_EPI_GATE_MASK: the activation gate of a data gradient as such a mask
+    int dry;                        // launchers: run the applicability checks only, launch nothing (mask-support query)
 };
 
 int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s);
@@ -45,6 +48,20 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
 int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, int dtype, hipStream_t s);
 
 #define STYLEX_NOT_APPLICABLE (-100)
+
+#ifdef __HIPCC__
+// bit k = (bf16 element k of the 16-byte vector > 0), with the float comparison the tensor-gate path uses
+__device__ __forceinline__ unsigned stylex_sign_bits8(uint4 v) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned m = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        m |= (__uint_as_float(w[d] << 16) > 0.f ? 1u : 0u) << (2 * d);
+        m |= (__uint_as_float(w[d] & 0xffff0000u) > 0.f ? 1u : 0u) << (2 * d + 1);
+    }
+    return m;
+}
+#endif
 // 3x3/s1/p1 bf16 kernel with the input halo resident in LDS (conv_halo.hip)
 int stylex_launch_halo(const ConvKParams& p, hipStream_t s);
 

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylex_hip.so")
 
 F32, BF16, BF16_ACT = 0, 1, 2  # BF16_ACT: bf16 MFMA + bf16 activation tensors in HBM
 EPI_BIAS, EPI_LRELU, EPI_OSCALE, EPI_NOISE, EPI_RESIDUAL, EPI_RELU, EPI_GATE, EPI_NOISE_NAT = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_MASK_OUT, EPI_GATE_MASK = 256, 512
 
 _c_f = ctypes.c_void_p  # device pointers travel as void*
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -33,6 +34,7 @@ class ConvEpilogue(ctypes.Structure):
         ("residual", ctypes.c_void_p),
         ("res_scale", ctypes.c_float),
         ("s2d_c", ctypes.c_int32),
+        ("mask", ctypes.c_void_p),
     ]
 
 
@@ -53,6 +55,8 @@ SIGNATURES = {
     "stylex_blur3x3_s2d_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_reflect_bwd_gate": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_bwd_gate": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_blur3x3_s2d_bwd_gate_mask": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_conv_mask_supported": (ctypes.c_int, [_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "stylex_add_at_even": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_subsample2_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_subsample2_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -333,11 +337,26 @@ def _split_workspace(lib, shp, which, precision, like):
     return _empty(nbytes // 4, dtype=torch.float32, device=like.device), nbytes
 
 
+_MASK_OK = {}
+
+
+def conv_mask_supported(sh, which, flags, precision):
+    """Does a conv launch of this shape write (which=0, forward with EPI_MASK_OUT) / read (which=1, data gradient with
+    EPI_GATE_MASK) the activation bit mask?  (stylex_conv_mask_supported; cached per shape.)"""
+    key = (tuple(sh), which, flags, precision)
+    hit = _MASK_OK.get(key)
+    if hit is None:
+        hit = _MASK_OK[key] = bool(load_library().stylex_conv_mask_supported(_shape(*sh), which, flags, precision))
+    return hit
+
+
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
                noise_w=None, noise_b=None, residual=None, res_scale=1.0, packed=None, w_shape=None, s2d_c=0,
-               noise_natural=False):
+               noise_natural=False, want_mask=False):
     """x: channels_last [B,C,H,W] in the precision's activation dtype; w: OIHW parameter.
-    Returns channels_last [B,N,Ho,Wo] of the same dtype."""
+    Returns channels_last [B,N,Ho,Wo] of the same dtype — with want_mask=True the pair (y, mask): mask = uint8
+    [B,Ho,Wo,N/8], one bit per element of y (y > 0), written by the same launch when the kernel that runs this shape can
+    (EPI_MASK_OUT), else None."""
     lib = _ensure_device(x)
     adt = act_dtype(precision)
     assert is_cl(x) and x.dtype == adt, (x.dtype, adt)
@@ -377,17 +396,24 @@ def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=No
         flags |= EPI_RESIDUAL
         epi.residual = residual.data_ptr()
         epi.res_scale = res_scale
+    mask = None
+    if want_mask and lrelu is True and conv_mask_supported(sh, 0, flags | EPI_MASK_OUT, precision):
+        mask = torch.empty((sh[0], sh[9], sh[10], sh[4] // 8), dtype=torch.uint8, device=x.device)
+        flags |= EPI_MASK_OUT
+        epi.mask = mask.data_ptr()
     shp = _shape(*sh)
     ws, ws_bytes = _split_workspace(lib, shp, 0, precision, x)
     _check(lib.stylex_conv2d_fwd(_ptr(x), _ptr(wf), _ptr(y), shp, flags, ctypes.byref(epi), precision, _ptr(ws),
                                  ws_bytes, _stream()), "stylex_conv2d_fwd")
-    return y
+    return (y, mask) if want_mask else y
 
 
 def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_scale=None, packed=None, w_shape=None,
-                    s2d_c=0, gate=None, gate_slope=0.2):
+                    s2d_c=0, gate=None, gate_slope=0.2, gate_mask=None):
     """`gate` (shape of dx, activation dtype): dx *= (gate > 0 ? 1 : gate_slope) in the kernel's store — the
-    LeakyReLU derivative of the layer that produced this conv's input (which IS the gate tensor)."""
+    LeakyReLU derivative of the layer that produced this conv's input (which IS the gate tensor).  `gate_mask`: the same
+    gate as the bit mask conv2d_fwd(want_mask=True) returned for that tensor (1/16 of its bytes); used when the launch
+    can read it (conv_mask_supported), otherwise `gate` must be given as well and is used."""
     lib = _ensure_device(dy)
     adt = act_dtype(precision)
     assert is_cl(dy) and dy.dtype == adt, (dy.dtype, adt)
@@ -404,11 +430,18 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     if out_scale is not None:
         flags |= EPI_OSCALE
         epi.out_scale = out_scale.data_ptr()
-    if gate is not None:
+    if gate_mask is not None and in_scale is None and out_scale is None and conv_mask_supported(sh, 1, EPI_GATE_MASK, precision):
+        assert gate_mask.dtype == torch.uint8 and gate_mask.numel() * 8 == sh[0] * sh[1] * sh[2] * sh[3]
+        flags |= EPI_GATE_MASK
+        epi.mask = gate_mask.data_ptr()
+        epi.res_scale = gate_slope
+    elif gate is not None:
         assert is_cl(gate) and tuple(gate.shape) == tuple(x_shape) and gate.dtype == adt
         flags |= EPI_GATE
         epi.residual = gate.data_ptr()
         epi.res_scale = gate_slope
+    else:
+        assert gate_mask is None, "this launch cannot read a gate mask and no gate tensor was given"
     shp = _shape(*sh)
     ws, ws_bytes = _split_workspace(lib, shp, 1, precision, dy)
     _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), shp, flags, ctypes.byref(epi), precision,
@@ -487,14 +520,25 @@ def blur3x3_s2d_fwd(x):
     return y
 
 
-def blur3x3_s2d_bwd(dy2, gate=None, slope=0.2):
-    """adjoint of blur3x3_s2d_fwd; with `gate` (the blur's forward input) the LeakyReLU derivative is fused in."""
+def blur_mask_ok(shape, dtype):
+    """Can blur3x3_s2d_bwd read the gate of a [B,C,H,W] tensor as a bit mask?  (the strip kernel's conditions)"""
+    _, c, h, w = shape
+    return dtype == torch.bfloat16 and c % 8 == 0 and h >= 8 and h % 2 == 0 and w % 2 == 0
+
+
+def blur3x3_s2d_bwd(dy2, gate=None, slope=0.2, gate_mask=None):
+    """adjoint of blur3x3_s2d_fwd; with `gate` (the blur's forward input) the LeakyReLU derivative is fused in;
+    `gate_mask`: that gate as the bit mask of conv2d_fwd(want_mask=True) (caller checks blur_mask_ok)."""
     lib = _ensure_device(dy2)
     assert is_cl(dy2)
     b, c4, h2, w2 = dy2.shape
     dx = empty_cl((b, c4 // 4, 2 * h2, 2 * w2), dy2)
     shp = _shape(b, 2 * h2, 2 * w2, c4 // 4)
-    if gate is None:
+    if gate_mask is not None:
+        assert gate_mask.dtype == torch.uint8 and gate_mask.numel() * 8 == dx.numel()
+        _check(lib.stylex_blur3x3_s2d_bwd_gate_mask(_ptr(dy2), _ptr(gate_mask), float(slope), _ptr(dx), shp, _adt(dy2),
+                                                    _stream()), "stylex_blur3x3_s2d_bwd_gate_mask")
+    elif gate is None:
         _check(lib.stylex_blur3x3_s2d_bwd(_ptr(dy2), _ptr(dx), shp, _adt(dy2), _stream()), "stylex_blur3x3_s2d_bwd")
     else:
         assert is_cl(gate) and gate.shape == dx.shape and gate.dtype == dy2.dtype

@@ -631,8 +631,23 @@ class _DBlockFast(torch.autograd.Function):
                 xs = hb.subsample2_fwd(x) if downsample else x
                 res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
             x.record_stream(side)
-        y1 = hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True)
-        y2 = hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True)
+        # Activation bit masks: the backward needs y2 ONLY for its sign (the LeakyReLU derivative fused into the blur
+        # adjoint) and y1 for its sign plus as the weight-gradient operand; where the forward kernel can write the sign
+        # bits alongside (1/16 of the bytes) the gated backward passes read those instead of the tensors, and y2 is not
+        # kept for the backward at all.  STYLEX_GATE_MASK=0: gate on the tensors.
+        n2, h2, wd2 = w2.shape[0], x.shape[2], x.shape[3]
+        s2d_next = bool(downsample) and (_PRECISION != hb.F32 and n2 % 64 == 0 and h2 % 2 == 0 and wd2 % 2 == 0
+                                         and wd2 // 2 >= 16 and h2 // 2 >= 16)
+        # (measured per launch at B=64, tools/bench_masks.py: gated data gradient 64->64 @256^2 .534 -> .445 ms, gated blur
+        # adjoint .323 -> .273, 128 @128^2 .356 -> .327 / .159 -> .141; writing the mask costs the forward 0 - .012 ms;
+        # at 64^2 and below the saving no longer covers that, so the masks are used from 128^2 up)
+        use_m = (_PRECISION == hb.BF16_ACT and os.environ.get("STYLEX_GATE_MASK", "1") != "0"
+                 and h2 * wd2 >= int(os.environ.get("STYLEX_GATE_MASK_MIN_PIXELS", 128 * 128)))
+        y1, m1 = hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True, want_mask=True) if use_m else (
+            hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True), None)
+        want_m2 = use_m and s2d_next and hb.blur_mask_ok((x.shape[0], n2, h2, wd2), x.dtype)
+        y2, m2 = hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True, want_mask=True) if want_m2 else (
+            hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True), None)
         s2d, xb = False, None
         def join():
             if side is not None:
@@ -656,14 +671,16 @@ class _DBlockFast(torch.autograd.Function):
         else:
             join()
             out = (y2 + res) * c
-        ctx.save_for_backward(x, xs if downsample else None, y1, y2, xb, w_res, w1, w2, w3)
+        assert m2 is None or s2d
+        ctx.save_for_backward(x, xs if downsample else None, y1, y2 if m2 is None else None, xb, w_res, w1, w2, w3, m1, m2)
+        ctx.y2_shape = tuple(y2.shape)
         ctx.cfg = (bool(downsample), s2d, cin, c)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out):
-        x, xs, y1, y2, xb, w_res, w1, w2, w3 = ctx.saved_tensors
+        x, xs, y1, y2, xb, w_res, w1, w2, w3, m1, m2 = ctx.saved_tensors
         downsample, s2d, cin, c = ctx.cfg
         if xs is None:
             xs = x
@@ -713,7 +730,7 @@ class _DBlockFast(torch.autograd.Function):
             xs.record_stream(side_bwd)
         if downsample:
             gb3 = gsum3
-            n = y2.shape[1]
+            n = ctx.y2_shape[1]
             if s2d:
                 _, wb2 = hb.pack_weight_s2d(w3, scale=c if alg else None)
                 gxb = hb.conv2d_bwd_data(gz3, None, tuple(xb.shape), 1, 1, prec, packed=wb2, w_shape=(w3.shape[0], 4 * n, 3, 3),
@@ -721,7 +738,7 @@ class _DBlockFast(torch.autograd.Function):
                 if want_w:
                     gw3 = hb.fold_weight_grad_s2d(hb.conv2d_bwd_weight(xb, gz3, (w3.shape[0], 4 * n, 3, 3), 1, 1, prec, s2d_c=n),
                                                   tuple(w3.shape))
-                gz2 = hb.blur3x3_s2d_bwd(gxb, gate=y2)  # blur adjoint + LeakyReLU derivative of y2 in one pass
+                gz2 = hb.blur3x3_s2d_bwd(gxb, gate=y2, gate_mask=m2)  # blur adjoint + LeakyReLU derivative of y2, one pass
             else:
                 wb3 = hb.pack_weight(w3, False, True, prec, scale=c)[1] if alg else None
                 gxb = hb.conv2d_bwd_data(gz3, w3, tuple(xb.shape), 2, 1, prec, packed=wb3, w_shape=tuple(w3.shape))
@@ -736,7 +753,7 @@ class _DBlockFast(torch.autograd.Function):
             gb2 = _channel_sum(gz2)
         if want_w:
             gw2 = hb.conv2d_bwd_weight(y1, gz2, tuple(w2.shape), 1, 1, prec)
-        gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1)  # + LeakyReLU derivative of y1
+        gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1, gate_mask=m1)  # + LeakyReLU derivative of y1
         if want_b:
             gb1 = _channel_sum(gz1)
         gxs = None

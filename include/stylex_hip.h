@@ -57,6 +57,11 @@ extern "C" {
 #define STYLEX_EPI_NOISE_NAT 128 /* with STYLEX_EPI_NOISE: the noise plane is in NATURAL order, value used at (h,w) is
                                  * noise[b][h][w] (the caller transposed the reference's plane once per generator
                                  * forward): the epilogue then reads 4 consecutive pixels with one 16-byte load */
+#define STYLEX_EPI_MASK_OUT 256 /* fwd, with STYLEX_EPI_LRELU: also write epi->mask, one bit per stored output element
+                                 * ([B][Ho][Wo][N/8] bytes; bit k of byte q of a pixel = (y[8q+k] > 0)) — everything a
+                                 * later STYLEX_EPI_GATE_MASK / stylex_blur3x3_s2d_bwd_gate_mask needs of y, at 1/16 of its
+                                 * bytes.  Only some kernels write it: ask stylex_conv_mask_supported() first.          */
+#define STYLEX_EPI_GATE_MASK 512 /* bwd_data: as STYLEX_EPI_GATE with the gate given as such a bit mask in epi->mask       */
 #define STYLEX_EPI_GATE 64     /* bwd_data only: dx *= (gate[m][c] > 0 ? 1 : res_scale) — the derivative of the
                                 * (Leaky)ReLU that produced this conv's input, applied while dx is written; the gate
                                 * tensor (= that input, [B][Hi][Wi][C], activation dtype) travels in epi->residual */
@@ -96,7 +101,13 @@ typedef struct {
     int32_t s2d_c;          /* >0: space-to-depth form of a 3x3/stride-2/pad-1 conv (see stylex_blur3x3_s2d_fwd):
                              * `shape` describes the 3x3/s1/p1 conv over 4*s2d_c channels, the weights come from
                              * stylex_pack_weight_s2d, structurally-zero taps are skipped.  s2d_c % 64 == 0. */
+    void* mask;             /* STYLEX_EPI_MASK_OUT: written; STYLEX_EPI_GATE_MASK: read (see the flags)          */
 } stylex_conv_epilogue;
+
+/* 1 when a launch with this shape / flags / precision (16-byte aligned tensors) runs on a kernel that writes
+ * (which = 0: stylex_conv2d_fwd with STYLEX_EPI_MASK_OUT) or reads (which = 1: stylex_conv2d_bwd_data with
+ * STYLEX_EPI_GATE_MASK) the activation bit mask; 0 otherwise — such a launch is then rejected with STYLEX_EINVAL. */
+int stylex_conv_mask_supported(const int64_t* shape, int which, int flags, int precision);
 
 /* Optional split-K workspace for launches that cannot fill the chip (few output tiles, long K):
  * query with stylex_conv2d_workspace_bytes(shape, which, precision) (which: 0 = fwd, 1 = bwd_data;
@@ -172,6 +183,10 @@ int stylex_blur3x3_reflect_bwd_gate(const void* dy, const void* gate, float slop
                                     int act_dtype, void* stream);
 int stylex_blur3x3_s2d_bwd_gate(const void* dy_s2d, const void* gate, float slope, void* dx, const int64_t* shape,
                                 int act_dtype, void* stream);
+/* The same with the gate given as the bit mask a forward conv wrote (STYLEX_EPI_MASK_OUT: [B][H][W][C/8] bytes): the
+ * pass then reads 1/16 of the gate tensor's bytes.  bf16 activations, C % 8 == 0, H >= 8 (STYLEX_EINVAL otherwise). */
+int stylex_blur3x3_s2d_bwd_gate_mask(const void* dy_s2d, const void* mask, float slope, void* dx, const int64_t* shape,
+                                     int act_dtype, void* stream);
 /* dst[b,2i,2j,:] += src[b,i,j,:] in place; shape = the FULL-resolution {B,H,W,C} of dst.  Sum of the two input
  * gradients of a DiscriminatorBlock (3x3 path + zero-inserted gradient of the 1x1/stride-2 conv_res path,
  * reference stylex_train.py:739-743) without the zero-inserted tensor. */

@@ -932,6 +932,81 @@ def test_small_spatial_gather_kernel(case):
     close(want_dx, got[1].double(), 1e-2, "dgrad vs fp64 definition")
 
 
+@pytest.mark.parametrize("case", [(3, 64, 64, 32, 64), (2, 128, 64, 48, 80), (2, 8, 64, 40, 64), (1, 256, 128, 16, 32)])
+def test_activation_bit_mask_paths_are_bit_identical(case):
+    """STYLEX_EPI_MASK_OUT / STYLEX_EPI_GATE_MASK / stylex_blur3x3_s2d_bwd_gate_mask: the forward conv writes one bit per
+    stored element (y > 0) next to y; the gated data gradient and the gated blur adjoint read those bits instead of the
+    gate tensor.  Same arithmetic, so everything must agree BIT FOR BIT with the tensor-gated launches; the mask itself
+    is checked against the definition.  Shapes: LDS-DMA kernel (ragged tiles included) and the RGB first-layer kernel
+    (C = 8); a shape no mask-capable kernel serves must return None / fall back."""
+    B, C, N, H, W = case
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(81)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x = mk(B, C, H, W)
+    if C == 8:
+        x[:, 3:] = 0
+    w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    y_ref = hb.conv2d_fwd(x, w, 1, 1, P, bias=bias, lrelu=True)
+    y, mask = hb.conv2d_fwd(x, w, 1, 1, P, bias=bias, lrelu=True, want_mask=True)
+    assert mask is not None and mask.shape == (B, H, W, N // 8)
+    assert torch.equal(y, y_ref)
+    bits = (y.permute(0, 2, 3, 1).float() > 0).reshape(B, H, W, N // 8, 8).to(torch.int32)
+    want = (bits << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(mask, want)
+    if C >= 64:  # the data gradient of a conv whose INPUT is y (gate = y): N -> N2 channels, reads the mask of y
+        N2 = 64
+        w2 = torch.randn(N2, N, 3, 3, device=DEV, generator=g) / (9 * N) ** 0.5
+        dy = mk(B, N2, H, W)
+        a = hb.conv2d_bwd_data(dy, w2, (B, N, H, W), 1, 1, P, gate=y)
+        b_ = hb.conv2d_bwd_data(dy, w2, (B, N, H, W), 1, 1, P, gate=y, gate_mask=mask)
+        assert hb.conv_mask_supported(hb.conv_shape((B, N, H, W), w2.shape, 1, 1), 1, hb.EPI_GATE_MASK, P)
+        assert torch.equal(a, b_)
+    if H % 2 == 0 and W % 2 == 0 and H >= 8:  # gated adjoint of the space-to-depth blur
+        dy2 = hb.blur3x3_s2d_fwd(mk(B, N, H, W))
+        assert hb.blur_mask_ok((B, N, H, W), torch.bfloat16)
+        assert torch.equal(hb.blur3x3_s2d_bwd(dy2, gate=y), hb.blur3x3_s2d_bwd(dy2, gate_mask=mask))
+    # a launch no mask-capable kernel serves: no mask, plain result
+    xs, ws_ = mk(2, 64, 8, 8), torch.randn(64, 64, 3, 3, device=DEV, generator=g) / 24
+    ys, ms = hb.conv2d_fwd(xs, ws_, 1, 1, P, lrelu=True, want_mask=True)
+    assert ms is None and torch.equal(ys, hb.conv2d_fwd(xs, ws_, 1, 1, P, lrelu=True))
+
+
+def test_fused_dblock_with_and_without_bit_masks():
+    """The fused DiscriminatorBlock with the activation bit masks (default) and with STYLEX_GATE_MASK=0 (gates read from
+    the activation tensors): output and every gradient bit-identical, at sizes where both masks are in use (RGB first
+    block and a 64 -> 128 block on the LDS-DMA kernel)."""
+    import os
+
+    ops.set_precision("bf16")
+    os.environ["STYLEX_GATE_MASK_MIN_PIXELS"] = "0"  # the product switches the masks on from 128^2 up
+    for cin, cout, size in ((3, 64, 64), (64, 128, 64)):
+        torch.manual_seed(21)
+        blk = st.DiscriminatorBlock(cin, cout, downsample=True).to(DEV)
+        x = torch.randn(3, cin, size, size, device=DEV, generator=torch.Generator(device=DEV).manual_seed(22))
+        res = []
+        for masks in ("1", "0"):
+            os.environ["STYLEX_GATE_MASK"] = masks
+            try:
+                blk.zero_grad()
+                xr = x.clone().requires_grad_()
+                prev = ops.set_fast(True)
+                try:
+                    y = blk(xr)
+                    r = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(23)).to(y.dtype)
+                    (y.float() * r.float()).sum().backward()
+                finally:
+                    ops.set_fast(prev)
+            finally:
+                os.environ.pop("STYLEX_GATE_MASK", None)
+            res.append([y.detach(), xr.grad] + [p.grad.clone() for p in blk.parameters()])
+        for a, b_ in zip(*res):
+            assert torch.equal(a, b_)
+    os.environ.pop("STYLEX_GATE_MASK_MIN_PIXELS", None)
+
+
 @pytest.mark.parametrize("shape", [(3, 4, 4, 4), (2, 4, 8, 16), (2, 3, 5, 7), (1, 8, 1, 1), (2, 4, 64, 64)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_rgb_up_blur_add_kernel(shape, prec):
