@@ -415,6 +415,14 @@ __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short
         int ih;
         float ch;
         F8 win[3];
+        // gate bits of the strip's rows, fetched up front (addresses are known; a load issued in the row loop right
+        // before its use would expose its latency ROWS times)
+        unsigned gm[ROWS];
+        if (ADJ && gmask) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                gm[r] = (h0 + r < H) ? gmask[((((long)b * H + h0 + r) * W + w) * C + c) >> 3] : 0u;
+        }
         blur_tap<ADJ>(h0, -1, H, ih, ch);
         win[0] = hrow(ih);
         win[1] = hrow(h0);
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256) void blur3x3_strip_kernel(const unsigned short
             } else if (ADJ && gmask) {  // the gate as one bit per element (STYLEX_EPI_MASK_OUT of the forward conv)
                 float a[8];
                 *reinterpret_cast<F8*>(a) = acc;
-                const unsigned m = gmask[o >> 3];
+                const unsigned m = gm[r];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] = ((m >> e) & 1u) ? a[e] : gslope * a[e];
                 acc = *reinterpret_cast<F8*>(a);
