@@ -285,14 +285,20 @@ struct GeomDma {
     static constexpr int SMEM_BYTES = 2 * BUF;            // 152.5 KiB: one block per CU
 };
 
-template <bool S2D>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKParams p) {
+// WAVES = 8 (plain layers): two wave quartets share the staged tiles and split the 9 taps (0-4 / 5-8), i.e. TWO waves
+// per SIMD.  With one wave per SIMD the transpose reads (ds_read_b64_tr_b16, 10 per MFMA group) ran far below the LDS
+// rate — 8-byte LDS reads need several waves per SIMD in flight — and each wave's MFMAs waited for its own reads: per
+// tile 4608 MFMA cycles + ~4750 cycles of DMA + the read stalls came to ~10300 cycles, fully serialised.
+template <bool S2D, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKParams p) {
     constexpr int TW = 32, TH = 8, HWD = 34, NP = 340;
     constexpr int DY_PANEL = GeomDma::DY_PANEL, X_PANEL = GeomDma::X_PANEL, X_OFF = GeomDma::X_OFF, BUF = GeomDma::BUF;
     static_assert(DY_PANEL == Geom<32>::DY_PANEL, "compute_tile addresses the dy panels with Geom<32>'s pitch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(WAVES == 4 || (WAVES == 8 && !S2D), "the tap split is for the plain 9-tap layers");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wc = wave & 1;
+    const int wn = (wave & 3) >> 1, wc = wave & 1;
+    const int tg = wave >> 2;  // tap group of this wave (WAVES == 8): 0 -> taps 0..4, 1 -> taps 5..8
     const int H = p.Ho, W = p.Wo, C = p.Ck, N = p.N;
     const int n_tiles = (N + 63) / 64, c_tiles = (C + 63) / 64;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKPar
         const int y0 = (tt / tiles_x) * TH, x0 = (tt % tiles_x) * TW;
         char* base = smem + buf * BUF;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {  // dy: 2 panels x 16 pieces of 16 pixels
-            const int ch = wave + 4 * it, panel = ch >> 4, piece = ch & 15;
+        for (int it = 0; it < 32 / WAVES; ++it) {  // dy: 2 panels x 16 pieces of 16 pixels
+            const int ch = wave + WAVES * it, panel = ch >> 4, piece = ch & 15;
             const int px = piece * 16 + lp;
             const int y = y0 + (px >> 5), x = x0 + (px & 31);
             const int nn = n0 + panel * 32 + slot * 8;
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKPar
                                              16, 0, 0);
         }
 #pragma unroll
-        for (int it = 0; it < 11; ++it) {  // x halo: 2 panels x 22 pieces
-            const int ch = wave + 4 * it;
+        for (int it = 0; it < (44 + WAVES - 1) / WAVES; ++it) {  // x halo: 2 panels x 22 pieces
+            const int ch = wave + WAVES * it;
             if (ch < 44) {
                 const int panel = ch >= 22 ? 1 : 0, piece = ch - panel * 22;
                 const int hp = piece * 16 + lp;
@@ -363,7 +369,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKPar
         if (tile + 1 < t_end) issue(tile + 1, buf ^ 1);
         const char* a_base = smem + buf * BUF + wn * DY_PANEL + lane_off;
         const char* b_base = smem + buf * BUF + X_OFF + wc * X_PANEL + lane_off;
-        if (!S2D) compute_tile<TW, 0x1ffu>(acc, a_base, b_base);
+        if (WAVES == 8) {
+            if (tg == 0) compute_tile<TW, 0x01fu>(acc, a_base, b_base);
+            else compute_tile<TW, 0x1e0u>(acc, a_base, b_base);
+        } else if (!S2D) compute_tile<TW, 0x1ffu>(acc, a_base, b_base);
         else if (tapmask == 0x010u) compute_tile<TW, 0x010u>(acc, a_base, b_base);
         else if (tapmask == 0x018u) compute_tile<TW, 0x018u>(acc, a_base, b_base);
         else if (tapmask == 0x012u) compute_tile<TW, 0x012u>(acc, a_base, b_base);
@@ -377,12 +386,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_dma_kernel(ConvKPar
         // modulated layer: the whole split lies in sample t_begin / tiles_img (plan), its x scale is a factor of the sum
         const float xsc = (p.a_scale && t_begin < t_end) ? p.a_scale[(long)(t_begin / tiles_img) * C + c] : 1.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t) {
+            if (WAVES == 8 && (t < 5) != (tg == 0)) continue;  // the other quartet's taps
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (n < N) out[((long)n * 9 + t) * C + c] = acc[t][r] * xsc;
             }
+        }
     }
 }
 
@@ -471,15 +482,18 @@ int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* 
     int blocks = ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * splits;
     *splits_out = splits;
     if (wgrad_dma_eligible(p)) {
-        auto k = p.s2d_c ? conv3x3_wgrad_halo_dma_kernel<true> : conv3x3_wgrad_halo_dma_kernel<false>;
-        static bool attr_done[2] = {false, false};
-        if (!attr_done[p.s2d_c ? 1 : 0]) {
+        static const bool w8 = !(getenv("STYLEX_WGRAD_DMA_W8") && getenv("STYLEX_WGRAD_DMA_W8")[0] == '0');
+        const int v = p.s2d_c ? 1 : (w8 ? 2 : 0);
+        auto k = v == 1 ? conv3x3_wgrad_halo_dma_kernel<true, 4> : v == 2 ? conv3x3_wgrad_halo_dma_kernel<false, 8>
+                                                                          : conv3x3_wgrad_halo_dma_kernel<false, 4>;
+        static bool attr_done[3] = {false, false, false};
+        if (!attr_done[v]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                GeomDma::SMEM_BYTES);
             if (e != hipSuccess) return (int)e;
-            attr_done[p.s2d_c ? 1 : 0] = true;
+            attr_done[v] = true;
         }
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), GeomDma::SMEM_BYTES, s, p);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(v == 2 ? 512 : 256), GeomDma::SMEM_BYTES, s, p);
         return (int)hipGetLastError();
     }
     const bool abf = p.act_bf16 && p.Ck % 8 == 0 && p.N % 8 == 0;
