@@ -1136,12 +1136,31 @@ void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long
     *split_len = len;
 }
 
-int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s) {
+// db[n] = sum over the splits (fixed order) of the per-split pixel sums of dy the LDS-DMA weight-gradient kernel left
+__global__ void bias_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int splits) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += part[(long)s * N + n];
+    db[n] = v;
+}
+
+int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s, float* db, int* db_done) {
+    if (db_done) *db_done = 0;
     if (precision == STYLEX_BF16 && stylex_wgrad_halo_applicable(p)) {
-        int hs = 0;
-        int rc = stylex_launch_wgrad_halo(p, partial, s, &hs);
+        int hs = 0, bias_done = 0;
+        if (db) {  // the bias partials live behind the weight-gradient partials of this plan
+            int ps, tps;
+            stylex_wgrad_halo_plan(p, &ps, &tps);
+            p.bias_partial = partial + (long)ps * p.N * 9 * p.Ck;
+        }
+        int rc = stylex_launch_wgrad_halo(p, partial, s, &hs, &bias_done);
         if (rc) return rc;
         launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s);
+        if (db && bias_done) {
+            hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3((p.N + 255) / 256), dim3(256), 0, s, p.bias_partial, db, p.N, hs);
+            if (db_done) *db_done = 1;
+        }
         return (int)hipGetLastError();
     }
     if (precision == STYLEX_BF16 && stylex_wgrad_tr_applicable(p)) {

@@ -63,13 +63,18 @@ struct Geom {
     static constexpr int SMEM_BYTES = 2 * DY_PANEL + 2 * X_PANEL;  // ~75 KiB -> 2 blocks / CU
 };
 
-template <int TW, unsigned MASK>
+// BIAS (MASK must not contain tap 0): acc[0] += dy x ONES, i.e. every column of acc[0] = sum over the tile's pixels of
+// dy[., n] — the bias gradient, for the price of one MFMA per k-step and no extra pass over dy.
+template <int TW, unsigned MASK, bool BIAS = false>
 __device__ __forceinline__ void compute_tile(f32x16 (&acc)[9], const char* a_base, const char* b_base) {
     constexpr int HWD = Geom<TW>::HWD, KS_PER_ROW = TW / 16;
+    static_assert(!BIAS || !(MASK & 1u), "the bias sum lives in the accumulator of tap 0");
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         const int r = ks / KS_PER_ROW, pw0 = (ks % KS_PER_ROW) * 16;
         bf16x8 av = tr_read8(a_base, (r * TW + pw0) * PIX_ROW, PIX_ROW);
+        if (BIAS) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, ones, acc[0], 0, 0, 0);
         bf16x8 bv[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -323,6 +328,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_wgrad_halo_dma_kernel(C
     const unsigned tapmask = S2D ? stylex_s2d_tap_mask((c0 + wc * 32) / p.s2d_c) : 0x1ffu;
     const int i16 = lane & 15, g = lane >> 4;
     const int lane_off = ((g >> 1) * 8 + (i16 >> 2)) * PIX_ROW + ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+    // bias gradient: the 4-tap quartet of the blocks of channel tile 0 (one of its two column waves) carries it
+    const bool do_bias = WAVES == 8 && p.bias_partial != nullptr && tg == 1 && c0 == 0 && wc == 0;
 
     const unsigned short* dy = reinterpret_cast<const unsigned short*>(p.a2);
     const unsigned short* xs = reinterpret_cast<const unsigned short*>(p.a);
@@ -371,6 +378,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_wgrad_halo_dma_kernel(C
         const char* b_base = smem + buf * BUF + X_OFF + wc * X_PANEL + lane_off;
         if (WAVES == 8) {
             if (tg == 0) compute_tile<TW, 0x01fu>(acc, a_base, b_base);
+            else if (do_bias) compute_tile<TW, 0x1e0u, true>(acc, a_base, b_base);
             else compute_tile<TW, 0x1e0u>(acc, a_base, b_base);
         } else if (!S2D) compute_tile<TW, 0x1ffu>(acc, a_base, b_base);
         else if (tapmask == 0x010u) compute_tile<TW, 0x010u>(acc, a_base, b_base);
@@ -382,6 +390,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_wgrad_halo_dma_kernel(C
     const int lj = lane & 31, lh = lane >> 5;
     float* out = p.y + (long)split * N * 9 * C;
     const int c = c0 + wc * 32 + lj;
+    if (do_bias && lj == 0) {  // every column of acc[0] holds the same sums: column 0 writes them
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n < N) p.bias_partial[(long)split * N + n] = acc[0][r];
+        }
+    }
     if (c < C) {
         // modulated layer: the whole split lies in sample t_begin / tiles_img (plan), its x scale is a factor of the sum
         const float xsc = (p.a_scale && t_begin < t_end) ? p.a_scale[(long)(t_begin / tiles_img) * C + c] : 1.f;
@@ -474,16 +489,19 @@ static int launch_wgrad_halo(const ConvKParams& p, int blocks, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out) {
+int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out, int* bias_done) {
     int splits, tps;
     stylex_wgrad_halo_plan(p, &splits, &tps);
     p.split_len = tps;
     p.y = partial;
+    if (bias_done) *bias_done = 0;
     int blocks = ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * splits;
     *splits_out = splits;
     if (wgrad_dma_eligible(p)) {
         static const bool w8 = !(getenv("STYLEX_WGRAD_DMA_W8") && getenv("STYLEX_WGRAD_DMA_W8")[0] == '0');
         const int v = p.s2d_c ? 1 : (w8 ? 2 : 0);
+        if (v != 2) p.bias_partial = nullptr;
+        else if (p.bias_partial && bias_done) *bias_done = 1;
         auto k = v == 1 ? conv3x3_wgrad_halo_dma_kernel<true, 4> : v == 2 ? conv3x3_wgrad_halo_dma_kernel<false, 8>
                                                                           : conv3x3_wgrad_halo_dma_kernel<false, 4>;
         static bool attr_done[3] = {false, false, false};

@@ -378,12 +378,22 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
         stylex_wgrad_tr_plan(p, &mode, &ts, &tl);
         if (ts > splits) splits = ts;
     }
-    return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float);
+    // + room for the per-split bias sums of stylex_conv2d_bwd_weight_bias
+    return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float) + (int64_t)splits * p.N * (int64_t)sizeof(float);
 }
 
 int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
                              const int64_t* sh, const float* x_scale, const float* dy_scale, int s2d_c, int precision,
                              void* stream) {
+    return stylex_conv2d_bwd_weight_bias(x, dy, dw, nullptr, nullptr, workspace, workspace_bytes, sh, x_scale, dy_scale, s2d_c,
+                                         precision, stream);
+}
+
+int stylex_conv2d_bwd_weight_bias(const void* x, const void* dy, float* dw, float* db, int* db_written, void* workspace,
+                                  int64_t workspace_bytes, const int64_t* sh, const float* x_scale, const float* dy_scale,
+                                  int s2d_c, int precision, void* stream) {
+    if (db_written) *db_written = 0;
+    if (db && !db_written) return STYLEX_EINVAL;
     if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh)) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
     if (workspace_bytes < stylex_conv2d_bwd_weight_workspace_bytes(sh)) return STYLEX_EWORKSPACE;
@@ -399,7 +409,7 @@ int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* wor
     if (s2d_c && (p.Ck != 4 * s2d_c || s2d_c % 64 || p.KH != 3 || p.stride != 1)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (s2d_c ? 4.0 : 1.0);
     ScopedTimer tm(2, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, true), (hipStream_t)stream, sh, s2d_c);
-    return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream);
+    return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream, db, db_written);
 }
 
 int stylex_pack_weight_s2d(const float* w, void* wf, void* wb, const int64_t* sh, void* stream) {

@@ -39,12 +39,15 @@ struct ConvKParams {
     unsigned char* mask;            // STYLEX_EPI_MASK_OUT: sign bits of the stored output, [M][N/8] bytes
     const unsigned char* gate_mask; // STYLEX_EPI_GATE_MASK: the activation gate of a data gradient as such a mask
     int dry;                        // launchers: run the applicability checks only, launch nothing (mask-support query)
+    float* bias_partial;            // wgrad: [splits][N] per-split sums of dy over the pixels (bias gradient), or null
 };
 
 int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s);
 int64_t stylex_igemm_workspace_bytes(const ConvKParams& p, int precision);
 void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long* split_len);
-int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s);
+// db != null: also produce db[n] = sum over pixels of dy[., n] when the selected kernel can (then *db_done = 1)
+int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s, float* db = nullptr,
+                        int* db_done = nullptr);
 int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, int dtype, hipStream_t s);
 
 #define STYLEX_NOT_APPLICABLE (-100)
@@ -82,7 +85,7 @@ int64_t stylex_gather_workspace_bytes(const ConvKParams& p);
 // 3x3/s1/p1 bf16 weight gradient with resident halo + LDS transpose reads (conv_wgrad_halo.hip)
 bool stylex_wgrad_halo_applicable(const ConvKParams& p);
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);
-int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out);
+int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out, int* bias_done = nullptr);
 
 // general bf16 weight gradient with LDS transpose reads (conv_wgrad_tr.hip)
 bool stylex_wgrad_tr_applicable(const ConvKParams& p);

@@ -51,6 +51,9 @@ SIGNATURES = {
     "stylex_conv2d_bwd_weight_workspace_bytes": (ctypes.c_int64, [_i64p]),
     "stylex_conv2d_bwd_weight": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p, _c_f, _c_f,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_conv2d_bwd_weight_bias": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                                                     ctypes.c_int64, _i64p, _c_f, _c_f, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_void_p]),
     "stylex_blur3x3_s2d_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_reflect_bwd_gate": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -449,7 +452,10 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     return dx
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None, s2d_c=0):
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None, s2d_c=0, want_bias_sum=False):
+    """Weight gradient (OIHW fp32).  want_bias_sum=True returns the pair (dw, db): db = dy summed over (b, h, w) in fp32
+    — the bias gradient — when the kernel serving this shape produces it from the dy tiles it stages anyway
+    (stylex_conv2d_bwd_weight_bias), else None (the caller reduces dy itself)."""
     lib = _ensure_device(x)
     adt = act_dtype(precision)
     assert is_cl(x) and is_cl(dy) and x.dtype == adt and dy.dtype == adt, (x.dtype, dy.dtype, adt)
@@ -461,6 +467,13 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
     ws = _empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
     dw = _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     x_scale, dy_scale = _f32(x_scale), _f32(dy_scale)
+    if want_bias_sum:
+        db = _empty(w_shape[0], dtype=torch.float32, device=x.device)
+        written = ctypes.c_int(0)
+        _check(lib.stylex_conv2d_bwd_weight_bias(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), ctypes.byref(written), _ptr(ws), nbytes,
+                                                 shp, _ptr(x_scale), _ptr(dy_scale), int(s2d_c), precision, _stream()),
+               "stylex_conv2d_bwd_weight_bias")
+        return dw, (db if written.value else None)
     _check(lib.stylex_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, _ptr(x_scale),
                                         _ptr(dy_scale), int(s2d_c), precision, _stream()), "stylex_conv2d_bwd_weight")
     return dw

@@ -749,16 +749,23 @@ class _DBlockFast(torch.autograd.Function):
                 gw3 = gw3 * wsc
         else:
             gz2 = hb.bias_act_bwd(gz3, y2)
-        if want_b:
-            gb2 = _channel_sum(gz2)
+        # bias gradients = per-channel sums of gz2 / gz1: taken from the weight-gradient kernel (which stages those
+        # tensors anyway) where it can, else a read-only reduction pass
+        fuse_b = want_b and want_w and os.environ.get("STYLEX_WGRAD_BIAS", "1") != "0"
         if want_w:
-            gw2 = hb.conv2d_bwd_weight(y1, gz2, tuple(w2.shape), 1, 1, prec)
+            gw2 = hb.conv2d_bwd_weight(y1, gz2, tuple(w2.shape), 1, 1, prec, want_bias_sum=fuse_b)
+            if fuse_b:
+                gw2, gb2 = gw2
+        if want_b and gb2 is None:
+            gb2 = _channel_sum(gz2)
         gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1, gate_mask=m1)  # + LeakyReLU derivative of y1
-        if want_b:
-            gb1 = _channel_sum(gz1)
         gxs = None
         if want_w:
-            gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec)
+            gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec, want_bias_sum=fuse_b)
+            if fuse_b:
+                gw1, gb1 = gw1
+        if want_b and gb1 is None:
+            gb1 = _channel_sum(gz1)
         if want_x:
             gx = hb.conv2d_bwd_data(gz1, w1p, tuple(x.shape), 1, 1, prec)
         if side_bwd is not None:  # join: the residual-path gradients were issued on the companion stream above

@@ -141,6 +141,13 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* shape);
 int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
                              const int64_t* shape, const float* x_scale, const float* dy_scale, int s2d_c,
                              int precision, void* stream);
+/* As stylex_conv2d_bwd_weight; additionally db[n] = sum over (b, ho, wo) of dy[., n] — the bias gradient of the same
+ * layer (reference: the bias half of aten::convolution_backward) — when the kernel that serves the shape can produce it
+ * from the dy tiles it has staged anyway (one extra MFMA per k-step against a vector of ones; today the LDS-DMA kernel):
+ * *db_written = 1 then, else 0 and db is untouched (the caller reduces dy itself). */
+int stylex_conv2d_bwd_weight_bias(const void* x, const void* dy, float* dw, float* db, int* db_written, void* workspace,
+                                  int64_t workspace_bytes, const int64_t* shape, const float* x_scale,
+                                  const float* dy_scale, int s2d_c, int precision, void* stream);
 
 /* Elementwise / resampling entry points take `act_dtype`: 0 = fp32 activations, 1 = bf16 activations
  * (the storage type of STYLEX_BF16_ACT); arithmetic is fp32 either way.

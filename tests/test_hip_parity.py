@@ -974,6 +974,28 @@ def test_activation_bit_mask_paths_are_bit_identical(case):
     assert ms is None and torch.equal(ys, hb.conv2d_fwd(xs, ws_, 1, 1, P, lrelu=True))
 
 
+@pytest.mark.parametrize("case", [(4, 64, 64, 64, 64), (3, 128, 64, 48, 80), (2, 64, 256, 32, 32), (33, 64, 64, 32, 32)])
+def test_bias_gradient_from_the_weight_gradient_kernel(case):
+    """stylex_conv2d_bwd_weight_bias: the LDS-DMA weight-gradient kernel also returns db[n] = sum of dy over (b, h, w)
+    (one MFMA per k-step against a vector of ones, per-split partials reduced in fixed order): against the fp64 sum of
+    the bf16 gradient, with ragged tiles, several output-channel tiles and many splits; dw unchanged by the option.
+    A shape another kernel serves reports None."""
+    B, C, N, H, W = case
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(91)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, dy = mk(B, C, H, W), mk(B, N, H, W)
+    dw0 = hb.conv2d_bwd_weight(x, dy, (N, C, 3, 3), 1, 1, P)
+    dw, db = hb.conv2d_bwd_weight(x, dy, (N, C, 3, 3), 1, 1, P, want_bias_sum=True)
+    assert torch.equal(dw, dw0)
+    assert db is not None and db.shape == (N,)
+    close(dy.double().sum(dim=(0, 2, 3)), db, 2e-5, "bias gradient")
+    xs, dys = mk(2, 64, 8, 8), mk(2, 64, 8, 8)
+    dws, dbs = hb.conv2d_bwd_weight(xs, dys, (64, 64, 3, 3), 1, 1, P, want_bias_sum=True)
+    assert dbs is None and torch.equal(dws, hb.conv2d_bwd_weight(xs, dys, (64, 64, 3, 3), 1, 1, P))
+
+
 def test_fused_dblock_with_and_without_bit_masks():
     """The fused DiscriminatorBlock with the activation bit masks (default) and with STYLEX_GATE_MASK=0 (gates read from
     the activation tensors): output and every gradient bit-identical, at sizes where both masks are in use (RGB first
