@@ -327,9 +327,26 @@ def main():
             "step_conv_tflops": round(gf * value / 1e3, 2),
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+    else:
+        line = None
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (seen after the line when
+    # stdout is a pipe) — tear the process group down and flush C stdio first
+    def flush_c_stdio():
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+
     if dist.is_initialized():
+        flush_c_stdio()
+        if world > 1:
+            dist.barrier()  # every rank has flushed before rank 0 prints
         dist.destroy_process_group()
+    flush_c_stdio()
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
