@@ -428,6 +428,10 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
     // resident block hides more than the wider tile saves in LDS reads, so the 64-channel variant is the default and
     // the 128-channel one serves output widths that are not a multiple of 64.
     if (on64 && p.Ck >= 64 && p.N % 64 == 0) return p.dry ? 0 : launch_dma<2>(p, s);
+    // narrow outputs (the data gradient of the first conv of D / the encoder: 64 -> 8 padded RGB channels): one
+    // 32-channel output sub-tile per wave; HBM-side (the input is 16x the output), the generic kernel ran it at 56 TF/s
+    static const bool on32 = !(getenv("STYLEX_HALO_DMA32") && getenv("STYLEX_HALO_DMA32")[0] == '0');
+    if (on32 && on64 && p.Ck >= 64 && p.N <= 32) return p.dry ? 0 : launch_dma<1>(p, s);
     if (p.N >= 128 && p.Ck >= 128) return p.dry ? 0 : launch_dma<4>(p, s);
     return STYLEX_NOT_APPLICABLE;
 }
