@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = ABF ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j], av[i], acc[i][j], 0, 0, 0)   // D^T
+                                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -225,6 +226,100 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(ConvKParams p
     // weight space is dead after the last barrier) and written with 16-byte row stores: a wave covers 1 KiB
     // of contiguous NHWC output when N == BN.
     const int lj = lane & 31, lh = lane >> 5;
+    if (ABF) {
+        // bf16 activations: the MFMA operands are swapped (D^T = W x X^T), so a lane holds ONE PIXEL (lj) and, per
+        // 32-channel sub-tile, the channels 8g + 4lh + (0..3), g = r >> 2: the per-pixel terms (noise) are one value per
+        // lane, the per-channel ones float4s, and the store needs no LDS transpose — one v_permlane32_swap per dword
+        // pairs the half-waves' quads into 8 consecutive channels (see conv_halo_dma.hip)
+        const bool act = (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) != 0;
+        const float slope = (p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f;
+        const bool w8 = p.N % 8 == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0;
+        unsigned short* yout = reinterpret_cast<unsigned short*>(p.y);
+        const unsigned short* aux = reinterpret_cast<const unsigned short*>(p.residual);  // residual or gate tensor (bf16)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = wave * 64 + i * 32 + lj;
+            const int ph = pix / TW, pw = pix - ph * TW;
+            const int y = y0 + ph, x = x0 + pw;
+            const bool pix_ok = y < H && x < W;
+            const long obase = ((long)(b * H + y) * W + x) * p.N;
+            float nz = 0.f;
+            if (EPIX && (p.flags & STYLEX_EPI_NOISE)) {
+                const int yc = min(y, (int)p.noise_stride - 1), xc = min(x, (int)p.noise_stride - 1);
+                nz = (p.flags & STYLEX_EPI_NOISE_NAT) ? p.noise[((long)b * p.noise_stride + yc) * p.noise_stride + xc]
+                                                      : p.noise[((long)b * p.noise_stride + xc) * p.noise_stride + yc];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                unsigned P[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + j * 32 + 8 * g + 4 * lh;
+                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    // N % 4 == 0 on this path (checked by the launcher), n % 4 == 0: the quad is in range as a whole
+                    const bool nok = n < p.N;
+                    auto ld4 = [&](const float* ptr, float dflt) -> float4 {
+                        return nok ? *reinterpret_cast<const float4*>(ptr + n) : make_float4(dflt, dflt, dflt, dflt);
+                    };
+                    if (p.flags & STYLEX_EPI_OSCALE) {
+                        const float4 o4 = ld4(p.out_scale + (long)b * p.N, 1.f);
+                        v[0] *= o4.x; v[1] *= o4.y; v[2] *= o4.z; v[3] *= o4.w;
+                    }
+                    if (p.flags & STYLEX_EPI_BIAS) {
+                        const float4 b4 = ld4(p.bias, 0.f);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    }
+                    if (EPIX && (p.flags & STYLEX_EPI_NOISE)) {
+                        const float4 w4 = ld4(p.noise_w, 0.f), c4 = ld4(p.noise_b, 0.f);
+                        v[0] += nz * w4.x + c4.x; v[1] += nz * w4.y + c4.y; v[2] += nz * w4.z + c4.z; v[3] += nz * w4.w + c4.w;
+                    }
+                    if (EPIX && (p.flags & (STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE)) && nok && pix_ok) {
+                        const uint2 rv = *reinterpret_cast<const uint2*>(aux + obase + n);
+                        const float a4[4] = {__uint_as_float(rv.x << 16), __uint_as_float(rv.x & 0xffff0000u),
+                                             __uint_as_float(rv.y << 16), __uint_as_float(rv.y & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (p.flags & STYLEX_EPI_RESIDUAL) v[e] = (v[e] + a4[e]) * p.res_scale;
+                            else v[e] = a4[e] > 0.f ? v[e] : p.res_scale * v[e];
+                        }
+                    }
+                    if (act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+                    }
+                    P[g][0] = pack_bf16(v[0], v[1]);
+                    P[g][1] = pack_bf16(v[2], v[3]);
+                }
+                if (w8) {
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            auto r2 = __builtin_amdgcn_permlane32_swap(P[g][h], P[g + 1][h], false, false);
+                            P[g][h] = r2[0];
+                            P[g + 1][h] = r2[1];
+                        }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int n = n0 + j * 32 + 16 * q + 8 * lh;
+                        if (pix_ok && n < p.N)
+                            *reinterpret_cast<uint4*>(yout + obase + n) = make_uint4(P[2 * q][0], P[2 * q][1], P[2 * q + 1][0], P[2 * q + 1][1]);
+                    }
+                } else {  // odd channel counts (padded RGB outputs): element stores
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + j * 32 + 8 * g + 4 * lh;
+                        const unsigned short h4[4] = {(unsigned short)(P[g][0] & 0xffffu), (unsigned short)(P[g][0] >> 16),
+                                                      (unsigned short)(P[g][1] & 0xffffu), (unsigned short)(P[g][1] >> 16)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (pix_ok && n + e < p.N) yout[obase + n + e] = h4[e];
+                    }
+                }
+            }
+        }
+        return;
+    }
     constexpr int OUT_ES = ABF ? 2 : 4;                    // output element size
     constexpr int OROW = BN * OUT_ES + 16;                 // LDS row pitch of the staged output tile (+16 B skew)
     static_assert(256 * OROW <= NP * ROWB + 9 * W_TAP, "output tile must fit in the staging LDS");
@@ -365,6 +460,13 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
     if (p.mask || p.gate_mask || p.dry) return STYLEX_NOT_APPLICABLE;  // bit masks: LDS-DMA / RGB kernels only
+    if (p.act_bf16) {  // the register epilogue reads the per-channel terms as float4 quads
+        if (p.N % 4 != 0) return STYLEX_NOT_APPLICABLE;
+        const void* quads[4] = {p.bias, p.out_scale, p.noise_w, p.noise_b};
+        for (const void* q : quads)
+            if (q && (reinterpret_cast<uintptr_t>(q) & 15)) return STYLEX_NOT_APPLICABLE;
+        if ((p.flags & (STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE)) && (reinterpret_cast<uintptr_t>(p.residual) & 7)) return STYLEX_NOT_APPLICABLE;
+    }
     const bool wide = p.Wo >= 32;
     const bool epix = (p.flags & (STYLEX_EPI_NOISE | STYLEX_EPI_RESIDUAL | STYLEX_EPI_GATE)) != 0;
     if (p.act_bf16) {
