@@ -193,7 +193,9 @@ class _BiasAct(torch.autograd.Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         gx = _BiasActBwd.apply(gy, y)
-        gb = gx.sum(dim=(0, 2, 3), dtype=torch.float32) if (ctx.has_bias and _want_param_grad(ctx, 1)) else None
+        gb = None
+        if ctx.has_bias and _want_param_grad(ctx, 1):
+            gb = _channel_sum(gx) if (not torch.is_grad_enabled() and gx.is_cuda and hb.is_cl(gx)) else gx.sum(dim=(0, 2, 3), dtype=torch.float32)
         return gx, gb
 
 
@@ -389,7 +391,9 @@ class _ConvBiasActDD(torch.autograd.Function):
         if _want_param_grad(ctx, 1):
             gw = _Wgrad.apply(x, gz, tuple(w.shape), stride, pad, s2d)
         if has_bias and _want_param_grad(ctx, 2):
-            gb = gz.sum(dim=(0, 2, 3), dtype=torch.float32)
+            # a backward that is not itself recorded (the ordinary loss.backward() of a penalty step) takes the read-only
+            # reduction kernel: 2.4x faster than the ATen reduce on the 256^2 tensors (.118 vs .285 ms at B=64)
+            gb = _channel_sum(gz) if (not torch.is_grad_enabled() and gz.is_cuda and hb.is_cl(gz)) else gz.sum(dim=(0, 2, 3), dtype=torch.float32)
         return gx, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None
 
 
