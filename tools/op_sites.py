@@ -8,6 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--top", type=int, default=60)
+ap.add_argument("--warm", type=int, default=6, help="train() calls before the profiled one (8 -> the profiled call is a penalty step)")
 args = ap.parse_args()
 sys.argv = ["bench.py"]
 sys.path.insert(0, ROOT)
@@ -25,7 +26,7 @@ import ops  # noqa: E402
 hb.load_library()
 ops.set_precision("bf16")
 tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
-for i in range(6):
+for i in range(args.warm):
     tr.train()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
