@@ -74,8 +74,8 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s);
 // first layer of D / encoder: 3x3 over the padded RGB slot (C = 8) to 64 channels, forward (conv_rgb.hip)
 int stylex_launch_rgb(const ConvKParams& p, hipStream_t s);
 
-// weights-stationary persistent streaming kernel for the C, N <= 64 layers at >= 128^2 (conv_ws.hip)
-int stylex_launch_ws(const ConvKParams& p, hipStream_t s);
+// persistent, software-pipelined LDS-DMA kernel for the unmodulated 3x3/s1 layers (conv_pipe.hip)
+int stylex_launch_pipe(const ConvKParams& p, hipStream_t s);
 
 // LDS-DMA implicit GEMM for the <= 8x8 px layers (conv_gather.hip): writes fp32 partials and fills p.ksplit / p.partial
 // for the split-K epilogue kernel

@@ -816,46 +816,61 @@ def test_graph_replay_matches_eager(tmp_path):
     np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("cn", [(64, 64), (64, 32), (32, 32), (32, 64)])
-def test_streaming_ws_kernel_matches_tile_kernels(cn):
-    """conv_ws.hip (weights-stationary persistent streaming kernel for the C, N <= 64 layers at >= 128^2; opt-in with
-    STYLEX_CONV_WS=1 — it measured slower, see the file header) against the per-tile kernels on the same inputs: forward with bias + LeakyReLU, plain data
-    gradient, data gradient with the activation gate, and the modulated data gradient (demodulation folded into the
-    staged weights, modulation as out_scale).  Same accumulation order -> bit-identical where no scale is folded."""
+PIPE_CASES = [
+    # B, C, N, H, W
+    (6, 64, 64, 64, 64),      # 32x32 px x 64 n tiles (N = 64), 4 chunks per tile, 24 tiles
+    (3, 64, 64, 40, 72),      # ragged rows and columns
+    (2, 128, 128, 64, 64),    # 16x32 px x 128 n tiles
+    (70, 128, 256, 32, 32),   # 280 tiles > 256 CUs: several tiles per block, two channel tiles per pixel tile
+    (1, 256, 384, 24, 40),    # ragged, three channel tiles
+    (2, 512, 512, 32, 32),    # 32 chunks per tile
+    (1, 128, 64, 16, 40),     # N = 64 with fewer than 32 rows: stays on the per-tile kernel (both arms identical)
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES)
+def test_pipelined_conv_kernel_matches_per_tile_kernel(case):
+    """conv_pipe.hip (persistent, software-pipelined LDS-DMA kernel; round 3) against the per-tile LDS-DMA kernel it
+    replaces (STYLEX_CONV_PIPE=0) on the same inputs: forward with bias + LeakyReLU (+ activation bit mask), plain data
+    gradient, data gradient gated by an activation tensor and by a bit mask.  Both kernels accumulate the 16-channel
+    chunks in the same order with the same MFMA, so the results are bit-identical; the forward is also checked against
+    the fp32 definition."""
     import os
 
-    C, N = cn
-    B, S = 8, 256  # 1024 tiles of 16x32 px: the streaming regime
+    B, C, N, H, W = case
     ops.set_precision("bf16")
     P = hb.BF16_ACT
-    g = torch.Generator(device=DEV).manual_seed(21)
+    g = torch.Generator(device=DEV).manual_seed(33)
     mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
-    x, dy, gate = mk(B, C, S, S), mk(B, N, S, S), mk(B, C, S, S)
+    x, dy, gate = mk(B, C, H, W), mk(B, N, H, W), mk(B, C, H, W)
     w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
     bias = torch.randn(N, device=DEV, generator=g)
-    d = torch.rand(B, N, device=DEV, generator=g) + 0.5
-    s1 = torch.randn(B, C, device=DEV, generator=g) * 0.5 + 1.0
+    # the gate as the bit mask a forward conv would have written: bit k of byte i = element 8 i + k of the NHWC tensor > 0
+    bits = (gate.permute(0, 2, 3, 1).float() > 0).reshape(B, H, W, C // 8, 8).to(torch.int32)
+    gmask = (bits * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous()
+    sh_d = hb.conv_shape((B, C, H, W), tuple(w.shape), 1, 1)
 
     def run():
-        return (hb.conv2d_fwd(x, w, 1, 1, P, bias=bias, lrelu=True),
-                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, 1, P),
-                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, 1, P, gate=gate),
-                hb.conv2d_bwd_data(dy, w, (B, C, S, S), 1, 1, P, in_scale=d, out_scale=s1))
+        y, m = hb.conv2d_fwd(x, w, 1, 1, P, bias=bias, lrelu=True, want_mask=True)
+        outs = [y, hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P), hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P, gate=gate)]
+        if m is not None:
+            outs.append(m)
+        if hb.conv_mask_supported(sh_d, 1, hb.EPI_GATE_MASK, P):
+            outs.append(hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P, gate_mask=gmask))
+            assert torch.equal(outs[-1], outs[2]), "mask-gated data gradient differs from the tensor-gated one"
+        return outs
 
-    ref = run()  # default: the per-tile kernels
-    os.environ["STYLEX_CONV_WS"] = "1"
+    os.environ["STYLEX_CONV_PIPE"] = "0"
     try:
-        got = run()
+        ref = run()
     finally:
-        os.environ.pop("STYLEX_CONV_WS", None)
-    names = ("fwd bias+lrelu", "dgrad", "dgrad+gate", "modulated dgrad")
-    for nm, a, b in zip(names, ref, got):
-        if nm == "modulated dgrad":
-            close(a.float(), b.float(), 2e-2, nm)  # scale folded into bf16 weights vs into bf16 activations
-        elif (C, N) == (64, 64):  # replaces the LDS-DMA kernel: same chunking and tap order -> bit-identical
-            assert torch.equal(a, b), "%s: max diff %g" % (nm, float((a.float() - b.float()).abs().max()))
-        else:  # replaces the register-staged kernel (32-channel chunks): summation order differs
-            close(a.float(), b.float(), 1e-2, nm)
+        os.environ.pop("STYLEX_CONV_PIPE", None)
+    got = run()
+    assert len(ref) == len(got) and len(got) >= 3
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), "output %d: max diff %g" % (k, float((a.float() - b.float()).abs().max()))
+    yr = F.leaky_relu(F.conv2d(x.float(), w.to(torch.bfloat16).float(), bias, 1, 1), 0.2)
+    close(yr, got[0].float(), 1e-2, "pipe fwd vs fp32 definition")
     torch.cuda.synchronize()
 
 
