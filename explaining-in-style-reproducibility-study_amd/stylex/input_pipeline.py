@@ -152,8 +152,9 @@ def cycle(iterable):
 
 def make_device_loader(folder, image_size, batch_size, device, num_workers=0, transparent=False, sampler=None,
                        shuffle=True, depth=3):
-    """DataLoader over decoded images -> Prefetcher of preprocessed device batches; returns (iterator, dataset)."""
-    ds = RawImageFolder(folder, image_size, transparent=transparent)
+    """DataLoader over decoded images -> Prefetcher of preprocessed device batches; returns (iterator, dataset).
+    `folder` may be an already built RawImageFolder (the Trainer sizes its DistributedSampler from it first)."""
+    ds = folder if isinstance(folder, RawImageFolder) else RawImageFolder(folder, image_size, transparent=transparent)
     loader = data.DataLoader(ds, num_workers=num_workers, batch_size=batch_size, sampler=sampler,
                              shuffle=shuffle and sampler is None, drop_last=True, collate_fn=collate_raw)
     return Prefetcher(cycle(loader), DevicePreprocessor(image_size, device), device, depth=depth), ds

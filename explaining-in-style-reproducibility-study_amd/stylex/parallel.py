@@ -43,11 +43,12 @@ class GradSync:
     reference stylex_train.py:274-285)."""
 
     def __init__(self, params, bucket_bytes=None, overlap=None):
-        # overlap (in-backward launch, 32 MB buckets) is the default; STYLEX_DDP_OVERLAP=0 issues few large
-        # collectives after the backward instead (A/B switch for the scaling runs)
+        # Default: few large (128 MB) collectives issued after the backward.  The in-backward launch (32 MB buckets from
+        # autograd hooks, STYLEX_DDP_OVERLAP=1) is covered by the gloo tests and a 1-rank RCCL run only — it stays
+        # opt-in until a >= 2-GPU RCCL run has shown both the rank-averaged gradients and a scaling gain on hardware.
         import os
 
-        self.overlap = (os.environ.get("STYLEX_DDP_OVERLAP", "1") == "1") if overlap is None else bool(overlap)
+        self.overlap = (os.environ.get("STYLEX_DDP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
         if bucket_bytes is None:
             bucket_bytes = (32 if self.overlap else 128) * 1024 * 1024
         seen, self.params = set(), []
@@ -85,6 +86,7 @@ class GradSync:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _reset(self):
+        self._nograd = []
         self._ready = [0] * len(self.buckets)
         self._events = [[] for _ in self.buckets]
         self._next = 0
@@ -149,8 +151,9 @@ class GradSync:
         dst, src = [], []
         for p in self.buckets[bi]:
             v = self._views[id(p)]
-            if p.grad is None:  # no gradient this phase: contributes zeros
+            if p.grad is None:  # no gradient this phase: contributes zeros to the collective ...
                 v.zero_()
+                self._nograd.append(p)  # ... and goes back to None afterwards (all_reduce), as on one GPU
             elif p.grad is not v:
                 dst.append(v)
                 src.append(p.grad)
@@ -172,6 +175,12 @@ class GradSync:
             work.wait()
             if not flat.is_cuda:
                 flat.div_(world)
+        # A parameter without a gradient in this phase has none on ANY rank (every rank runs the same schedule: same
+        # phase, same micro-steps, same alternating / encoder switches), so its reduced "gradient" is exactly zero.
+        # Leave .grad = None as the single-GPU path and the reference's DDP do — Adam then skips the parameter instead
+        # of advancing its step count and decaying its moments with a zero gradient.
+        for p in self._nograd:
+            p.grad = None
         self._reset()
 
 

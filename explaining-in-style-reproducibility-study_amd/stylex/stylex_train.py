@@ -89,6 +89,21 @@ def _capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
+def _own_rng_mode(fn):
+    """Public Trainer entry points draw with THEIR Trainer's device_rng setting, whatever another Trainer of the
+    process used last (the module-level draw helpers read _Staging.DEVICE_RNG)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        prev, _Staging.DEVICE_RNG = _Staging.DEVICE_RNG, self.device_rng
+        try:
+            return fn(self, *a, **k)
+        finally:
+            _Staging.DEVICE_RNG = prev
+    return wrapped
+
+
 def raise_if_nan(t):  # reference :269-271
     if torch.isnan(t):
         raise NanException
@@ -145,7 +160,8 @@ class _Staging:
                 slot[1].synchronize()
         return slot
 
-    DEVICE_RNG = os.environ.get("STYLEX_DEVICE_RNG", "0") == "1"
+    ENV_DEVICE_RNG = os.environ.get("STYLEX_DEVICE_RNG", "0") == "1"
+    DEVICE_RNG = ENV_DEVICE_RNG  # set by the Trainer that is drawing (per-instance state, see _own_rng_mode)
 
     @classmethod
     def upload(cls, shape, fill, device):
@@ -576,12 +592,15 @@ class Trainer:
         self.graphs = (os.environ.get("STYLEX_GRAPHS", "0") == "1") if graphs is None else bool(graphs)
         self.graph_warmup = graph_warmup
         self._static, self._graph_cache, self._graph_pool, self._calls, self._graph_warm = {}, {}, None, 0, set()
-        self._nan_hook = os.environ.get("STYLEX_NAN_HOOK", "0") == "1"
+        # backward-time raise_if_nan hook (reference :1352): opt-in, and never under DDP — it would raise on ONE rank
+        # from inside a backward whose bucket all-reduces the other ranks are already waiting in; there the MAX-reduced
+        # device-side flag of train() is the (collective) NaN check
+        self._nan_hook = os.environ.get("STYLEX_NAN_HOOK", "0") == "1" and not is_ddp
         # N2 (input_pipeline.py): decode-only workers + prefetch thread + on-device resize / crop / scaling
         self.device_pipeline = (os.environ.get("STYLEX_DEVICE_PIPELINE", "0") == "1") if device_pipeline is None \
             else bool(device_pipeline)
-        if device_rng is not None:
-            _Staging.DEVICE_RNG = bool(device_rng)
+        # per-instance (a class-level switch leaked into every later Trainer of the process and broke their CPU-RNG parity)
+        self.device_rng = _Staging.ENV_DEVICE_RNG if device_rng is None else bool(device_rng)
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
         if classifier is not None:
@@ -661,11 +680,14 @@ class Trainer:
         if self.device_pipeline:
             import input_pipeline
 
-            probe = input_pipeline.RawImageFolder(folder, self.image_size, transparent=self.transparent)
-            sampler = DistributedSampler(probe, rank=self.rank, num_replicas=self.world_size,
+            # the decode-only dataset has no augmentation stage (the reference's RandomApply(aug_prob, crop + flip) runs
+            # on PIL images in the worker): refuse instead of silently training without it
+            assert not self.dataset_aug_prob, "device_pipeline=True does not implement dataset_aug_prob > 0"
+            ds = input_pipeline.RawImageFolder(folder, self.image_size, transparent=self.transparent)
+            sampler = DistributedSampler(ds, rank=self.rank, num_replicas=self.world_size,
                                          shuffle=True) if self.is_ddp else None
             self.loader, self.dataset = input_pipeline.make_device_loader(
-                folder, self.image_size, math.ceil(self.batch_size / self.world_size), self.device,
+                ds, self.image_size, math.ceil(self.batch_size / self.world_size), self.device,
                 num_workers=num_workers, transparent=self.transparent, sampler=sampler, shuffle=not self.is_ddp)
         else:
             self.dataset = Dataset(folder, self.image_size, transparent=self.transparent, aug_prob=self.dataset_aug_prob)
@@ -1013,6 +1035,7 @@ class Trainer:
         gp = acc["gp"]
         return torch.stack((acc["d"], acc["g"], acc["rec"], acc["kl"], gp if gp is not None else acc["d"]))
 
+    @_own_rng_mode
     def train(self):
         """One optimiser step of D, then one of G (reference :1249-1506)."""
         assert exists(self.loader), "You must first initialize the data source with `.set_data_src(<folder of images>)`"
@@ -1085,8 +1108,11 @@ class Trainer:
             m.EMA()
         if self.is_main and self.steps <= 25000 and self.steps % 1000 == 2:
             m.reset_parameter_averaging()
-        if self.is_main and (self.steps % self.save_every == 0 or self.steps % self.evaluate_every == 0):
-            self._resolve_losses()  # never checkpoint a NaN state (reference :1483-1486 precedes the save)
+        if self.steps % self.save_every == 0 or self.steps % self.evaluate_every == 0:
+            # never checkpoint a NaN state (reference :1483-1486 precedes the save).  On EVERY rank: the flag is already
+            # MAX-reduced, and the reload it triggers broadcasts parameters — a rank that skipped this call would be in
+            # the next phase's gradient all-reduce while rank 0 sits in that broadcast
+            self._resolve_losses()
         if self.is_main:
             if self.steps % self.save_every == 0:
                 self.save(self.checkpoint_num)
@@ -1230,6 +1256,7 @@ class Trainer:
     # ---- evaluation / generation (reference :1508-1698) ---------------------------------------
 
     @torch.no_grad()
+    @_own_rng_mode
     def evaluate(self, encoder_input=False, num=0, trunc=1.0):
         m = self.StylEx
         m.eval()
@@ -1282,6 +1309,7 @@ class Trainer:
         raise RuntimeError("FID needs pytorch_fid + Inception weights (network) — out of scope offline")
 
     @torch.no_grad()
+    @_own_rng_mode
     def truncate_style(self, tensor, trunc_psi=0.75):
         m = self.StylEx
         if not exists(self.av):
@@ -1308,6 +1336,7 @@ class Trainer:
         return evaluate_in_chunks(self.batch_size, G, w_styles, noi).clamp_(0., 1.)
 
     @torch.no_grad()
+    @_own_rng_mode
     def generate_interpolation(self, num=0, num_image_tiles=8, trunc=1.0, num_steps=100, save_frames=False):
         m = self.StylEx
         m.eval()

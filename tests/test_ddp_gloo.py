@@ -135,7 +135,10 @@ def _gradsync_worker(rank, world, port, q):
             if mode == "armed":
                 launched_before = sync._next  # buckets already in flight when the backward returned
             sync.all_reduce()
-            got = torch.cat([p.grad.reshape(-1) for p in params])
+            # a parameter without a gradient on any rank contributes zeros to the collective and is handed back with
+            # .grad = None (as on one GPU: Adam skips it instead of stepping on a zero gradient)
+            assert all(p.grad is None for p in unused.parameters())
+            got = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
             results[mode] = (float((got - want).abs().max()), launched_before if mode == "armed" else None)
         q.put((rank, results))
     finally:
@@ -226,7 +229,7 @@ def test_gradsync_world4_uneven_bucket_readiness():
     assert any(r[3] > 0 for r in res)
 
 
-def _nan_worker(rank, world, port, tmp, q):
+def _nan_worker(rank, world, port, tmp, q, on_save_step=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -244,18 +247,27 @@ def _nan_worker(rank, world, port, tmp, q):
         batches = [torch.rand(2, 3, size, size, generator=gd) for _ in range(8)]
         tr = st.Trainer(name="n%d" % rank, base_dir=tmp, image_size=size, network_capacity=2, fmap_max=16, batch_size=4,
                         gradient_accumulate_every=1, classifier=TinyClassifier(seed=99), lpips_fn=LPIPSStandIn(seed=4242),
-                        classifier_name="resnet", evaluate_every=10 ** 9, save_every=10 ** 9, is_ddp=True, rank=rank,
-                        world_size=world, device=torch.device("cpu"))
+                        classifier_name="resnet", evaluate_every=10 ** 9, save_every=2 if on_save_step else 10 ** 9,
+                        is_ddp=True, rank=rank, world_size=world, device=torch.device("cpu"))
         tr.loader = st.cycle(batches)
         tr.save = lambda *a, **k: None
         tr.evaluate = lambda *a, **k: None
         loads = []
-        tr.load = lambda num=-1: loads.append((tr.steps, num))
+
+        def fake_load(num=-1):  # the real load() ends in a parameter broadcast: a collective every rank must enter
+            loads.append((tr.steps, num))
+            import parallel
+
+            parallel.broadcast_parameters(tr.StylEx.D)
+
+        tr.load = fake_load
         tr.init_StylEx()
         real_stack = tr._loss_stack
         events = []
         for call in range(4):
-            if call == 1 and rank == 1:  # ONLY rank 1 sees a NaN loss, on its second call
+            # ONLY rank 1 sees a NaN loss: on its second call, or (on_save_step) on the call whose step number is a
+            # multiple of save_every — there the scalars are resolved inside the same call, before the checkpoint
+            if call == (2 if on_save_step else 1) and rank == 1:
                 tr._loss_stack = lambda acc: real_stack(acc) * float("nan")
             else:
                 tr._loss_stack = real_stack
@@ -270,14 +282,18 @@ def _nan_worker(rank, world, port, tmp, q):
 
 
 @pytest.mark.timeout(600)
-def test_nan_restart_is_collective(tmp_path):
+@pytest.mark.parametrize("on_save_step", [False, True])
+def test_nan_restart_is_collective(tmp_path, on_save_step):
     """A NaN loss on ONE rank makes EVERY rank take the reload-and-raise path at the same train() call (the flag is
-    MAX-reduced on the device inside the step that produced it), so the collectives of load()/the next step line up."""
+    MAX-reduced on the device inside the step that produced it), so the collectives of load()/the next step line up.
+    on_save_step: the NaN falls on a checkpoint step, where the scalars are resolved at the end of the SAME call — on
+    every rank, not only on rank 0 (round-2 hole: rank 0 entered load()'s broadcast while the others went on into the
+    next discriminator all-reduce)."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, str(tmp_path), q, on_save_step)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
@@ -285,5 +301,6 @@ def test_nan_restart_is_collective(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     (r0, ev0, loads0), (r1, ev1, loads1) = res
-    assert ev0 == ev1 == ["ok", "ok", "nan", "ok"], (ev0, ev1)  # detected while enqueueing the call after the NaN one
+    # detected while enqueueing the call after the NaN one / inside the NaN call itself on a checkpoint step
+    assert ev0 == ev1 == ["ok", "ok", "nan", "ok"], (ev0, ev1)
     assert loads0 == loads1 and len(loads0) == 1
