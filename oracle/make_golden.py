@@ -3,7 +3,7 @@ container: it imports the reference (/root/reference) through ``ref_shim`` and
 writes input/expected-output vectors to ``tests/golden/*.npz``.  The vectors are
 data; no reference source travels.
 
-    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,newarch,diffaug,curve]
+    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,newarch,diffaug,curve,evalsurface,envelope]
 
 Conventions: every fixture stores the seeds needed to regenerate weights
 (``torch.manual_seed(seed)`` then construct ``StylEx(...)``), all inputs that are
@@ -413,6 +413,58 @@ def gen_curve(st, n=100):
          threads=torch.get_num_threads())
 
 
+def gen_evalsurface(st):
+    """N3 — evaluation / EMA / truncation surface of the reference Trainer (stylex_train.py:985-999 EMA +
+    reset_parameter_averaging, :1508-1575 evaluate, :1624-1656 truncate_style / generate_truncated) at 16 px:
+    three train() calls across step 20010 (the EMA update fires there), then truncate_style on a given tensor (the
+    seeded 2000-sample W mean), then the three image grids evaluate() hands to save_image — with and without
+    encoder input — captured from the reference's own call."""
+    size, cap, fmax, bs = 16, 4, 32, 2
+    cls = ref_shim.TinyClassifier(seed=99)
+    gd = torch.Generator().manual_seed(7)
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    seed_all(42)
+    tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), cls, batches, image_size=size, network_capacity=cap,
+                                         fmap_max=fmax, batch_size=bs, gradient_accumulate_every=1, lr=2e-4,
+                                         ttur_mult=1.5, rec_scaling=1, kl_scaling=1, num_image_tiles=2)
+    tr.init_StylEx()
+    tr.steps = 20009
+    rows = []
+    for i in range(3):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss])
+        print("evalsurface step", tr.steps - 1, rows[-1])
+    names, pst = param_stats(tr.StylEx)  # S, G, D, encoder AND the averaged copies SE / GE after the EMA update
+    out = dict(config=np.array([size, cap, fmax, bs, 1, 2]), seed=42, data_seed=7, cls_seed=99, lpips_seed=4242,
+               start_step=20009, scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst)
+    # truncate_style: W mean of 2000 seeded samples, then the affine pull towards it
+    seed_all(123)
+    tr.av = None
+    t_in = torch.randn(4, tr.StylEx.G.latent_dim)
+    out["trunc_in"], out["trunc_psi"] = t_in, 0.6
+    out["trunc_out"] = st.Trainer.truncate_style(tr, t_in.clone(), trunc_psi=0.6)
+    out["trunc_av"] = np.asarray(tr.av)
+    # evaluate(): the tensors the reference passes to torchvision.utils.save_image
+    grids = []
+    st.torchvision.utils.save_image = lambda t, path, nrow=8, **k: grids.append((os.path.basename(str(path)), t.detach().clone(), nrow))
+    for k, (seed, enc) in enumerate(((77, False), (78, True))):
+        seed_all(seed)
+        tr.av = None
+        st.Trainer.evaluate(tr, encoder_input=enc, num=k)
+    st.torchvision.utils.save_image = lambda *a, **k: None
+    out["grid_names"] = np.array([g[0] for g in grids])
+    out["grid_nrow"] = np.array([g[2] for g in grids])
+    out["eval_seeds"] = np.array([77, 78])
+    for i, g in enumerate(grids):
+        out["grid/%d" % i] = g[1]
+        print("grid", g[0], tuple(g[1].shape), g[2])
+    # reset_parameter_averaging: the averaged copies become the live weights again
+    tr.StylEx.reset_parameter_averaging()
+    names2, pst2 = param_stats(tr.StylEx)
+    out["param_stats_after_reset"] = pst2
+    save("evalsurface_16", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="init,ops,nets,losses,steps")
@@ -422,7 +474,7 @@ def main():
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
                      ("steps", gen_steps), ("cfg4", gen_cfg4), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
-                     ("curve", gen_curve)):
+                     ("curve", gen_curve), ("evalsurface", gen_evalsurface)):
         if name in todo:
             if name == "steps" and a.step_cases:
                 fn(st, set(a.step_cases.split(",")))

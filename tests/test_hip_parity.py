@@ -18,7 +18,7 @@ import stylex_train as st  # noqa: E402
 from conftest import load_golden  # noqa: E402
 from lpips_standin import LPIPSStandIn  # noqa: E402
 from test_oracle_vs_golden import build_nets_model, close_stats  # noqa: E402
-from test_host_logic_cpu import assert_param_stats, make_cfg4_trainer, make_trainer, run_steps  # noqa: E402
+from test_host_logic_cpu import assert_param_stats, check_evalsurface, make_cfg4_trainer, make_trainer, run_steps  # noqa: E402
 
 DEV = "cuda:0"
 TOL32, TOLBF = 2e-5, 4e-2
@@ -520,6 +520,12 @@ def test_trainer_step_parity_gpu(tag, tmp_path):
     # all 226 parameter tensors after the last step vs the reference's: sums to 2e-3 of the abs-sum; single elements to
     # n * lr_D (an element whose gradient is summation-order noise takes a +-lr Adam step in either direction)
     assert_param_stats(tr, g, head_atol=n * 3e-4)
+
+
+def test_eval_ema_truncation_surface_vs_reference_golden_gpu(tmp_path):
+    """N3 on the HIP path: EMA / reset_parameter_averaging, truncate_style, generate_truncated and the three image
+    grids of evaluate() against the reference Trainer's own outputs (tests/golden/evalsurface_16.npz)."""
+    check_evalsurface(tmp_path, device=torch.device(DEV), tol=2e-3, head_atol=3 * 3e-4)
 
 
 def test_config4_mobilenet_pl_step_parity_gpu(tmp_path):

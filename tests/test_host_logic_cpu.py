@@ -3,6 +3,7 @@ losses, Trainer control flow — against the vectors captured from the reference
 kernels cannot run here, so the product's op surface is replaced by the oracle's CPU test
 double (oracle/cpu_ops.py) for the duration of this file; the numerical parity of the kernels
 themselves is the job of the ``-m gpu`` tests."""
+import os
 import random
 
 import numpy as np
@@ -193,6 +194,87 @@ def test_config4_mobilenet_pl_step_parity_cpu(tmp_path):
     np.testing.assert_allclose(rows[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
     np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
     assert_param_stats(tr, g)
+
+
+def check_evalsurface(tmp_path, device=None, tol=1e-3, head_atol=1e-4):
+    """N3 — EMA / reset_parameter_averaging, truncate_style, generate_truncated and evaluate() of the product Trainer
+    against tests/golden/evalsurface_16.npz, captured from the reference Trainer itself (oracle/make_golden.py::
+    gen_evalsurface; reference stylex_train.py:985-999, :1508-1575, :1624-1656).  Same seeds -> same draws: the
+    2000-sample W mean, the truncated styles and the three image grids evaluate() writes (regular / EMA / mixing
+    regularities; with and without encoder input) must match."""
+    g = load_golden("evalsurface_16")
+    size, cap, fmax, bs, gae, tiles = (int(v) for v in g["config"])
+    cls = TinyClassifier(seed=int(g["cls_seed"]))
+    gd = torch.Generator().manual_seed(int(g["data_seed"]))
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    lp = LPIPSStandIn(seed=int(g["lpips_seed"]))
+    if device is not None:
+        cls.to(device)
+        lp = lp.to(device)
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    tr = st.Trainer(name="ev", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax, batch_size=bs,
+                    gradient_accumulate_every=gae, lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1, classifier=cls,
+                    lpips_fn=lp, classifier_name="resnet", evaluate_every=10 ** 9, save_every=10 ** 9, device=device,
+                    num_image_tiles=tiles)
+    tr.loader = st.cycle(batches)
+    tr.dataset = list(range(1000))
+    tr.save = lambda *a, **k: None
+    real_evaluate = tr.evaluate
+    tr.evaluate = lambda *a, **k: None
+    tr.init_StylEx()
+    tr.steps = int(g["start_step"])
+    rows = []
+    for _ in range(len(g["scalars"])):  # three calls across step 20010: the EMA update fires inside the second one
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss])
+    np.testing.assert_allclose(np.array(rows, dtype=np.float64), g["scalars"], rtol=tol, atol=tol)
+    assert_param_stats(tr, g, head_atol=head_atol)  # includes SE.* / GE.*: the averaged copies after update_moving_average
+    params = dict(tr.StylEx.named_parameters())
+    moved = max(float((params["GE." + n[2:]] - p).detach().abs().max()) for n, p in params.items() if n.startswith("G."))
+    assert moved > 0, "the averaged generator must differ from the live one after training steps"
+    # truncate_style: seeded 2000-sample mean of S(z), then trunc_psi * (w - mean) + mean
+    torch.manual_seed(123)
+    np.random.seed(123)
+    random.seed(123)
+    tr.av = None
+    t_in = torch.randn(4, tr.StylEx.G.latent_dim)
+    np.testing.assert_array_equal(t_in.numpy(), g["trunc_in"])
+    dev = tr.device
+    t_out = tr.truncate_style(t_in.to(dev), trunc_psi=float(g["trunc_psi"]))
+    close(g["trunc_av"], torch.as_tensor(tr.av), tol)  # W mean of truncate_style
+    close(g["trunc_out"], t_out.detach().cpu(), tol)
+    # evaluate(): capture what the product hands to its image writer
+    grids = []
+    orig = st.save_image_grid
+    st.save_image_grid = lambda imgs, path, nrow=8: grids.append((os.path.basename(str(path)), imgs.detach().float().cpu(), nrow))
+    try:
+        for k, (sd, enc) in enumerate(zip((int(v) for v in g["eval_seeds"]), (False, True))):
+            torch.manual_seed(sd)
+            np.random.seed(sd)
+            random.seed(sd)
+            tr.av = None
+            real_evaluate(encoder_input=enc, num=k)
+    finally:
+        st.save_image_grid = orig
+    assert [n for n, _, _ in grids] == [str(n) for n in g["grid_names"]]
+    assert [r for _, _, r in grids] == [int(r) for r in g["grid_nrow"]]
+    for i, (name, imgs, _) in enumerate(grids):
+        close(g["grid/%d" % i], imgs, 5 * tol)  # evaluate grid `name`
+    # reset_parameter_averaging (:997-999)
+    tr.StylEx.reset_parameter_averaging()
+    params = dict(tr.StylEx.named_parameters())
+    for name, gs in zip(g["param_names"], g["param_stats_after_reset"]):
+        close_stats(gs, params[str(name)].detach().cpu(), 2e-3, head_atol=head_atol)
+    for n, p in params.items():
+        if n.startswith("G."):
+            assert torch.equal(params["GE." + n[2:]], p)
+
+
+def test_eval_ema_truncation_surface_vs_reference_golden_cpu(tmp_path):
+    check_evalsurface(tmp_path)
 
 
 def test_missing_classifier_checkpoint_raises(tmp_path, monkeypatch):
