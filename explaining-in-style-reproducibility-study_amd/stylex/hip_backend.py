@@ -84,6 +84,11 @@ SIGNATURES = {
                                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
+    "stylex_weight_sumsq": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_modcoeff_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_float, ctypes.c_void_p]),
+    "stylex_modcoeff_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_torgb_chunks": (ctypes.c_int, [_i64p]),
     "stylex_torgb_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_torgb_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
@@ -450,6 +455,57 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), shp, flags, ctypes.byref(epi), precision,
                                       _ptr(ws), ws_bytes, _stream()), "stylex_conv2d_bwd_data")
     return dx
+
+
+def weight_sumsq(w):
+    """wsq[o][i] = sum over the taps of w[o][i][.]^2 (fp32) — the weight-only factor of the demodulation coefficient;
+    cached per Parameter version like the packed operands."""
+    lib = _ensure_device(w)
+    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+    key = None
+    if cacheable:
+        key = (w.data_ptr(), w._version, tuple(w.shape), "wsq", None)
+        hit = _cache_hit(key, w)
+        if hit is not None and hit[0] is not None:
+            return hit[0]
+    w_param = w
+    w = w.detach().contiguous().float()
+    o, c = w.shape[0], w.shape[1]
+    k = w.numel() // (o * c)
+    wsq = _empty(o * c, dtype=torch.float32, device=w.device).view(o, c)
+    _check(lib.stylex_weight_sumsq(_ptr(w), _ptr(wsq), o, c, k, _stream()), "stylex_weight_sumsq")
+    if key is not None:
+        _cache_put(key, w_param, wsq, None)
+    return wsq
+
+
+def modcoeff_fwd(style, wsq, eps):
+    """(style + 1, rsqrt((style + 1)^2 @ wsq^T + eps)) in one launch; style [B, C] fp32, wsq [O, C]."""
+    lib = _ensure_device(style)
+    style = _f32(style)
+    b, c = style.shape
+    o = wsq.shape[0]
+    s1 = _empty(b * c, dtype=torch.float32, device=style.device).view(b, c)
+    d = _empty(b * o, dtype=torch.float32, device=style.device).view(b, o)
+    _check(lib.stylex_modcoeff_fwd(_ptr(style), _ptr(wsq), _ptr(s1), _ptr(d), b, c, o, float(eps), _stream()),
+           "stylex_modcoeff_fwd")
+    return s1, d
+
+
+def modcoeff_bwd(gd, d, s1, wsq, w, gs1, want_style, want_weight):
+    """Gradients of modcoeff_fwd w.r.t. style (incl. the direct gradient gs1 of s1, or None) and the OIHW weight."""
+    lib = _ensure_device(gd)
+    gd = _f32(gd)
+    gs1 = _f32(gs1)
+    b, c = s1.shape
+    o = d.shape[1]
+    wc = w.detach().contiguous().float()
+    k = wc.numel() // (o * c)
+    gstyle = _empty(b * c, dtype=torch.float32, device=gd.device).view(b, c) if want_style else None
+    gw = _empty(wc.numel(), dtype=torch.float32, device=gd.device).view(wc.shape) if want_weight else None
+    _check(lib.stylex_modcoeff_bwd(_ptr(gd), _ptr(d), _ptr(s1), _ptr(wsq), _ptr(wc), _ptr(gs1), _ptr(gstyle), _ptr(gw), b, c,
+                                   o, k, _stream()), "stylex_modcoeff_bwd")
+    return gstyle, gw
 
 
 def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None, s2d_c=0, want_bias_sum=False):

@@ -979,10 +979,36 @@ def impl():
     return _IMPL
 
 
+class _ModCoeffs(torch.autograd.Function):
+    """(style + 1, demodulation coefficient) of a modulated conv as ONE launch (csrc/style_coeffs.hip; `wsq`, the
+    weight-only factor, is cached per parameter version) with a two-launch first-order backward — the ATen composition
+    below is ~8 launches forward and ~15 backward per call, 28 calls per step."""
+
+    @staticmethod
+    def forward(ctx, style, weight, eps):
+        wsq = hb.weight_sumsq(weight)
+        s1, d = hb.modcoeff_fwd(style, wsq, eps)
+        ctx.save_for_backward(s1, d, wsq, weight)
+        return s1, d
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gs1, gd):
+        s1, d, wsq, weight = ctx.saved_tensors
+        need_s, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if gd is None:  # the coefficient was not used: only the direct gradient of s1 remains
+            return (gs1 if need_s else None), None, None
+        gstyle, gw = hb.modcoeff_bwd(gd, d, s1, wsq, weight, gs1, need_s, need_w)
+        return gstyle, gw, None
+
+
 def mod_coeffs(style, weight, demod=True, eps=1e-8):
     """(s+1, demodulation coefficient) of a modulated conv (:650-656 in the batched form): small dense math on
     [B,C] / [O,I] tensors, independent of the activations — the Generator evaluates it for all layers ahead of
     the conv chain on a companion stream."""
+    if (demod and _IMPL is HipOps and style.is_cuda and fast_enabled() and style.dim() == 2
+            and os.environ.get("STYLEX_MODCOEFF", "1") != "0"):
+        return _ModCoeffs.apply(style, weight, eps)
     s1 = style + 1
     d = None
     if demod:

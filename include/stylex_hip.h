@@ -221,6 +221,25 @@ int stylex_bias_act_bwd(const void* dy, const void* y, void* dx, const int64_t* 
  * reduction per row block; deterministic. */
 int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void* stream);
 
+/* ---- modulated-conv coefficients (SURVEY §8(b) `demod_coeff` / `bwd_style`) --------------------
+ * Conv2DMod.forward (reference stylex_train.py:650-656) in the batched form:
+ *   s1[b][i] = style[b][i] + 1,   d[b][o] = rsqrt( sum_i s1[b][i]^2 * wsq[o][i] + eps ),
+ *   wsq[o][i] = sum_k W[o][i][k]^2  (k over the KH*KW taps).
+ * All tensors fp32 and dense: style, s1 [B][C]; d, gd [B][O]; wsq [O][C]; w, gw [O][C][K].
+ * stylex_weight_sumsq: one launch per weight VERSION (cache it until the optimiser step).
+ * stylex_modcoeff_fwd: writes s1 and d.
+ * stylex_modcoeff_bwd: first-order backward through d (gd = dL/dd):
+ *   gstyle[b][i] = (gs1 ? gs1[b][i] : 0) + 2 s1[b][i] * sum_o dq[b][o] wsq[o][i],  dq = -gd d^3 / 2
+ *   gw[o][i][k]  = 2 w[o][i][k] * sum_b dq[b][o] s1[b][i]^2
+ * gs1 = the gradient that reaches s1 directly (from the conv's input scale), or NULL; gstyle / gw may be NULL
+ * (that gradient is not needed).  Fixed summation order (deterministic). */
+int stylex_weight_sumsq(const float* w, float* wsq, int64_t O, int64_t C, int64_t K, void* stream);
+int stylex_modcoeff_fwd(const float* style, const float* wsq, float* s1, float* d, int64_t B, int64_t C, int64_t O,
+                        float eps, void* stream);
+int stylex_modcoeff_bwd(const float* gd, const float* d, const float* s1, const float* wsq, const float* w,
+                        const float* gs1, float* gstyle, float* gw, int64_t B, int64_t C, int64_t O, int64_t K,
+                        void* stream);
+
 /* ---- fused fast path (steps that need no double backward) ------------------------------------
  * Backward-side kernels that fold the LeakyReLU mask, a scale and the per-(image, channel)
  * reductions into ONE pass.  Tensors NHWC fp32, shape = {B, H, W, C}, C % 4 == 0, C <= 1024.

@@ -413,6 +413,36 @@ def gen_curve(st, n=100):
          threads=torch.get_num_threads())
 
 
+def gen_envelope(st, n=12):
+    """X1 — the reference against ITSELF: the curve_64 run (config-1 shape, 8 threads) repeated with 4 and with 2
+    intra-op threads.  Only the summation order of the CPU kernels changes, yet the untrained GAN amplifies it
+    step by step; the spread of these trajectories is the envelope inside which any correct implementation's
+    trajectory can be expected to stay (tests: HIP-vs-reference error <= c x reference-vs-reference error)."""
+    size, cap, fmax, bs, gae = 64, 16, 512, 4, 2
+    out = {}
+    keep = torch.get_num_threads()
+    for threads in (4, 2):
+        torch.set_num_threads(threads)
+        cls = ref_shim.TinyClassifier(seed=99)
+        gd = torch.Generator().manual_seed(7)
+        batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+        seed_all(42)
+        tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), cls, batches, image_size=size,
+                                             network_capacity=cap, fmap_max=fmax, batch_size=bs,
+                                             gradient_accumulate_every=gae, lr=2e-4, ttur_mult=1.5, rec_scaling=1,
+                                             kl_scaling=1)
+        rows, t0 = [], time.time()
+        for i in range(n):
+            tr.train()
+            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                         tr.last_gp_loss if tr.last_gp_loss is not None else np.nan])
+            print("envelope t%d" % threads, i, rows[-1], "%.0fs" % (time.time() - t0))
+        out["scalars_t%d" % threads] = np.array(rows, dtype=np.float64)
+    torch.set_num_threads(keep)
+    save("curve_64_envelope", config=np.array([size, cap, fmax, bs, gae]), seed=42, data_seed=7, cls_seed=99,
+         lpips_seed=4242, threads=np.array([4, 2]), **out)
+
+
 def gen_evalsurface(st):
     """N3 — evaluation / EMA / truncation surface of the reference Trainer (stylex_train.py:985-999 EMA +
     reset_parameter_averaging, :1508-1575 evaluate, :1624-1656 truncate_style / generate_truncated) at 16 px:
@@ -474,7 +504,7 @@ def main():
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
                      ("steps", gen_steps), ("cfg4", gen_cfg4), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
-                     ("curve", gen_curve), ("evalsurface", gen_evalsurface)):
+                     ("curve", gen_curve), ("evalsurface", gen_evalsurface), ("envelope", gen_envelope)):
         if name in todo:
             if name == "steps" and a.step_cases:
                 fn(st, set(a.step_cases.split(",")))

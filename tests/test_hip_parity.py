@@ -639,6 +639,40 @@ def test_loss_curve_short_horizon_vs_reference():
     assert err[2].max() <= 2e-2, err  # third call: losses of order 1e4, still within 2 %
 
 
+def test_loss_curve_inside_reference_envelope():
+    """X1 (north_star: loss curves vs the CPU reference) as a statistical statement.  The untrained GAN is chaotic:
+    the reference's OWN trajectory moves when only the summation order of its CPU kernels changes — tests/golden/
+    curve_64_envelope.npz holds the curve_64 run repeated with 4 and 2 intra-op threads (oracle/make_golden.py::
+    gen_envelope): 1e-7 at step 0, 3e-4 at step 3, 2e-2 at step 6, > 0.1 from step 8 on (saturated).  The HIP fp32
+    path differs from the reference by a different summation order too (MFMA chains, fused epilogues), with a larger
+    step-0 difference (1.5e-6).  Asserted: until the envelope saturates, the HIP-vs-reference error of every step
+    stays within 3x the reference-vs-reference error reached up to three steps later (the head start a 10x larger
+    initial perturbation buys at the measured ~5x growth per step), and all 12 steps stay finite."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("curve_check", os.path.join(root, "tools", "curve_check.py"))
+    cc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cc)
+    env = load_golden("curve_64_envelope")
+    n = len(env["scalars_t4"])
+    got, ref = cc.run(n=n, precision="fp32")
+    assert np.isfinite(got[:, :4]).all()
+    rel = lambda a: (np.abs(a[:, :4] - ref[:, :4]) / np.maximum(1.0, np.abs(ref[:, :4]))).max(1)  # noqa: E731
+    e_hip = rel(got)
+    e_ref = np.maximum(rel(env["scalars_t4"]), rel(env["scalars_t2"]))  # reference vs reference, per step
+    head, c, sat = 3, 3.0, 0.2
+    checked = 0
+    for k in range(n):
+        bound = e_ref[:min(k + head, n - 1) + 1].max()
+        if bound >= sat:  # the reference no longer agrees with itself to 20 %: nothing left to assert but finiteness
+            break
+        assert e_hip[k] <= c * bound, "step %d: HIP error %.3e vs %gx envelope %.3e\n%s\n%s" % (k, e_hip[k], c, bound, e_hip, e_ref)
+        checked += 1
+    assert checked >= 5, (checked, e_ref)
+
+
 # ---- full-size, size-independent properties at BASELINE.json's 256 px / B=32 shapes ------------
 
 
@@ -820,6 +854,43 @@ def test_graph_replay_matches_eager(tmp_path):
     assert np.isfinite(b).all()
     np.testing.assert_allclose(b[:4], a[:4], rtol=1e-4, atol=1e-5)  # eager + warm passes: same arithmetic
     np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("shape", [(5, 24, 40, 3), (64, 512, 512, 3), (3, 64, 32, 3), (7, 130, 77, 1)])
+def test_modcoeff_kernels_vs_torch_composition(shape):
+    """csrc/style_coeffs.hip (`demod_coeff` / `bwd_style` of SURVEY §8(b)): s1 = style + 1 and the demodulation
+    coefficient d = rsqrt(s1^2 @ sum_k W^2 + eps) (reference :650-656), forward and first-order backward (gradients
+    reaching d AND s1), against the ATen composition in float64."""
+    B, C, O, k = shape
+    g = torch.Generator().manual_seed(5)
+    style = torch.randn(B, C, generator=g) * 0.5
+    w = torch.randn(O, C, k, k, generator=g) / (C * k * k) ** 0.5
+    r1, r2 = torch.randn(B, C, generator=g), torch.randn(B, O, generator=g)
+    sr, wr = style.double().requires_grad_(), w.double().requires_grad_()
+    s1r = sr + 1
+    dr = torch.rsqrt((s1r * s1r) @ wr.pow(2).sum(dim=(2, 3)).t() + 1e-8)
+    ((s1r * r1.double()).sum() + (dr * r2.double()).sum()).backward()
+    sd, wd = style.to(DEV).requires_grad_(), torch.nn.Parameter(w.to(DEV))
+    prev = ops.set_fast(True)
+    try:
+        s1, d = ops.mod_coeffs(sd, wd, True, 1e-8)
+        assert type(s1.grad_fn).__name__.startswith("_ModCoeffs"), "the fused kernels must serve the fast path"
+        ((s1 * r1.to(DEV)).sum() + (d * r2.to(DEV)).sum()).backward()
+    finally:
+        ops.set_fast(prev)
+    close(s1r, s1, 1e-6, "s1")
+    close(dr, d, 2e-6, "d")
+    close(sr.grad, sd.grad, 2e-5, "grad style")
+    close(wr.grad, wd.grad, 2e-5, "grad weight")
+    # only s1 used downstream (no demodulation gradient): the direct gradient passes through
+    sd2 = style.to(DEV).requires_grad_()
+    prev = ops.set_fast(True)
+    try:
+        s1b, _ = ops.mod_coeffs(sd2, wd, True, 1e-8)
+        (s1b * r1.to(DEV)).sum().backward()
+    finally:
+        ops.set_fast(prev)
+    close(r1, sd2.grad, 1e-6, "grad style via s1 only")
 
 
 PIPE_CASES = [
