@@ -57,20 +57,21 @@ def rand_translation(x, ratio=0.125):
     return out * ok.unsqueeze(1).to(x.dtype)
 
 
-def rand_offset(x, ratio=1, ratio_h=1, ratio_v=1):  # :51-71 (Python random.randint per image, torch.roll)
-    w, h = x.size(2), x.size(3)
-    imgs = []
-    for img in x.unbind(dim=0):
-        max_h = int(w * ratio * ratio_h)
-        max_v = int(h * ratio * ratio_v)
-        value_h = random.randint(0, max_h) * 2 - max_h
-        value_v = random.randint(0, max_v) * 2 - max_v
-        if abs(value_h) > 0:
-            img = torch.roll(img, value_h, 2)
-        if abs(value_v) > 0:
-            img = torch.roll(img, value_v, 1)
-        imgs.append(img)
-    return torch.stack(imgs)
+def rand_offset(x, ratio=1, ratio_h=1, ratio_v=1):
+    """:51-71 — a circular shift of every image by its own random (horizontal, vertical) amount.  The amounts are
+    drawn exactly as the reference draws them (Python `random.randint`, per image, horizontal first; note its naming:
+    the horizontal range is derived from size(2) and applied along the last axis), then ALL images are shifted by one
+    batched gather per axis on the tensor's device — out[b, :, i, j] = x[b, :, (i - v_b) mod H, (j - h_b) mod W] —
+    instead of the reference's per-image torch.roll + stack."""
+    b, _, hh, ww = x.shape
+    max_h, max_v = int(hh * ratio * ratio_h), int(ww * ratio * ratio_v)
+    shifts = [(random.randint(0, max_h) * 2 - max_h, random.randint(0, max_v) * 2 - max_v) for _ in range(b)]
+    sh = torch.tensor([s[0] for s in shifts], dtype=torch.long).to(x.device).view(b, 1)
+    sv = torch.tensor([s[1] for s in shifts], dtype=torch.long).to(x.device).view(b, 1)
+    src_w = (torch.arange(ww, device=x.device).view(1, ww) - sh) % ww  # [B, W]
+    src_h = (torch.arange(hh, device=x.device).view(1, hh) - sv) % hh  # [B, H]
+    out = x.gather(3, src_w.view(b, 1, 1, ww).expand(-1, x.size(1), hh, -1))
+    return out.gather(2, src_h.view(b, 1, hh, 1).expand(-1, x.size(1), -1, ww))
 
 
 def rand_offset_h(x, ratio=1):

@@ -457,6 +457,45 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     return dx
 
 
+def _bf16_matrix(w, scale=None):
+    """[N, C] bf16 copy of a 1x1 conv weight (x scale), cached per Parameter version like the packed operands."""
+    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+    key = None
+    if cacheable:
+        key = (w.data_ptr(), w._version, tuple(w.shape), "bf16mat", scale)
+        hit = _cache_hit(key, w)
+        if hit is not None and hit[0] is not None:
+            return hit[0]
+    m = w.detach().reshape(w.shape[0], -1)
+    m = (m * scale if scale is not None else m).to(torch.bfloat16).contiguous()
+    if key is not None:
+        _cache_put(key, w, m, None)
+    return m
+
+
+def conv1x1_gemm_fwd(x, w, bias):
+    """1x1 / stride-1 conv of a channels_last bf16 tensor as the plain GEMM it is — [B*H*W, C] x [C, N] (+ bias) on
+    hipBLASLt (torch.addmm): the residual path of a DiscriminatorBlock after the even-pixel gather.  Measured against
+    the generic implicit-GEMM kernel at B = 128 (tools/probes/gemm1x1_probe.py): 64->128 @64^2 .161 -> .049 ms,
+    128->256 @32^2 .094 -> .025, 256->512 @16^2 .060 -> .021.  Same arithmetic (bf16 operands, fp32 accumulate, one
+    rounding of the result)."""
+    assert is_cl(x) and x.dtype == torch.bfloat16
+    b, c, h, wd = x.shape
+    wm = _bf16_matrix(w)
+    x2 = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)
+    y2 = torch.mm(x2, wm.t()) if bias is None else torch.addmm(bias.detach().to(torch.bfloat16), x2, wm.t())
+    return y2.view(b, h, wd, wm.shape[0]).permute(0, 3, 1, 2)
+
+
+def conv1x1_gemm_bwd_data(dy, w, scale=None):
+    """Data gradient of the same conv: [B*H*W, N] x [N, C] (the weight optionally pre-multiplied by `scale`)."""
+    assert is_cl(dy) and dy.dtype == torch.bfloat16
+    b, n, h, wd = dy.shape
+    wm = _bf16_matrix(w, scale)
+    dx2 = torch.mm(dy.permute(0, 2, 3, 1).reshape(b * h * wd, n), wm)
+    return dx2.view(b, h, wd, wm.shape[1]).permute(0, 3, 1, 2)
+
+
 def weight_sumsq(w):
     """wsq[o][i] = sum over the taps of w[o][i][.]^2 (fp32) — the weight-only factor of the demodulation coefficient;
     cached per Parameter version like the packed operands."""

@@ -625,15 +625,19 @@ class _DBlockFast(torch.autograd.Function):
         # the 1x1 residual path (even-pixel gather + small GEMM) is independent of the two 3x3 convs until the merge:
         # companion HIP stream, joined before the kernel that merges
         side = _fork_side(x)
+        # the 1x1 conv of the residual path is a plain GEMM: hipBLASLt in the bf16 mode (2-3x the generic kernel)
+        res_gemm = _PRECISION == hb.BF16_ACT and os.environ.get("STYLEX_RES_GEMM", "1") != "0"
+        conv_res = (lambda t: hb.conv1x1_gemm_fwd(t, wrp if cin == 3 else w_res, b_res)) if res_gemm else (
+            lambda t: hb.conv2d_fwd(t, wrp, 1, 0, _PRECISION, bias=b_res))
         if side is None:
             xs = hb.subsample2_fwd(x) if downsample else x
-            res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
+            res = conv_res(xs)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 xs = hb.subsample2_fwd(x) if downsample else x
-                res = hb.conv2d_fwd(xs, wrp, 1, 0, _PRECISION, bias=b_res)
+                res = conv_res(xs)
             x.record_stream(side)
         # Activation bit masks: the backward needs y2 ONLY for its sign (the LeakyReLU derivative fused into the blur
         # adjoint) and y1 for its sign plus as the weight-gradient operand; where the forward kernel can write the sign
@@ -718,6 +722,14 @@ class _DBlockFast(torch.autograd.Function):
         # residual path (1x1 weight gradient + data gradient on the quarter-size tensor): companion stream, joined
         # before its results are used at the end
         side_bwd, side_out, main = _fork_side(g_out), None, torch.cuda.current_stream() if g_out.is_cuda else None
+        res_gemm = prec == hb.BF16_ACT and os.environ.get("STYLEX_RES_GEMM", "1") != "0"
+
+        def res_dgrad():
+            if res_gemm:  # [M, N] x [N, C] on hipBLASLt, the 1/sqrt(2) folded into the bf16 weight copy as below
+                return hb.conv1x1_gemm_bwd_data(gz3, wrp if cin == 3 else w_res, scale=c if alg else None)
+            wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
+            return hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+
         if side_bwd is not None:
             side_bwd.wait_stream(main)
             with torch.cuda.stream(side_bwd):
@@ -727,8 +739,7 @@ class _DBlockFast(torch.autograd.Function):
                     if alg:
                         s_gw = s_gw * wsc
                 if want_x:
-                    wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
-                    s_gx = hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+                    s_gx = res_dgrad()
                 side_out = (s_gw, s_gx)
             gz3.record_stream(side_bwd)
             xs.record_stream(side_bwd)
@@ -784,8 +795,7 @@ class _DBlockFast(torch.autograd.Function):
                 if alg:
                     gw_res = gw_res * wsc
             if want_x:
-                wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
-                gxs = hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
+                gxs = res_dgrad()
         if want_w and cin == 3:
             gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
         if want_x:

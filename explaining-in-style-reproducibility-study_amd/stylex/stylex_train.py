@@ -1333,6 +1333,11 @@ class Trainer:
             # half there) with the class probabilities appended, for all layers
             w_truncated = [(torch.cat((w_truncated[0][0], probabilities), dim=1), self.StylEx.G.num_layers)]
         w_styles = styles_def_to_tensor(w_truncated)
+        # with encoder input the styles have len(image_batch) rows while the noise was drawn for num_image_tiles^2: the
+        # reference's chunk-wise zip pairs row i with row i and drops the rest (:1653) — which only works while both
+        # split into equally sized chunks (under DDP the loader batch is batch_size / world rows, and the first chunk
+        # of styles no longer matches the first chunk of noise); pairing row by row explicitly is the same result
+        noi = noi[:w_styles.shape[0]]
         return evaluate_in_chunks(self.batch_size, G, w_styles, noi).clamp_(0., 1.)
 
     @torch.no_grad()

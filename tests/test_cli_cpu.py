@@ -99,3 +99,43 @@ def test_new_architecture_switch_and_evaluate(tmp_path, monkeypatch):
     tr.evaluate(encoder_input=True, num=6)
     assert sorted(os.listdir(tmp_path / "results" / "e")) == ["5--ema.png", "5--mr.png", "5-.png", "6-from_encoder-ema.png",
                                                                "6-from_encoder-mr.png", "6-from_encoder.png"]
+
+
+@pytest.mark.timeout(900)
+def test_cli_multi_gpus_through_torchrun_gloo(tmp_path):
+    """`cli.py --multi_gpus` as the driver launches a multi-GPU job: `python -m torch.distributed.run` with one process
+    per rank (here 2 ranks over gloo on the CPU test double; on the GPU box the same code path picks "nccl" = RCCL).
+    Both ranks run the same number of train() calls with the per-rank batch, all-reduce their gradients, and only
+    rank 0 writes the checkpoint / config (reference cli.py:49-51, stylex_train.py:1188-1193)."""
+    import socket
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    data = tmp_path / "imgs"
+    data.mkdir()
+    rng = np.random.RandomState(1)
+    for i in range(8):
+        Image.fromarray(rng.randint(0, 255, (32, 32, 3), dtype=np.uint8)).save(data / f"{i}.png")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    launcher = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cli_cpu_double.py")
+    env = dict(os.environ, OMP_NUM_THREADS="2", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), launcher, str(data), "--results_dir", str(tmp_path / "results"), "--models_dir",
+           str(tmp_path / "models"), "--name", "ddp", "--new", "--multi_gpus", "--image_size", "16", "--network_capacity", "2",
+           "--fmap_max", "16", "--batch_size", "4", "--gradient_accumulate_every", "1", "--num_train_steps", "2",
+           "--num_workers", "0", "--save_every", "2", "--evaluate_every", "1000000", "--tensorboard_dir", "None",
+           "--classifier_path", "None"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "1/2 process initialized." in out.stdout and "2/2 process initialized." in out.stdout
+    mdir = tmp_path / "models" / "ddp"
+    cks = sorted(f for f in os.listdir(mdir) if f.startswith("model_"))
+    assert cks, os.listdir(mdir)
+    ck = torch.load(mdir / cks[-1])
+    assert ck["version"] == "1.8.7"
+    assert all(torch.isfinite(v).all() for v in ck["StylEx"].values() if torch.is_floating_point(v))

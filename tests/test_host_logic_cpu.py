@@ -277,6 +277,45 @@ def test_eval_ema_truncation_surface_vs_reference_golden_cpu(tmp_path):
     check_evalsurface(tmp_path)
 
 
+def test_lpips_state_dict_loading_and_published_formula():
+    """LPIPS.load_lpips_state_dict takes the key layout of the lpips package (net.slice<k>.<idx>.weight / .bias,
+    lin<k>.model.1.weight — reference: lpips.LPIPS(net='alex'), stylex_train.py:404) and the forward is the published
+    metric: unit-normalised AlexNet taps, squared difference, non-negative 1x1 weights, spatial mean, summed."""
+    import torch.nn.functional as F
+
+    from lpips_alex import _ALEX, LPIPS
+
+    m = LPIPS(seed=1)
+    g = torch.Generator().manual_seed(9)
+    sd = {}
+    for i, (ci, co, k, s, p, mp, idx) in enumerate(_ALEX):
+        sd["net.slice%d.%d.weight" % (i + 1, idx)] = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        sd["net.slice%d.%d.bias" % (i + 1, idx)] = torch.randn(co, generator=g) * 0.1
+        sd["lin%d.model.1.weight" % i] = torch.rand(1, co, 1, 1, generator=g) / co
+    before = [p.clone() for p in m.cw]
+    m.load_lpips_state_dict(sd)
+    for i, (_, _, _, _, _, _, idx) in enumerate(_ALEX):
+        assert torch.equal(m.cw[i], sd["net.slice%d.%d.weight" % (i + 1, idx)]) and not torch.equal(m.cw[i], before[i])
+        assert torch.equal(m.cb[i], sd["net.slice%d.%d.bias" % (i + 1, idx)])
+        assert torch.equal(m.lin[i], sd["lin%d.model.1.weight" % i])
+    a, b = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    got = m(a, b)
+    # the published computation, written out independently of the module's forward
+    shift, scale = torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1), torch.tensor([.458, .448, .450]).view(1, 3, 1, 1)
+    fa, fb, want = (a - shift) / scale, (b - shift) / scale, 0
+    for i, (ci, co, k, s, p, mp, idx) in enumerate(_ALEX):
+        if mp:
+            fa, fb = F.max_pool2d(fa, 3, 2), F.max_pool2d(fb, 3, 2)
+        w_, b_ = sd["net.slice%d.%d.weight" % (i + 1, idx)], sd["net.slice%d.%d.bias" % (i + 1, idx)]
+        fa, fb = F.relu(F.conv2d(fa, w_, b_, stride=s, padding=p)), F.relu(F.conv2d(fb, w_, b_, stride=s, padding=p))
+        na = fa / (fa.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+        nb = fb / (fb.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+        want = want + ((na - nb) ** 2 * sd["lin%d.model.1.weight" % i]).sum(1, keepdim=True).mean(dim=(2, 3), keepdim=True)
+    assert got.shape == (2, 1, 1, 1)
+    close(want, got, 1e-5)
+    assert float(m(a, a).abs().max()) == 0.0 and float(got.min()) > 0.0
+
+
 def test_missing_classifier_checkpoint_raises(tmp_path, monkeypatch):
     """A named classifier checkpoint that does not exist is an error (as in the reference, where torch.load raises),
     never a silent random-weight classifier; None is the explicit opt-in used by the synthetic benchmarks."""
