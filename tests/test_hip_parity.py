@@ -653,6 +653,40 @@ def test_loss_curve_short_horizon_vs_reference():
     assert err[2].max() <= 2e-2, err  # third call: losses of order 1e4, still within 2 %
 
 
+def test_config2_full_size_bf16_train_calls(tmp_path):
+    """BASELINE config 2 whole, as bench.py builds it: 256 px, batch 32, GAE 2, ResNet-18 classifier, bf16 — two
+    train() calls (the first is a gradient-penalty step) through every full-size kernel path of the step.  Asserted:
+    all scalars finite, every parameter finite, and the first call's losses inside the band an untrained StylEx
+    produces on uniform-noise batches with these seeds (measured: d 13.97, g 9.30, rec 3.54, kl 1.30, gp 12.49; the
+    second call already shows the untrained GAN's excursions, g 2e4, which is why only call 0 is banded)."""
+    import argparse
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+
+    ops.set_precision("bf16")
+    try:
+        a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir=str(tmp_path), precision="bf16")
+        tr = bench.build_trainer(a, torch.device(DEV), 0, 1)
+        rows = []
+        for _ in range(2):
+            tr.train()
+            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss, tr.last_gp_loss])
+        torch.cuda.synchronize()
+        rows = np.array(rows, dtype=np.float64)
+        print("config 2, two calls:", rows)
+        assert np.isfinite(rows).all(), rows
+        assert all(bool(torch.isfinite(p).all()) for p in tr.StylEx.parameters())
+        d0, g0, rec0, kl0, gp0 = rows[0]
+        assert 7.0 < d0 < 28.0 and 1.7 < rec0 < 7.0 and 0.0 <= kl0 < 5.0 and 3.0 < gp0 < 50.0, rows[0]
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_loss_curve_inside_reference_envelope():
     """X1 (north_star: loss curves vs the CPU reference) as a statistical statement.  The untrained GAN is chaotic:
     the reference's OWN trajectory moves when only the summation order of its CPU kernels changes — tests/golden/
