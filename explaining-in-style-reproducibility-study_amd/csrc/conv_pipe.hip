@@ -32,12 +32,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // kernel argument (not in the anonymous namespace: a kernel's host stub needs externally visible parameter types)
 struct StylexPipeArgs {
     int total_tiles;
     unsigned m_ntiles, m_tpi, m_tx;  // magic reciprocals of n_tiles, tiles per image, tiles_x
-    int dbg;                         // ablation switches of tools/bench_pipe.py (STYLEX_PIPE_DBG): 1 no stores, 2 every halo from tile 0, 4 every weight tile from n0 = 0
+    int dbg;                         // ablation switches of tools/bench_pipe.py (STYLEX_PIPE_DBG): 1 no stores, 2 every halo from tile 0, 4 every weight tile from n0 = 0, 8 do not wait for the epilogue stores (WRONG results: timing ablation only)
 };
 
 namespace {
@@ -248,40 +249,57 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
     // consecutive channels of one pixel per quad; v_permlane32_swap pairs the half-waves' quads into 16-byte stores)
     const bool act = EPI == 0 && (p.flags & (STYLEX_EPI_LRELU | STYLEX_EPI_RELU)) != 0;
     const float slope = (p.flags & STYLEX_EPI_RELU) ? 0.f : 0.2f;
-    unsigned short* yout = reinterpret_cast<unsigned short*>(p.y);
-    const unsigned short* gate = reinterpret_cast<const unsigned short*>(p.residual);  // EPI == 1
     const float gslope = p.res_scale;
-    const unsigned char* gmask = p.gate_mask;                                           // EPI == 2
-    unsigned char* mask_out = EPI == 0 ? p.mask : nullptr;
+    const bool mask_out = EPI == 0 && p.mask != nullptr;
     auto gatem = [&](unsigned u, unsigned bits) -> unsigned {
         const float a0 = __uint_as_float(u << 16), c0 = __uint_as_float(u & 0xffff0000u);
-        return (unsigned)to_bf16((bits & 1u) ? a0 : gslope * a0) | ((unsigned)to_bf16((bits & 2u) ? c0 : gslope * c0) << 16);
+        f32x2_t t = {(bits & 1u) ? a0 : gslope * a0, (bits & 2u) ? c0 : gslope * c0};
+        bf16x2_t r = __builtin_convertvector(t, bf16x2_t);
+        return *reinterpret_cast<unsigned*>(&r);
     };
     auto gate2 = [&](unsigned u, unsigned g) -> unsigned {
         const float a0 = __uint_as_float(u << 16), c0 = __uint_as_float(u & 0xffff0000u);
         const float ga = __uint_as_float(g << 16), gc = __uint_as_float(g & 0xffff0000u);
-        return (unsigned)to_bf16(ga > 0.f ? a0 : gslope * a0) | ((unsigned)to_bf16(gc > 0.f ? c0 : gslope * c0) << 16);
+        f32x2_t t = {ga > 0.f ? a0 : gslope * a0, gc > 0.f ? c0 : gslope * c0};
+        bf16x2_t r = __builtin_convertvector(t, bf16x2_t);
+        return *reinterpret_cast<unsigned*>(&r);
+    };
+    // Addressing: buffer stores / loads through descriptors of y (and the gate tensor / bit masks, which share its
+    // geometry).  soffset = the tile's first output element + image row i (uniform, SALU), voffset = what a lane adds
+    // to it — pixel lj of row 4*rg, channel half nh, quad half lh: 32 bits, the same for every tile — and (j, q) are
+    // instruction immediates.  Pixels outside the image get an out-of-range voffset: the store is dropped (a gate load
+    // returns 0) by the bounds check, so there is no exec-mask branch and no 64-bit vector arithmetic per store (the
+    // first version spent more issue slots on v_mad_u64 / v_lshl_add_u64 / s_and_saveexec than on the stores).
+    const unsigned bytes_y = (unsigned)((long)p.B * H * W * N * 2);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)bytes_y, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rgate = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, (int)bytes_y, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        EPI == 2 ? const_cast<unsigned char*>(p.gate_mask) : p.mask, 0, (int)(bytes_y >> 4), 0x00020000);
+    const unsigned rowb = (unsigned)(W * N) * 2u;  // bytes between image rows
+    const unsigned lane_off = (unsigned)(((4 * rg) * W + li) * N + nh * 64 + 8 * lk) * 2u;
+    auto pack2 = [](float a, float c) -> unsigned {  // one v_cvt_pk_bf16_f32 (RNE), low half = a
+        f32x2_t t = {a, c};
+        bf16x2_t r = __builtin_convertvector(t, bf16x2_t);
+        return *reinterpret_cast<unsigned*>(&r);
     };
     auto epilogue = [&](int b, int y0, int x0, int n0) {
-        const int lj = li, lh = lk;
+        const int lh = lk;
         const int nb = n0 + nh * 64;
-        const int x = x0 + lj;
+        const unsigned t_off = __builtin_amdgcn_readfirstlane((unsigned)((((long)(b * H + y0) * W + x0) * N + n0) * 2));
+        const unsigned voff_col = x0 + li < W ? lane_off : OOB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             // gates of the whole 4-row x 32-channel slab first: eight loads in flight instead of one per store
-            uint4 gv[4][2];
+            u32x4 gv[4][2];
             unsigned gm[4][2];
             if (EPI != 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int y = y0 + 4 * rg + i;
-                    const bool pix_ok = y < H && x < W;
-                    const long obase = ((long)(b * H + y) * W + x) * N;
+                    const unsigned voff = y0 + 4 * rg + i < H ? voff_col : OOB, soff = t_off + i * rowb;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const long o = obase + nb + j * 32 + 16 * q + 8 * lh;
-                        if (EPI == 1) gv[i][q] = pix_ok ? *reinterpret_cast<const uint4*>(gate + o) : make_uint4(0u, 0u, 0u, 0u);
-                        if (EPI == 2) gm[i][q] = pix_ok ? (unsigned)gmask[o >> 3] : 0u;
+                        if (EPI == 1) gv[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rgate, voff + (j * 64 + q * 32), soff, 0);
+                        if (EPI == 2) gm[i][q] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (voff >> 4) + (j * 4 + q * 2), soff >> 4, 0);
                     }
                 }
             }
@@ -293,9 +311,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                             : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int y = y0 + 4 * rg + i;
-                const bool pix_ok = y < H && x < W;
-                const long obase = ((long)(b * H + y) * W + x) * N;
+                const unsigned voff = y0 + 4 * rg + i < H ? voff_col : OOB, soff = t_off + i * rowb;
                 unsigned P[4][2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -307,8 +323,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                         v2 = v2 > 0.f ? v2 : slope * v2;
                         v3 = v3 > 0.f ? v3 : slope * v3;
                     }
-                    P[g][0] = (unsigned)to_bf16(v0) | ((unsigned)to_bf16(v1) << 16);
-                    P[g][1] = (unsigned)to_bf16(v2) | ((unsigned)to_bf16(v3) << 16);
+                    P[g][0] = pack2(v0, v1);
+                    P[g][1] = pack2(v2, v3);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g += 2)
@@ -320,7 +336,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                     }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int n = nb + j * 32 + 16 * q + 8 * lh;
                     uint4 v = make_uint4(P[2 * q][0], P[2 * q][1], P[2 * q + 1][0], P[2 * q + 1][1]);
                     if (EPI == 1) {
                         v.x = gate2(v.x, gv[i][q].x);
@@ -334,10 +349,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                         v.z = gatem(v.z, m >> 4);
                         v.w = gatem(v.w, m >> 6);
                     }
-                    if (pix_ok && !(pa.dbg & 1)) {
-                        const long o = obase + n;
-                        *reinterpret_cast<uint4*>(yout + o) = v;
-                        if (mask_out) mask_out[o >> 3] = (unsigned char)stylex_sign_bits8(v);
+                    if (!(pa.dbg & 1)) {
+                        u32x4 vv = {v.x, v.y, v.z, v.w};
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, ry, voff + (j * 64 + q * 32), soff, 0);
+                        // A VMEM store of more than 8 bytes needs a wait state before a VALU write of its data
+                        // registers.  hipcc does not pad it for a buffer store with an SGPR soffset (LLVM's rule says
+                        // the hazard needs an immediate soffset), yet gfx950 showed it: `buffer_store_dwordx4 v[172:175]`
+                        // followed by `v_and_b32 v172, ...` stored the NEW v172 in lanes 12-15 / 28-31 of every row of
+                        // 16.  The data registers are operands of the nop statement, so nothing can overwrite them
+                        // before it, and the memory clobber keeps the statement behind the store.
+                        asm volatile("s_nop 1" : "+v"(vv) : : "memory");
+                        if (mask_out)
+                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)stylex_sign_bits8(v), rmask, (voff >> 4) + (j * 4 + q * 2),
+                                                                 soff >> 4, 0);
                     }
                 }
             }
@@ -421,7 +445,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
     __builtin_amdgcn_sched_barrier(0);
 #define PIPE_LAST(AVC, BVC, AVN, BVN, BNEXT)                   \
     lds_wait(AVC, BVC);                                        \
-    wait_vmcnt<HP_MAX>();                                      \
+    if (pa.dbg & 8) wait_vmcnt<HP_MAX + 16>();                 \
+    else wait_vmcnt<HP_MAX>();                                 \
     __builtin_amdgcn_s_barrier();                              \
     asm volatile("" ::: "memory");                             \
     load_tap<NT, 0>(AVN, BVN, addr, BNEXT);                    \
@@ -451,7 +476,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
         c_ch += 2;
         if (c_ch == nchunks) {  // tile complete: its stores drain under the next tile's MFMAs
             c_ch = 0;
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU readers (see mfma1)
+            // MFMA results -> VALU readers (see mfma1).  The accumulators are operands of the statement: a plain
+            // "memory" clobber does not stop hipcc from scheduling the epilogue's first accumulator reads ABOVE it
+            // (seen: the lanes / rows the last MFMA passes write came out as garbage in one epilogue variant).
+            asm volatile("s_nop 15\n\ts_nop 15"
+                         : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                           "+v"(acc[3][0]), "+v"(acc[3][1]));
             epilogue(cb, cy0, cx0, cn0);
             if (++c_k < my_tiles) {
                 decode(c_k, cb, cy0, cx0, cn0);
@@ -523,7 +553,9 @@ int stylex_launch_pipe(const ConvKParams& p, hipStream_t s) {
     if (p.Ck < 64 || p.Ck % 32 != 0 || p.N % 64 != 0 || p.N > 512 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (reinterpret_cast<uintptr_t>(p.y) & 15))
         return STYLEX_NOT_APPLICABLE;
-    if ((long)p.B * p.Ho * p.Wo * p.Ck * 2 >= (1l << 31) || (long)p.N * 9 * p.Ck * 2 >= (1l << 31)) return STYLEX_NOT_APPLICABLE;
+    if ((long)p.B * p.Ho * p.Wo * p.Ck * 2 >= (1l << 31) || (long)p.N * 9 * p.Ck * 2 >= (1l << 31) ||
+        (long)p.B * p.Ho * p.Wo * p.N * 2 >= (1l << 31))
+        return STYLEX_NOT_APPLICABLE;
     if (p.dry) return 0;
     const bool n128 = p.N % 128 == 0 && !(env && env[0] == '6');
     if (n128) return launch_pipe_epi<128>(p, s);

@@ -8,6 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--top", type=int, default=60)
+ap.add_argument("--by-count", action="store_true", help="rank call sites by number of calls instead of device time")
 ap.add_argument("--warm", type=int, default=6, help="train() calls before the profiled one (8 -> the profiled call is a penalty step)")
 args = ap.parse_args()
 sys.argv = ["bench.py"]
@@ -57,7 +58,9 @@ for e in prof.events():
 tot = sum(site_t.values())
 print("device time of top-level aten ops: %.2f ms/step over %d calls" % (tot / 1e3, sum(site_n.values())))
 SKIP = ("aten::conv2d", "aten::convolution_backward", "aten::batch_norm", "aten::native_batch_norm_backward")
-for (site, name), t in site_t.most_common(args.top + 8):
+order = sorted(site_t, key=lambda k: -site_n[k]) if args.by_count else [k for k, _ in site_t.most_common(args.top + 8)]
+for (site, name) in order[:args.top + 8]:
+    t = site_t[(site, name)]
     if name in SKIP:
         continue
     print("%8.1f us %5d  %-26s %s" % (t, site_n[(site, name)], name, site))
