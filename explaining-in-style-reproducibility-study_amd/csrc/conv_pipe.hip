@@ -38,7 +38,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct StylexPipeArgs {
     int total_tiles;
     unsigned m_ntiles, m_tpi, m_tx;  // magic reciprocals of n_tiles, tiles per image, tiles_x
-    int dbg;                         // ablation switches of tools/bench_pipe.py (STYLEX_PIPE_DBG): 1 no stores, 2 every halo from tile 0, 4 every weight tile from n0 = 0, 8 do not wait for the epilogue stores (WRONG results: timing ablation only)
+    int dbg;                         // ablation switches of tools/bench_pipe.py (STYLEX_PIPE_DBG): 1 no stores, 2 every halo from tile 0, 4 every weight tile from n0 = 0, 8 do not wait for the epilogue stores, 16 store full 128-byte lines (8 and 16: WRONG results, timing ablations only)
 };
 
 namespace {
@@ -276,42 +276,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
         EPI == 2 ? const_cast<unsigned char*>(p.gate_mask) : p.mask, 0, (int)(bytes_y >> 4), 0x00020000);
     const unsigned rowb = (unsigned)(W * N) * 2u;  // bytes between image rows
-    const unsigned lane_off = (unsigned)(((4 * rg) * W + li) * N + nh * 64 + 8 * lk) * 2u;
     auto pack2 = [](float a, float c) -> unsigned {  // one v_cvt_pk_bf16_f32 (RNE), low half = a
         f32x2_t t = {a, c};
         bf16x2_t r = __builtin_convertvector(t, bf16x2_t);
         return *reinterpret_cast<unsigned*>(&r);
     };
+    // FULL-LINE STORES.  After the permlane32 pairing a lane holds, for pixel p = lane % 32 of a row tile, the four
+    // 16-byte pieces S = 4j + 2q + lh of the wave's 128-byte channel run — a store instruction per (j, q) would touch 32
+    // different 128-byte lines with 32 bytes each.  Measured (ablation dbg 16): the same bytes written as whole lines
+    // take 17 % off 64->64 @256^2 and 8-14 % off the 128^2 layers — the partial-line write requests, not the bytes,
+    // were what the stores cost.  So the register index m = 2j + q is transposed with lane bits 4:3 (pixel / 8) first:
+    // bit 3 <-> q by a DPP row rotate by 8 with a bank mask (one instruction per dword), bit 4 <-> j by
+    // v_permlane16_swap.  Afterwards register k holds pixels 8k .. 8k+7, lane = (lh, j, q, pixel % 8): one instruction
+    // stores eight complete lines.  The coalescing is by ADDRESS, so the lanes need no further reordering.
+    const unsigned lane_off = (unsigned)(((4 * rg) * W + (lane & 7)) * N + nh * 64) * 2u +
+                              (unsigned)(4 * ((lane >> 4) & 1) + 2 * ((lane >> 3) & 1) + (lane >> 5)) * 16u;
+    const unsigned pixb8 = (unsigned)N * 16u;  // bytes between pixel p and p + 8
     auto epilogue = [&](int b, int y0, int x0, int n0) {
         const int lh = lk;
         const int nb = n0 + nh * 64;
         const unsigned t_off = __builtin_amdgcn_readfirstlane((unsigned)((((long)(b * H + y0) * W + x0) * N + n0) * 2));
-        const unsigned voff_col = x0 + li < W ? lane_off : OOB;
+        // operand-side addressing (gates, bit masks): pixel li, pieces (j, q, lh) — the layout before the transpose
+        const unsigned g_off = x0 + li < W ? (unsigned)(((4 * rg) * W + li) * N + nh * 64 + 8 * lh) * 2u : OOB;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            // gates of the whole 4-row x 32-channel slab first: eight loads in flight instead of one per store
-            u32x4 gv[4][2];
-            unsigned gm[4][2];
-            if (EPI != 0) {
+        for (int i = 0; i < 4; ++i) {
+            const bool row_ok = y0 + 4 * rg + i < H;
+            const unsigned soff = t_off + i * rowb;
+            u32x4 R[4];  // R[2j + q]
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned voff = y0 + 4 * rg + i < H ? voff_col : OOB, soff = t_off + i * rowb;
+            for (int j = 0; j < 2; ++j) {
+                u32x4 gv[2];
+                unsigned gm[2];
+                if (EPI != 0) {
+                    const unsigned voff = row_ok ? g_off : OOB;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        if (EPI == 1) gv[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rgate, voff + (j * 64 + q * 32), soff, 0);
-                        if (EPI == 2) gm[i][q] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (voff >> 4) + (j * 4 + q * 2), soff >> 4, 0);
+                        if (EPI == 1) gv[q] = __builtin_amdgcn_raw_buffer_load_b128(rgate, voff + (j * 64 + q * 32), soff, 0);
+                        if (EPI == 2) gm[q] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (voff >> 4) + (j * 4 + q * 2), soff >> 4, 0);
                     }
                 }
-            }
-            float4 b4[4];
+                float4 b4[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b4[g] = (EPI == 0 && (p.flags & STYLEX_EPI_BIAS))
-                            ? *reinterpret_cast<const float4*>(smem + Cfg::BIAS_BASE + (nb + j * 32 + 8 * g + 4 * lh) * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned voff = y0 + 4 * rg + i < H ? voff_col : OOB, soff = t_off + i * rowb;
+                for (int g = 0; g < 4; ++g)
+                    b4[g] = (EPI == 0 && (p.flags & STYLEX_EPI_BIAS))
+                                ? *reinterpret_cast<const float4*>(smem + Cfg::BIAS_BASE + (nb + j * 32 + 8 * g + 4 * lh) * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
                 unsigned P[4][2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -338,31 +347,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                 for (int q = 0; q < 2; ++q) {
                     uint4 v = make_uint4(P[2 * q][0], P[2 * q][1], P[2 * q + 1][0], P[2 * q + 1][1]);
                     if (EPI == 1) {
-                        v.x = gate2(v.x, gv[i][q].x);
-                        v.y = gate2(v.y, gv[i][q].y);
-                        v.z = gate2(v.z, gv[i][q].z);
-                        v.w = gate2(v.w, gv[i][q].w);
+                        v.x = gate2(v.x, gv[q].x);
+                        v.y = gate2(v.y, gv[q].y);
+                        v.z = gate2(v.z, gv[q].z);
+                        v.w = gate2(v.w, gv[q].w);
                     } else if (EPI == 2) {
-                        const unsigned m = gm[i][q];
+                        const unsigned m = gm[q];
                         v.x = gatem(v.x, m);
                         v.y = gatem(v.y, m >> 2);
                         v.z = gatem(v.z, m >> 4);
                         v.w = gatem(v.w, m >> 6);
                     }
-                    if (!(pa.dbg & 1)) {
-                        u32x4 vv = {v.x, v.y, v.z, v.w};
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, ry, voff + (j * 64 + q * 32), soff, 0);
-                        // A VMEM store of more than 8 bytes needs a wait state before a VALU write of its data
-                        // registers.  hipcc does not pad it for a buffer store with an SGPR soffset (LLVM's rule says
-                        // the hazard needs an immediate soffset), yet gfx950 showed it: `buffer_store_dwordx4 v[172:175]`
-                        // followed by `v_and_b32 v172, ...` stored the NEW v172 in lanes 12-15 / 28-31 of every row of
-                        // 16.  The data registers are operands of the nop statement, so nothing can overwrite them
-                        // before it, and the memory clobber keeps the statement behind the store.
-                        asm volatile("s_nop 1" : "+v"(vv) : : "memory");
-                        if (mask_out)
-                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)stylex_sign_bits8(v), rmask, (voff >> 4) + (j * 4 + q * 2),
-                                                                 soff >> 4, 0);
-                    }
+                    if (mask_out && !(pa.dbg & 1))  // one byte per 8 channels, addressed in the pre-transpose layout
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)stylex_sign_bits8(v), rmask,
+                                                             ((row_ok ? g_off : OOB) >> 4) + (j * 4 + q * 2), soff >> 4, 0);
+                    R[2 * j + q] = u32x4{v.x, v.y, v.z, v.w};
+                }
+            }
+            // transpose register index (j, q) <-> lane bits (4, 3)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {  // q <-> lane bit 3: lanes 8-15 of a row take the partner's q = 1 ... register
+                    const unsigned a0 = R[2 * j][d], a1 = R[2 * j + 1][d];
+                    R[2 * j][d] = (unsigned)__builtin_amdgcn_update_dpp((int)a0, (int)a1, 0x128, 0xF, 0xC, false);
+                    R[2 * j + 1][d] = (unsigned)__builtin_amdgcn_update_dpp((int)a1, (int)a0, 0x128, 0xF, 0x3, false);
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {  // j <-> lane bit 4: odd 16-lane rows of R[q] <-> even rows of R[2 + q]
+                    auto r = __builtin_amdgcn_permlane16_swap(R[q][d], R[2 + q][d], false, false);
+                    R[q][d] = r[0];
+                    R[2 + q][d] = r[1];
+                }
+            if (!(pa.dbg & 1)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // register k = 2 * (pixel bit 4) + (pixel bit 3): pixels 8k .. 8k + 7
+                    const unsigned voff = (row_ok && x0 + 8 * k + (lane & 7) < W) ? lane_off : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(R[k], ry, voff, soff + k * pixb8, 0);
+                    // A VMEM store of more than 8 bytes needs a wait state before a VALU write of its data registers.
+                    // hipcc does not pad it for a buffer store with an SGPR soffset (LLVM's rule ties the hazard to an
+                    // immediate soffset), yet gfx950 showed it: `buffer_store_dwordx4 v[172:175]` directly followed by
+                    // `v_and_b32 v172, ...` stored the NEW v172 in lanes 12-15 / 28-31 of every row of 16.  The data
+                    // registers are operands of the nop statement, so nothing overwrites them before it, and the
+                    // memory clobber keeps the statement behind the store.
+                    asm volatile("s_nop 1" : "+v"(R[k]) : : "memory");
                 }
             }
         }
