@@ -648,6 +648,37 @@ int stylex_blur3x3_s2d_fwd(const void* x, void* y, EW_ARGS) {
     LAUNCH_EW(blur3x3_fwd_kernel, (long)B * H * W * C, x, y, x, y, B, H, W, C, bf, 1);
 }
 int stylex_blur3x3_s2d_bwd(const void* dy, void* dx, EW_ARGS) { return blur_bwd_impl(dy, nullptr, 0.f, dx, 1, sh, act_dtype, stream); }
+// RGB image (3 channels, any strides, fp32 or bf16) -> one 16-byte channel slot per pixel: bf16 NHWC [B][H][W][8], channels
+// 3..7 zero.  One launch instead of cast + channels_last copy + zero tensor + cat in front of the first conv of the
+// discriminator / encoder (DiscriminatorBlock 0 reads RGB; the vector load paths want whole 16-byte slots).
+__global__ __launch_bounds__(256) void pad_rgb8_kernel(const void* __restrict__ x, uint4* __restrict__ y, long npix, int H, int W,
+                                                       long sb, long sc, long sh, long sw, int x_bf16) {
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const long t = i / W;
+        const int h = (int)(t % H);
+        const long b = t / H;
+        const long o = b * sb + h * sh + w * sw;
+        unsigned short c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (x_bf16) c[k] = reinterpret_cast<const unsigned short*>(x)[o + k * sc];
+            else c[k] = (unsigned short)(act_pack2(reinterpret_cast<const float*>(x)[o + k * sc], 0.f) & 0xffffu);
+        }
+        y[i] = make_uint4((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2], 0u, 0u);
+    }
+}
+
+int stylex_pad_rgb8(const void* x, void* y, const int64_t* shape, const int64_t* strides, int x_is_bf16, void* stream) {
+    if (!x || !y || !shape || !strides || shape[0] < 1 || shape[1] < 1 || shape[2] < 1) return STYLEX_EINVAL;
+    if (reinterpret_cast<uintptr_t>(y) & 15) return STYLEX_EINVAL;
+    const long npix = (long)shape[0] * shape[1] * shape[2];
+    long blocks = (npix + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pad_rgb8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (uint4*)y, npix, (int)shape[1],
+                       (int)shape[2], (long)strides[0], (long)strides[1], (long)strides[2], (long)strides[3], x_is_bf16);
+    return (int)hipGetLastError();
+}
 int stylex_subsample2_fwd(const void* x, void* y, EW_ARGS) {
     EW_UNPACK
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;

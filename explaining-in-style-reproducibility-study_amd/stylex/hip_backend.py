@@ -84,6 +84,7 @@ SIGNATURES = {
                                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
+    "stylex_pad_rgb8": (ctypes.c_int, [_c_f, _c_f, _i64p, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_weight_sumsq": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_modcoeff_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_float, ctypes.c_void_p]),
@@ -455,6 +456,18 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, precision, in_scale=None, out_s
     _check(lib.stylex_conv2d_bwd_data(_ptr(dy), _ptr(wb), _ptr(dx), shp, flags, ctypes.byref(epi), precision,
                                       _ptr(ws), ws_bytes, _stream()), "stylex_conv2d_bwd_data")
     return dx
+
+
+def pad_rgb8(x):
+    """[B, 3, H, W] (any strides, fp32 or bf16) -> channels_last bf16 [B, 8, H, W] with channels 3..7 zero, one launch."""
+    lib = _ensure_device(x)
+    assert x.dim() == 4 and x.shape[1] == 3 and x.dtype in (torch.float32, torch.bfloat16)
+    b, _, h, w = x.shape
+    y = _empty((b, h, w, 8), dtype=torch.bfloat16, device=x.device)
+    shp = (ctypes.c_int64 * 3)(b, h, w)
+    st = (ctypes.c_int64 * 4)(*x.stride())
+    _check(lib.stylex_pad_rgb8(_ptr(x), _ptr(y), shp, st, int(x.dtype == torch.bfloat16), _stream()), "stylex_pad_rgb8")
+    return y.permute(0, 3, 1, 2)
 
 
 def _bf16_matrix(w, scale=None):

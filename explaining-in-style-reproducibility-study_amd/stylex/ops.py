@@ -614,13 +614,20 @@ class _DBlockFast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_res, b_res, w1, b1, w2, b2, w3, b3, downsample):
         c = 1 / math.sqrt(2)
-        x = _cl(_act(x))
         cin = x.shape[1]
-        if cin == 3:  # RGB input: pad to one 16-byte channel slot (see _pad_rgb); gradients are sliced back
+        if (cin == 3 and _PRECISION == hb.BF16_ACT and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+                and os.environ.get("STYLEX_PAD_RGB", "1") != "0"):
+            # RGB input, bf16 mode: cast + channels_last + zero-pad to one 16-byte channel slot in ONE pass
+            x = hb.pad_rgb8(x.detach())
+            w1p = torch.cat([w1, w1.new_zeros(w1.shape[0], 5, 3, 3)], dim=1)
+            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], 5, 1, 1)], dim=1)
+        elif cin == 3:  # RGB input: pad to one 16-byte channel slot (see _pad_rgb); gradients are sliced back
+            x = _cl(_act(x))
             x, w1p, _ = _pad_rgb(x, w1)
             x = _cl(x)
             wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], x.shape[1] - 3, 1, 1)], dim=1)
         else:
+            x = _cl(_act(x))
             w1p, wrp = w1, w_res
         # the 1x1 residual path (even-pixel gather + small GEMM) is independent of the two 3x3 convs until the merge:
         # companion HIP stream, joined before the kernel that merges

@@ -221,6 +221,11 @@ int stylex_bias_act_bwd(const void* dy, const void* y, void* dx, const int64_t* 
  * reduction per row block; deterministic. */
 int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void* stream);
 
+/* RGB input of the first DiscriminatorBlock (reference stylex_train.py:724-726 reads a 3-channel image): any strided
+ * [B][3][H][W] view (strides in ELEMENTS for b, c, h, w), fp32 or bf16 -> bf16 NHWC [B][H][W][8] with channels 3..7
+ * zero — the 16-byte slot the vector load paths of the conv kernels want — in one pass. */
+int stylex_pad_rgb8(const void* x, void* y, const int64_t* shape_bhw, const int64_t* strides_bchw, int x_is_bf16, void* stream);
+
 /* ---- modulated-conv coefficients (SURVEY §8(b) `demod_coeff` / `bwd_style`) --------------------
  * Conv2DMod.forward (reference stylex_train.py:650-656) in the batched form:
  *   s1[b][i] = style[b][i] + 1,   d[b][o] = rsqrt( sum_i s1[b][i]^2 * wsq[o][i] + eps ),

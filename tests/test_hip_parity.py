@@ -941,6 +941,21 @@ def test_modcoeff_kernels_vs_torch_composition(shape):
     close(r1, sd2.grad, 1e-6, "grad style via s1 only")
 
 
+def test_pad_rgb8_kernel_all_input_layouts():
+    """stylex_pad_rgb8: a 3-channel image in any of the layouts the Trainer hands to D / the encoder (fp32 NCHW from the
+    loader, fp32 channels_last, the bf16 3-of-4-channel view the generator returns) -> bf16 NHWC with 8 channels, the last
+    five zero; values are the RNE bf16 rounding of the input (bit-exact)."""
+    g = torch.Generator().manual_seed(3)
+    x32 = torch.randn(3, 3, 20, 28, generator=g).to(DEV)
+    four = torch.randn(3, 4, 20, 28, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    for name, x in (("fp32 nchw", x32), ("fp32 nhwc", x32.contiguous(memory_format=torch.channels_last)),
+                    ("bf16 view of 4-channel storage", four[:, :3]), ("fp32 transposed view", x32.transpose(2, 3).transpose(2, 3))):
+        y = hb.pad_rgb8(x)
+        assert y.shape == (3, 8, 20, 28) and y.dtype == torch.bfloat16 and hb.is_cl(y), name
+        assert torch.equal(y[:, :3], x.to(torch.bfloat16)), name
+        assert float(y[:, 3:].abs().max()) == 0.0, name
+
+
 PIPE_CASES = [
     # B, C, N, H, W
     (6, 64, 64, 64, 64),      # 32x32 px x 64 n tiles (N = 64), 4 chunks per tile, 24 tiles
