@@ -146,6 +146,7 @@ class _Staging:
     last copy has completed."""
     RING = 8
     _slots = {}
+    _upload_streams = {}
 
     @classmethod
     def take(cls, shape):
@@ -175,9 +176,26 @@ class _Staging:
         if device.type != "cuda":
             return fill(torch.empty(shape)).to(device)
         slot = cls.take(shape)
-        out = fill(slot[0]).to(device, non_blocking=True)
-        slot[1] = torch.cuda.Event()
-        slot[1].record()
+        if _capturing() or os.environ.get("STYLEX_UPLOAD_STREAM", "1") == "0":
+            out = fill(slot[0]).to(device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+            return out
+        # The copy goes to a dedicated upload stream: the host runs whole phases ahead of the GPU, so a copy enqueued
+        # on the compute stream sits behind that backlog and then executes IN ORDER between two kernels (0.35-0.4 ms
+        # per 8 MB noise plane, four per step, nothing else running); on its own stream the SDMA engine moves it while
+        # the compute kernels ahead of it are still running, and the consumer only waits for the (long finished) event.
+        cur = torch.cuda.current_stream(device)
+        up = cls._upload_streams.get(device)
+        if up is None:
+            up = cls._upload_streams[device] = torch.cuda.Stream(device)
+        host = fill(slot[0])
+        with torch.cuda.stream(up):
+            out = host.to(device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(up)
+        cur.wait_event(slot[1])
+        out.record_stream(cur)
         return out
 
 
@@ -189,6 +207,7 @@ def _release_staging_at_exit():
     except Exception:  # noqa: BLE001
         pass
     _Staging._slots.clear()
+    _Staging._upload_streams.clear()
 
 
 atexit.register(_release_staging_at_exit)
@@ -705,7 +724,21 @@ class Trainer:
     # ---- the hot path -------------------------------------------------------------------
 
     def _next_batch(self):
-        return next(self.loader).to(self.device, non_blocking=True)
+        batch = next(self.loader)
+        if batch.device == self.device or self.device.type != "cuda" or _capturing():
+            return batch.to(self.device, non_blocking=True)
+        # loader batches (pinned by the DataLoader) take the upload stream too, see _Staging.upload
+        cur = torch.cuda.current_stream(self.device)
+        up = _Staging._upload_streams.get(self.device)
+        if up is None:
+            up = _Staging._upload_streams[self.device] = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(up):
+            out = batch.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        cur.wait_event(ev)
+        out.record_stream(cur)
+        return out
 
     def _resolve_losses(self, raise_nan=True):
         """Wait for the pending loss copy of the last step (only that copy, not the stream) and publish the
