@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--top", type=int, default=60)
 ap.add_argument("--by-count", action="store_true", help="rank call sites by number of calls instead of device time")
+ap.add_argument("--by-func", action="store_true", help="aggregate per innermost package function (or autograd node) instead of per call chain")
 ap.add_argument("--warm", type=int, default=6, help="train() calls before the profiled one (8 -> the profiled call is a penalty step)")
 args = ap.parse_args()
 sys.argv = ["bench.py"]
@@ -50,9 +51,17 @@ for e in prof.events():
     site = "?"
     frames = [fr for fr in (e.stack or []) if fr.split("(")[0] in OURS]
     if frames:  # innermost package frames
-        site = " <- ".join(fr[:44] for fr in frames[:3])
-    elif e.stack:
-        site = "[autograd engine / other] " + e.stack[0][-60:]
+        site = " <- ".join(fr[:44] for fr in frames[:1 if args.by_func else 3])
+    else:
+        par, node = e.cpu_parent, None
+        while par is not None:  # an op issued by the autograd engine itself: name the node it runs under
+            if "evaluate_function" in par.name or par.name.endswith("Backward0") or "Backward" in par.name:
+                node = par.name
+            par = par.cpu_parent
+        if node:
+            site = "[engine] " + node[-70:]
+        elif e.stack:
+            site = "[other] " + e.stack[0][-60:]
     site_t[(site, e.name)] += dt
     site_n[(site, e.name)] += 1
 tot = sum(site_t.values())
@@ -61,6 +70,6 @@ SKIP = ("aten::conv2d", "aten::convolution_backward", "aten::batch_norm", "aten:
 order = sorted(site_t, key=lambda k: -site_n[k]) if args.by_count else [k for k, _ in site_t.most_common(args.top + 8)]
 for (site, name) in order[:args.top + 8]:
     t = site_t[(site, name)]
-    if name in SKIP:
+    if name in SKIP or (args.by_func and t <= 0):
         continue
     print("%8.1f us %5d  %-26s %s" % (t, site_n[(site, name)], name, site))
