@@ -1,0 +1,201 @@
+// frozen_ew.hip — the elementwise tail of the frozen classifier's conv layers (reference
+// stylex/resnet_classifier.py:29-71: a torchvision ResNet-18 in eval mode, weights without gradients).
+//
+// The convolutions of the classifier stay on the stock library (fp32, north_star); what runs between them does not have
+// to be four library launches per conv.  An eval-mode BatchNorm is the per-channel affine map y = x * s[c] + t[c]
+// (s = gamma / sqrt(var + eps), t = beta - mean * s), so `bn -> relu`, `bn -> (+ identity) -> relu` and the stem's
+// `bn -> relu -> maxpool(3, 2, 1)` are each ONE pass over the conv output here, with a first-order backward towards the
+// input image (the generated batch is classified with gradients, reference stylex_train.py:1452-1459).  HBM-bound fp32
+// NCHW streams: per step they were ~2.5 ms of library kernels (BatchNorm 60 launches, ReLU 51, add 24, max-pool 3+1,
+// threshold_backward 17, BatchNorm backward 20+20).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stylex_internal.h"
+
+namespace {
+
+// y = act(x * s[c] + t[c] (+ r)); V consecutive elements of one (b, c) plane per lane
+template <int V>
+__global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                             const float* __restrict__ t, const float* __restrict__ r,
+                                                             float* __restrict__ y, unsigned total_v, unsigned HW, unsigned C,
+                                                             int relu) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total_v; i += gridDim.x * 256u) {
+        const unsigned e = i * V;
+        const unsigned c = (e / HW) % C;
+        const float sc = s[c], sh = t[c];
+        float v[V], rr[V];
+        if (V == 4) {
+            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + e);
+            if (r) *reinterpret_cast<float4*>(rr) = *reinterpret_cast<const float4*>(r + e);
+        } else {
+            v[0] = x[e];
+            if (r) rr[0] = r[e];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float o = fmaf(v[k], sc, sh);
+            if (r) o += rr[k];
+            v[k] = relu ? fmaxf(o, 0.f) : o;
+        }
+        if (V == 4) *reinterpret_cast<float4*>(y + e) = *reinterpret_cast<float4*>(v);
+        else y[e] = v[0];
+    }
+}
+
+// gres = gy * [y > 0] (when relu), gx = gres * s[c]; gres may be null (no residual), gx may alias nothing else
+template <int V>
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                             const float* __restrict__ s, float* __restrict__ gx,
+                                                             float* __restrict__ gres, unsigned total_v, unsigned HW, unsigned C,
+                                                             int relu) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total_v; i += gridDim.x * 256u) {
+        const unsigned e = i * V;
+        const unsigned c = (e / HW) % C;
+        const float sc = s[c];
+        float g[V], yy[V], o[V];
+        if (V == 4) {
+            *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(gy + e);
+            if (relu) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + e);
+        } else {
+            g[0] = gy[e];
+            if (relu) yy[0] = y[e];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (relu && !(yy[k] > 0.f)) g[k] = 0.f;
+            o[k] = g[k] * sc;
+        }
+        if (V == 4) {
+            *reinterpret_cast<float4*>(gx + e) = *reinterpret_cast<float4*>(o);
+            if (gres) *reinterpret_cast<float4*>(gres + e) = *reinterpret_cast<float4*>(g);
+        } else {
+            gx[e] = o[0];
+            if (gres) gres[e] = g[0];
+        }
+    }
+}
+
+// y[b][c][oh][ow] = max over the 3x3 / stride-2 / pad-1 window of relu(x * s[c] + t[c]); idx = window-local position of
+// the maximum (row-major scan, first strict maximum — ATen's rule), 255 when the maximum is not positive (the ReLU then
+// blocks the gradient whichever element the pool would have picked).
+__global__ __launch_bounds__(256) void affine_relu_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                                      const float* __restrict__ t, float* __restrict__ y,
+                                                                      unsigned char* __restrict__ idx, unsigned total, int C,
+                                                                      int H, int W, int Ho, int Wo) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int ow = i % Wo, oh = (i / Wo) % Ho;
+        const unsigned plane = i / (Wo * Ho);
+        const int c = plane % C;
+        const float sc = s[c], sh = t[c];
+        const float* xp = x + (size_t)plane * H * W;
+        float best = -INFINITY;
+        int bi = 255;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = 2 * oh - 1 + kh;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = 2 * ow - 1 + kw;
+                if (w < 0 || w >= W) continue;
+                const float v = fmaf(xp[h * W + w], sc, sh);
+                if (v > best) {
+                    best = v;
+                    bi = kh * 3 + kw;
+                }
+            }
+        }
+        y[i] = fmaxf(best, 0.f);
+        if (idx) idx[i] = best > 0.f ? (unsigned char)bi : (unsigned char)255;
+    }
+}
+
+// gx[b][c][h][w] = s[c] * sum of gy over the (<= 4) windows whose recorded maximum is this element
+__global__ __launch_bounds__(256) void affine_relu_maxpool_bwd_kernel(const float* __restrict__ gy,
+                                                                      const unsigned char* __restrict__ idx,
+                                                                      const float* __restrict__ s, float* __restrict__ gx,
+                                                                      unsigned total, int C, int H, int W, int Ho, int Wo) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int w = i % W, h = (i / W) % H;
+        const unsigned plane = i / (W * H);
+        const int c = plane % C;
+        const float* gp = gy + (size_t)plane * Ho * Wo;
+        const unsigned char* ip = idx + (size_t)plane * Ho * Wo;
+        float acc = 0.f;
+        // windows oh with 2*oh - 1 <= h <= 2*oh + 1
+        const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;
+        for (int oh = oh0; oh <= oh1; ++oh) {
+            if (oh >= Ho) continue;
+            const int kh = h - (2 * oh - 1);
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                if (ow >= Wo) continue;
+                const int kw = w - (2 * ow - 1);
+                if (ip[oh * Wo + ow] == kh * 3 + kw) acc += gp[oh * Wo + ow];
+            }
+        }
+        gx[i] = acc * s[c];
+    }
+}
+
+inline unsigned grid_for(unsigned long n) {
+    unsigned long b = (n + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int stylex_affine_act_nchw_fwd(const float* x, const float* scale, const float* shift, const float* residual, float* y, int64_t B,
+                               int64_t C, int64_t HW, int relu, void* stream) {
+    if (!x || !scale || !shift || !y || B < 1 || C < 1 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
+    const unsigned long total = (unsigned long)(B * C * HW);
+    const bool v4 = HW % 4 == 0 && !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                      reinterpret_cast<uintptr_t>(residual)) & 15);
+    if (v4)
+        hipLaunchKernelGGL(affine_act_fwd_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                           residual, y, (unsigned)(total / 4), (unsigned)HW, (unsigned)C, relu);
+    else
+        hipLaunchKernelGGL(affine_act_fwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                           residual, y, (unsigned)total, (unsigned)HW, (unsigned)C, relu);
+    return (int)hipGetLastError();
+}
+
+int stylex_affine_act_nchw_bwd(const float* gy, const float* y, const float* scale, float* gx, float* gres, int64_t B, int64_t C,
+                               int64_t HW, int relu, void* stream) {
+    if (!gy || !scale || !gx || (relu && !y) || B < 1 || C < 1 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
+    const unsigned long total = (unsigned long)(B * C * HW);
+    const bool v4 = HW % 4 == 0 && !((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y) |
+                                      reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(gres)) & 15);
+    if (v4)
+        hipLaunchKernelGGL(affine_act_bwd_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, gy, y, scale, gx,
+                           gres, (unsigned)(total / 4), (unsigned)HW, (unsigned)C, relu);
+    else
+        hipLaunchKernelGGL(affine_act_bwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, gy, y, scale, gx,
+                           gres, (unsigned)total, (unsigned)HW, (unsigned)C, relu);
+    return (int)hipGetLastError();
+}
+
+int stylex_affine_relu_maxpool_fwd(const float* x, const float* scale, const float* shift, float* y, unsigned char* idx, int64_t B,
+                                   int64_t C, int64_t H, int64_t W, void* stream) {
+    if (!x || !scale || !shift || !y || B < 1 || C < 1 || H < 1 || W < 1 || B * C * H * W > 0x7fffffffLL) return STYLEX_EINVAL;
+    const int Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);  // floor((H + 2 - 3) / 2) + 1
+    const unsigned long total = (unsigned long)(B * C) * Ho * Wo;
+    hipLaunchKernelGGL(affine_relu_maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
+                       idx, (unsigned)total, (int)C, (int)H, (int)W, Ho, Wo);
+    return (int)hipGetLastError();
+}
+
+int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, const float* scale, float* gx, int64_t B, int64_t C,
+                                   int64_t H, int64_t W, void* stream) {
+    if (!gy || !idx || !scale || !gx || B < 1 || C < 1 || H < 1 || W < 1 || B * C * H * W > 0x7fffffffLL) return STYLEX_EINVAL;
+    const int Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);
+    const unsigned long total = (unsigned long)(B * C * H * W);
+    hipLaunchKernelGGL(affine_relu_maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, gy, idx, scale, gx,
+                       (unsigned)total, (int)C, (int)H, (int)W, Ho, Wo);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

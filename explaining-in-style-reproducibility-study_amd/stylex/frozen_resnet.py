@@ -8,8 +8,10 @@ stock PyTorch module.  The 7x7 stem, max-pool, average pool and the linear head 
 FLOPs).
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
+import hip_backend as hb
 import ops
 
 
@@ -69,4 +71,97 @@ class HipFrozenResNet(nn.Module):
         finally:
             ops.set_fast(prev)
         x = x.float()
+        return m.fc(torch.flatten(m.avgpool(x), 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Default on the GPU: library convolutions (fp32, untouched) + fused elementwise tails (csrc/frozen_ew.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+
+
+def _affine(bn):
+    """(scale, shift) with bn(x) == x * scale[c] + shift[c] for an eval-mode BatchNorm (fp32, like ATen's own
+    batch_norm_elementwise: invstd = 1 / sqrt(var + eps))."""
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
+    shift = (bn.bias - bn.running_mean * scale).detach().float().contiguous()
+    return scale, shift
+
+
+class _AffineAct(torch.autograd.Function):
+    """act(x * scale[c] + shift[c] (+ residual)): `bn -> relu` / `bn -> (+ identity) -> relu` of a BasicBlock
+    (torchvision resnet.py BasicBlock.forward) in one pass; first-order backward to x and the residual."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        y = hb.affine_act_fwd(x, scale, shift, residual, relu)
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        y, scale = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        want_res = has_res and ctx.needs_input_grad[3]
+        gx, gres = hb.affine_act_bwd(gy.contiguous(), y, scale, relu, want_res)
+        return (gx if ctx.needs_input_grad[0] else None), None, None, gres, None
+
+
+class _AffineReluPool(torch.autograd.Function):
+    """maxpool(3, 2, 1)(relu(x * scale[c] + shift[c])): the stem of the ResNet after conv1 in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        y, idx = hb.affine_relu_maxpool_fwd(x, scale, shift, want_idx=x.requires_grad)
+        ctx.save_for_backward(idx, scale)
+        ctx.in_hw = tuple(x.shape[2:])
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        idx, scale = ctx.saved_tensors
+        return hb.affine_relu_maxpool_bwd(gy.contiguous(), idx, scale, ctx.in_hw), None, None
+
+
+class FusedTailResNet(nn.Module):
+    """The frozen eval-mode ResNet with its convolutions exactly as before (F.conv2d on the module's own fp32 weights)
+    and every BatchNorm / ReLU / residual add / max-pool between them on the fused fp32 kernels."""
+
+    def __init__(self, model):
+        super().__init__()
+        assert not model.training, "the classifier must be in eval mode (BatchNorm as an affine map)"
+        self.model = model
+        self.aff = {}
+        for name, mod in model.named_modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                self.aff[name] = _affine(mod)
+
+    @staticmethod
+    def supports(model):
+        if not HipFrozenResNet.supports(model):
+            return False
+        mp = model.maxpool
+        as2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)  # noqa: E731
+        return (as2(mp.kernel_size), as2(mp.stride), as2(mp.padding), as2(mp.dilation), mp.ceil_mode) == (
+            (3, 3), (2, 2), (1, 1), (1, 1), False) and all(p.dtype == torch.float32 for p in model.parameters())
+
+    @staticmethod
+    def _conv(x, conv):
+        return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+    def forward(self, x):
+        m = self.model
+        x = x.float().contiguous()
+        x = _AffineReluPool.apply(self._conv(x, m.conv1).contiguous(), *self.aff["bn1"])
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(m, "layer%d" % li)):
+                pre = "layer%d.%d." % (li, bi)
+                idt = x
+                if blk.downsample is not None:
+                    idt = _AffineAct.apply(self._conv(x, blk.downsample[0]).contiguous(), *self.aff[pre + "downsample.1"],
+                                           None, False)
+                out = _AffineAct.apply(self._conv(x, blk.conv1).contiguous(), *self.aff[pre + "bn1"], None, True)
+                x = _AffineAct.apply(self._conv(out, blk.conv2).contiguous(), *self.aff[pre + "bn2"], idt, True)
         return m.fc(torch.flatten(m.avgpool(x), 1))

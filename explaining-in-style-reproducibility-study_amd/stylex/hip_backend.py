@@ -85,6 +85,14 @@ SIGNATURES = {
     "stylex_scale_reduce": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p]),
     "stylex_pad_rgb8": (ctypes.c_int, [_c_f, _c_f, _i64p, _i64p, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_affine_act_nchw_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_int, ctypes.c_void_p]),
+    "stylex_affine_act_nchw_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_int, ctypes.c_void_p]),
+    "stylex_affine_relu_maxpool_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64,
+                                                      ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_affine_relu_maxpool_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                      ctypes.c_int64, ctypes.c_void_p]),
     "stylex_weight_sumsq": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_modcoeff_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_float, ctypes.c_void_p]),
@@ -273,6 +281,24 @@ def _cache_put(key, w_param, wf, wb):
     ev = torch.cuda.Event()
     ev.record()
     _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream)
+
+
+def scaled_linear_params(w, b, lr_mul):
+    """(w * lr_mul, b * lr_mul) of an equalised-learning-rate linear layer (EqualLinear.forward, reference
+    :585-586), cached until the optimiser modifies the parameters: the mapping network runs 2-4 times per step on the
+    same weights, and each run used to issue the two multiplies again (8 layers x 2 launches per run)."""
+    _ensure_device(w)
+    key = ("eql", w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(w.shape), float(lr_mul))
+    cacheable = isinstance(w, torch.nn.Parameter)
+    hit = _cache_hit(key, w) if cacheable else None
+    if hit is not None:
+        return hit
+    with torch.no_grad():
+        ws = w.detach() * lr_mul
+        bs = None if b is None else b.detach() * lr_mul
+    if cacheable:
+        _cache_put(key, w, ws, bs)
+    return ws, bs
 
 
 def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
@@ -468,6 +494,52 @@ def pad_rgb8(x):
     st = (ctypes.c_int64 * 4)(*x.stride())
     _check(lib.stylex_pad_rgb8(_ptr(x), _ptr(y), shp, st, int(x.dtype == torch.bfloat16), _stream()), "stylex_pad_rgb8")
     return y.permute(0, 3, 1, 2)
+
+
+def _dense_f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), "the frozen-classifier kernels take dense fp32 NCHW tensors"
+    return t
+
+
+def affine_act_fwd(x, scale, shift, residual=None, relu=True):
+    """act(x * scale[c] + shift[c] (+ residual)) on a dense fp32 NCHW tensor, one pass (stylex_affine_act_nchw_fwd)."""
+    lib = _ensure_device(x)
+    b, c, h, w = _dense_f32(x).shape
+    y = torch.empty_like(x)
+    _check(lib.stylex_affine_act_nchw_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(_dense_f32(residual)) if residual is not None
+                                          else None, _ptr(y), b, c, h * w, int(relu), _stream()), "stylex_affine_act_nchw_fwd")
+    return y
+
+
+def affine_act_bwd(gy, y, scale, relu=True, want_res=False):
+    lib = _ensure_device(gy)
+    b, c, h, w = _dense_f32(gy).shape
+    gx = torch.empty_like(gy)
+    gres = torch.empty_like(gy) if want_res else None
+    _check(lib.stylex_affine_act_nchw_bwd(_ptr(gy), _ptr(y) if relu else None, _ptr(scale), _ptr(gx),
+                                          _ptr(gres) if want_res else None, b, c, h * w, int(relu), _stream()),
+           "stylex_affine_act_nchw_bwd")
+    return gx, gres
+
+
+def affine_relu_maxpool_fwd(x, scale, shift, want_idx):
+    lib = _ensure_device(x)
+    b, c, h, w = _dense_f32(x).shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((b, c, ho, wo), dtype=torch.float32, device=x.device)
+    idx = torch.empty((b, c, ho, wo), dtype=torch.uint8, device=x.device) if want_idx else None
+    _check(lib.stylex_affine_relu_maxpool_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(idx) if want_idx else None,
+                                              b, c, h, w, _stream()), "stylex_affine_relu_maxpool_fwd")
+    return y, idx
+
+
+def affine_relu_maxpool_bwd(gy, idx, scale, in_hw):
+    lib = _ensure_device(gy)
+    b, c = _dense_f32(gy).shape[:2]
+    gx = torch.empty((b, c, in_hw[0], in_hw[1]), dtype=torch.float32, device=gy.device)
+    _check(lib.stylex_affine_relu_maxpool_bwd(_ptr(gy), _ptr(idx), _ptr(scale), _ptr(gx), b, c, in_hw[0], in_hw[1], _stream()),
+           "stylex_affine_relu_maxpool_bwd")
+    return gx
 
 
 def _bf16_matrix(w, scale=None):

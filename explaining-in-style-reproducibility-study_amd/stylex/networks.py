@@ -121,7 +121,17 @@ class StyleVectorizer(nn.Module):  # reference :590-601
         self.net = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.net(F.normalize(x, dim=1))
+        x = F.normalize(x, dim=1)
+        mods, i = list(self.net), 0
+        while i < len(mods):  # EqualLinear + LeakyReLU pairs run as one fused node (ops.equal_linear)
+            m = mods[i]
+            if isinstance(m, EqualLinear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                x = ops.equal_linear(x, m.weight, getattr(m, "bias", None), m.lr_mul, mods[i + 1].negative_slope)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class Conv2DMod(nn.Module):  # reference :632-667

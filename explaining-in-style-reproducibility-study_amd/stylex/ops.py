@@ -26,6 +26,7 @@ import math
 import os
 
 import torch
+import torch.nn.functional as F
 
 import hip_backend as hb
 
@@ -712,7 +713,7 @@ class _DBlockFast(torch.autograd.Function):
         alg = downsample and prec != hb.F32
         if alg:
             gz3 = g_out
-            gsum3 = _channel_sum(g_out) * c if want_b else None
+            gsum3 = _channel_sum(g_out) if want_b else None  # its 1/sqrt(2) rides the multi-tensor multiply below
         elif _reducible(g_out.shape[1]):
             gz3, gsum3 = hb.act_bwd_reduce(g_out, None, False, c, want_dx=True, want_sum=want_b)
         else:
@@ -743,8 +744,6 @@ class _DBlockFast(torch.autograd.Function):
                 s_gw = s_gx = None
                 if want_w:
                     s_gw = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec)
-                    if alg:
-                        s_gw = s_gw * wsc
                 if want_x:
                     s_gx = res_dgrad()
                 side_out = (s_gw, s_gx)
@@ -767,8 +766,6 @@ class _DBlockFast(torch.autograd.Function):
                 if want_w:
                     gw3 = hb.conv2d_bwd_weight(xb, gz3, tuple(w3.shape), 2, 1, prec)
                 gz2 = hb.blur3x3_bwd_gate(gxb, y2)
-            if want_w and alg:
-                gw3 = gw3 * wsc
         else:
             gz2 = hb.bias_act_bwd(gz3, y2)
         # bias gradients = per-channel sums of gz2 / gz1: taken from the weight-gradient kernel (which stages those
@@ -799,10 +796,10 @@ class _DBlockFast(torch.autograd.Function):
         else:
             if want_w:
                 gw_res = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec)
-                if alg:
-                    gw_res = gw_res * wsc
             if want_x:
                 gxs = res_dgrad()
+        if alg and (want_w or want_b):  # the 1/sqrt(2) owed by the gradients computed from the unscaled gz3: one launch
+            torch._foreach_mul_([t for t in (gw_res, gw3, gsum3) if t is not None], wsc)
         if want_w and cin == 3:
             gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
         if want_x:
@@ -994,6 +991,48 @@ def use_impl(impl):
 
 def impl():
     return _IMPL
+
+
+class _EqualLinearFast(torch.autograd.Function):
+    """lrelu(x @ (W * lr_mul)^T + b * lr_mul) — one EqualLinear (+ LeakyReLU) of the mapping network (reference
+    :576-601) as one autograd node: the scaled parameters come from a per-version cache, forward = one addmm + one
+    in-place LeakyReLU, backward = activation derivative, two GEMMs, one scale, one column sum (the ATen composition
+    was 4-5 launches forward and 8-9 backward per layer).  First-order only: the mapping network is never
+    differentiated twice (the path-length penalty differentiates G with respect to its styles, reference :306-316)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lr_mul, slope):
+        ws, bs = hb.scaled_linear_params(w, b, lr_mul)
+        y = torch.addmm(bs, x, ws.t()) if bs is not None else torch.mm(x, ws.t())
+        if slope is not None:
+            y = F.leaky_relu_(y, slope)
+        ctx.save_for_backward(x, ws, y if slope is not None else None)
+        ctx.cfg = (lr_mul, slope, b is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, ws, y = ctx.saved_tensors
+        lr_mul, slope, has_b = ctx.cfg
+        if y is not None:
+            g = torch.ops.aten.leaky_relu_backward(g, y, slope, True)
+        gx = torch.mm(g, ws) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            gs = g * lr_mul  # d(W * lr_mul) / dW: scale the (small) activation gradient once instead of both results
+            gw = torch.mm(gs.t(), x) if ctx.needs_input_grad[1] else None
+            gb = gs.sum(0) if has_b and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None
+
+
+def equal_linear(x, weight, bias, lr_mul, slope=None):
+    """EqualLinear (+ LeakyReLU(slope)) on the fused node when first-order gradients suffice, else the composition."""
+    if (_IMPL is HipOps and x.is_cuda and x.dim() == 2 and fast_enabled() and x.dtype == torch.float32
+            and os.environ.get("STYLEX_EQL", "1") != "0"):
+        return _EqualLinearFast.apply(x, weight, bias, lr_mul, slope)
+    y = F.linear(x, weight * lr_mul, bias=None if bias is None else bias * lr_mul)
+    return y if slope is None else F.leaky_relu(y, slope)
 
 
 class _ModCoeffs(torch.autograd.Function):

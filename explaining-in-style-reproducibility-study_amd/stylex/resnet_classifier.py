@@ -61,8 +61,18 @@ class ResNet:
         (frozen_resnet.py; exact in 'fp32' mode, +2.8 % step throughput in 'bf16' mode — but a bf16 ReLU network's
         INPUT GRADIENT was measured 20 % off in the L2 sense (D's own LeakyReLU chain: 1.5 %), too noisy a
         classifier signal to be the default)."""
-        if not x.is_cuda or os.environ.get("STYLEX_FROZEN_HIP", "0") != "1":
+        if not x.is_cuda:
             return self.model
+        if os.environ.get("STYLEX_FROZEN_HIP", "0") != "1":
+            # default: the library's fp32 convolutions, everything between them (eval BatchNorm, ReLU, residual add,
+            # max-pool) on the fused fp32 kernels of csrc/frozen_ew.hip; STYLEX_FROZEN_FUSE=0 = the plain nn.Module
+            if os.environ.get("STYLEX_FROZEN_FUSE", "1") == "0":
+                return self.model
+            if getattr(self, "_fused", None) is None:
+                from frozen_resnet import FusedTailResNet
+
+                self._fused = FusedTailResNet(self.model) if FusedTailResNet.supports(self.model) else self.model
+            return self._fused
         if getattr(self, "_hip", None) is None:
             from frozen_resnet import HipFrozenResNet
 

@@ -226,6 +226,27 @@ int stylex_rowwise_sumsq(const float* x, float* out, const int64_t* shape, void*
  * zero — the 16-byte slot the vector load paths of the conv kernels want — in one pass. */
 int stylex_pad_rgb8(const void* x, void* y, const int64_t* shape_bhw, const int64_t* strides_bchw, int x_is_bf16, void* stream);
 
+/* ---- elementwise tail of the frozen classifier's conv layers ------------------------------------
+ * The classifier (reference stylex/resnet_classifier.py:29-71, a torchvision ResNet-18 in eval mode) keeps its
+ * convolutions on the stock library; an eval-mode BatchNorm is the affine map y = x * scale[c] + shift[c]
+ * (scale = gamma / sqrt(var + eps), shift = beta - mean * scale), so BasicBlock's `bn -> relu` and
+ * `bn -> (+ identity) -> relu` are one pass each, and the stem's `bn -> relu -> maxpool(3, 2, 1)` is one pass.
+ * Dense fp32 NCHW tensors, [B][C][HW]; scale / shift [C].  `residual`, `gres`, `idx` may be NULL.
+ *   fwd:  y = act(x * scale[c] + shift[c] + residual),  act = relu when `relu` != 0
+ *   bwd:  gres = gy * [y > 0] (all of gy without relu),  gx = gres * scale[c]
+ *   maxpool fwd: y[oh][ow] = max_{3x3 window, stride 2, pad 1} relu(x * scale[c] + shift[c]);  idx = window-local
+ *        position (kh * 3 + kw) of the first strict maximum in row-major order (ATen's rule), 255 where the maximum
+ *        is not positive;  Ho = (H - 1) / 2 + 1
+ *   maxpool bwd: gx[h][w] = scale[c] * sum of gy over the windows whose idx names (h, w)   (a gather: deterministic) */
+int stylex_affine_act_nchw_fwd(const float* x, const float* scale, const float* shift, const float* residual, float* y, int64_t B,
+                               int64_t C, int64_t HW, int relu, void* stream);
+int stylex_affine_act_nchw_bwd(const float* gy, const float* y, const float* scale, float* gx, float* gres, int64_t B, int64_t C,
+                               int64_t HW, int relu, void* stream);
+int stylex_affine_relu_maxpool_fwd(const float* x, const float* scale, const float* shift, float* y, unsigned char* idx, int64_t B,
+                                   int64_t C, int64_t H, int64_t W, void* stream);
+int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, const float* scale, float* gx, int64_t B, int64_t C,
+                                   int64_t H, int64_t W, void* stream);
+
 /* ---- modulated-conv coefficients (SURVEY §8(b) `demod_coeff` / `bwd_style`) --------------------
  * Conv2DMod.forward (reference stylex_train.py:650-656) in the batched form:
  *   s1[b][i] = style[b][i] + 1,   d[b][o] = rsqrt( sum_i s1[b][i]^2 * wsq[o][i] + eps ),

@@ -4,6 +4,8 @@ oracle and the golden vectors captured from the reference.
 Tolerances (stated per north_star): fp32 mode 2e-5 relative to the tensor's max-abs (only the
 summation order differs: v_mfma_f32_32x32x2_f32 is an fmaf chain); bf16 mode 3e-2 (operands
 rounded to bf16, fp32 accumulate); resampling index arithmetic is exact, values to 1e-6."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -939,6 +941,146 @@ def test_modcoeff_kernels_vs_torch_composition(shape):
     finally:
         ops.set_fast(prev)
     close(r1, sd2.grad, 1e-6, "grad style via s1 only")
+
+
+def test_mapping_network_fused_node_vs_reference_composition():
+    """StyleVectorizer (reference :590-601) on the fused EqualLinear+LeakyReLU node with cached scaled parameters, and
+    latent_to_w mapping the two latents of a style-mixing step in one pass: values and all parameter / input gradients
+    against the float64 composition F.linear(x, W * lr_mul, b * lr_mul) -> leaky_relu; the cache follows in-place
+    parameter updates."""
+    import networks
+    import stylex_train as st
+
+    torch.manual_seed(11)
+    S = networks.StyleVectorizer(66, 3, lr_mul=0.1).to(DEV)
+    with torch.no_grad():
+        for p in S.parameters():
+            p.add_(torch.randn_like(p) * 0.3)
+    z1, z2 = torch.randn(5, 66, device=DEV, requires_grad=True), torch.randn(5, 66, device=DEV, requires_grad=True)
+    r = torch.randn(10, 66, device=DEV)
+
+    def reference(z):
+        x = torch.nn.functional.normalize(z.double(), dim=1)
+        for m in S.net:
+            if isinstance(m, networks.EqualLinear):
+                x = torch.nn.functional.linear(x, m.weight.double() * m.lr_mul, m.bias.double() * m.lr_mul)
+            else:
+                x = torch.nn.functional.leaky_relu(x, 0.2)
+        return x
+
+    for rep in range(2):  # second round: after an in-place parameter update (stale cache = wrong values)
+        want = torch.cat((reference(z1), reference(z2)))
+        gref = torch.autograd.grad((want * r.double()).sum(), [z1, z2] + list(S.parameters()))
+        prev = ops.set_fast(True)
+        try:
+            (w1, n1), (w2, n2) = st.latent_to_w(S, [(z1, 3), (z2, 4)])
+            assert (n1, n2) == (3, 4)
+            fn, kinds = w1.grad_fn, set()
+            while fn is not None:  # split <- fused layer 3 <- fused layer 2 <- ...
+                kinds.add(type(fn).__name__)
+                fn = fn.next_functions[0][0] if fn.next_functions else None
+            assert "_EqualLinearFastBackward" in kinds, "the fused node must serve the fast path: %s" % kinds
+            got = torch.cat((w1, w2))
+            ggot = torch.autograd.grad((got * r).sum(), [z1, z2] + list(S.parameters()))
+        finally:
+            ops.set_fast(prev)
+        close(want, got, 2e-6, "mapping network output (round %d)" % rep)
+        for a, b, nm in zip(gref, ggot, ["z1", "z2"] + [n for n, _ in S.named_parameters()]):
+            close(a, b, 2e-5, "grad " + nm)
+        with torch.no_grad():
+            for p in S.parameters():
+                p.mul_(1.1)
+    # outside the fast mode the differentiable composition serves (same values)
+    assert ops.fast_enabled() is False
+    close(reference(z1), S(z1), 2e-6, "composition path")
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 7), (2, 8, 12, 10), (4, 3, 9, 13)])
+def test_frozen_tail_kernels_vs_aten(shape):
+    """csrc/frozen_ew.hip against the ATen ops they replace in the frozen classifier: eval BatchNorm (as an affine map)
+    -> (+ residual) -> ReLU, and BatchNorm -> ReLU -> MaxPool2d(3, 2, 1); values, input / residual gradients, odd sizes
+    (scalar path: H*W % 4 != 0) and windows clipped by the border.  Ties inside a pooling window (incl. all-negative
+    windows) follow ATen's first-maximum rule."""
+    from frozen_resnet import _AffineAct, _AffineReluPool
+
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 31 + w)
+    x = torch.randn(b, c, h, w, generator=g)
+    x[:, :, : h // 2] = torch.round(x[:, :, : h // 2] * 2) / 2  # many exact ties and many all-negative windows
+    res = torch.randn(b, c, h, w, generator=g)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    sc[0] = -sc[0]  # a negative BatchNorm scale flips the order inside the pooling window
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    aff = xr * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    y_ref = torch.relu(aff + rr)
+    p_ref = torch.nn.functional.max_pool2d(torch.relu(aff), 3, 2, 1)
+    gy, gp = torch.randn(y_ref.shape, generator=g), torch.randn(p_ref.shape, generator=g)
+    gxa, gra = torch.autograd.grad((y_ref * gy).sum(), [xr, rr], retain_graph=True)
+    gxp, = torch.autograd.grad((p_ref * gp).sum(), [xr])
+    xd, rd = x.to(DEV).requires_grad_(), res.to(DEV).requires_grad_()
+    y = _AffineAct.apply(xd, sc.to(DEV), sh.to(DEV), rd, True)
+    gxd, grd = torch.autograd.grad((y * gy.to(DEV)).sum(), [xd, rd])
+    close(y_ref, y, 1e-6, "affine + residual + relu")
+    close(gxa, gxd, 1e-6, "its input gradient")
+    close(gra, grd, 1e-6, "its residual gradient")
+    y2 = _AffineAct.apply(xd, sc.to(DEV), sh.to(DEV), None, False)  # downsample branch: no residual, no relu
+    close(aff, y2, 1e-6, "affine only")
+    close(gy * sc.view(1, -1, 1, 1), torch.autograd.grad((y2 * gy.to(DEV)).sum(), [xd])[0], 1e-6, "affine-only gradient")
+    p = _AffineReluPool.apply(xd, sc.to(DEV), sh.to(DEV))
+    close(p_ref, p, 1e-6, "affine + relu + maxpool")
+    close(gxp, torch.autograd.grad((p * gp.to(DEV)).sum(), [xd])[0], 1e-6, "its input gradient")
+    with torch.no_grad():  # no index plane without a gradient consumer
+        close(p_ref, _AffineReluPool.apply(x.to(DEV), sc.to(DEV), sh.to(DEV)), 1e-6, "affine + relu + maxpool (no grad)")
+
+
+def test_frozen_classifier_fused_tails_match_plain_module():
+    """ResNet.classify_images (reference resnet_classifier.py:57-71) with the fused elementwise tails (default on the
+    GPU) against the plain nn.Module (STYLEX_FROZEN_FUSE=0): logits and the gradient reaching the images, fp32, the
+    same library convolutions on both sides (tolerance = the rounding of bn(x) as x * s + t)."""
+    import resnet_classifier as rc
+
+    clf = rc.ResNet(None, 0, output_size=2, image_size=64)
+    with torch.no_grad():  # non-trivial BatchNorm statistics
+        for m in clf.model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    torch.manual_seed(3)
+    img = torch.rand(4, 3, 64, 64, device=DEV)
+    coef = torch.tensor([[1.0, -2.0]])
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["STYLEX_FROZEN_FUSE"] = mode
+        try:
+            x = img.clone().requires_grad_()
+            logits = clf.classify_images(x)
+            gx, = torch.autograd.grad((logits * coef.to(DEV)).sum(), [x])
+            outs[mode] = (logits.detach().double().cpu(), gx.double().cpu())
+        finally:
+            os.environ.pop("STYLEX_FROZEN_FUSE", None)
+    assert type(clf._net(img)).__name__ == "FusedTailResNet", "the fused tails must be the default on the GPU"
+    # ground truth: the same module in float64 on the CPU.  An fp32 rounding difference can flip the gate of a ReLU
+    # whose input is ~0, which moves the image gradient far more than the rounding itself — so the fused path is held
+    # to the error the PLAIN fp32 module shows against float64, not to a rounding-sized bound against the plain module
+    import copy
+
+    m64 = copy.deepcopy(clf.model).double().cpu()
+    x64 = img.double().cpu().requires_grad_()
+    xin = F.interpolate(x64, size=[224, 224], mode="bilinear", align_corners=False)
+    xin = (xin - clf._mean.double().cpu()) / clf._std.double().cpu()
+    l64 = m64(xin)
+    g64, = torch.autograd.grad((l64 * coef.double()).sum(), [x64])
+
+    def rel(a, ref):
+        return ((a - ref).norm() / ref.norm()).item()
+
+    e_plain = (rel(outs["0"][0], l64.detach()), rel(outs["0"][1], g64))
+    e_fused = (rel(outs["1"][0], l64.detach()), rel(outs["1"][1], g64))
+    assert e_fused[0] <= max(3 * e_plain[0], 2e-6), ("logits", e_fused, e_plain)
+    assert e_fused[1] <= max(3 * e_plain[1], 2e-5), ("image gradient", e_fused, e_plain)
+    close(outs["0"][0], outs["1"][0].float(), 2e-5, "logits")
 
 
 def test_pad_rgb8_kernel_all_input_layouts():

@@ -6,6 +6,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 fam = {}
 def family(n):
+    if "conv3x3_pipe" in n: return "pipelined fwd/dgrad"
+    if "conv_gather" in n: return "gather fwd/dgrad (<= 8 px)"
+    if "conv3x3_rgb" in n: return "rgb first layer"
+    if "modcoeff" in n or "wsq_kernel" in n: return "modulation coefficients"
     if "conv3x3_halo" in n: return "halo fwd/dgrad"
     if "wgrad_halo" in n: return "halo wgrad"
     if "conv_igemm" in n: return "igemm v1 fwd/dgrad"
