@@ -93,6 +93,10 @@ SIGNATURES = {
                                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_affine_relu_maxpool_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_lpips_tap_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_lpips_tap_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_void_p]),
     "stylex_weight_sumsq": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_modcoeff_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_float, ctypes.c_void_p]),
@@ -540,6 +544,35 @@ def affine_relu_maxpool_bwd(gy, idx, scale, in_hw):
     _check(lib.stylex_affine_relu_maxpool_bwd(_ptr(gy), _ptr(idx), _ptr(scale), _ptr(gx), b, c, in_hw[0], in_hw[1], _stream()),
            "stylex_affine_relu_maxpool_bwd")
     return gx
+
+
+def lpips_taps_fwd(f0s, f1s, lins, keep_norms):
+    """sum over the taps of mean_p sum_c lin[c] (n0 - n1)^2  ->  ([B] distances, saved per-pixel norms)."""
+    lib = _ensure_device(f0s[0])
+    b = f0s[0].shape[0]
+    blocks = [(f.shape[2] * f.shape[3] + 255) // 256 for f in f0s]
+    partial = torch.empty((b, sum(blocks)), dtype=torch.float32, device=f0s[0].device)
+    norms, off = [], 0
+    for f0, f1, lin, nb in zip(f0s, f1s, lins, blocks):
+        _, c, h, w = _dense_f32(f0).shape
+        assert _dense_f32(f1).shape == f0.shape and lin.numel() == c
+        r0 = torch.empty((b, h * w), dtype=torch.float32, device=f0.device) if keep_norms else None
+        r1 = torch.empty_like(r0) if keep_norms else None
+        _check(lib.stylex_lpips_tap_fwd(_ptr(f0), _ptr(f1), _ptr(lin), ctypes.c_void_p(partial.data_ptr() + 4 * off), _ptr(r0),
+                                        _ptr(r1), b, c, h * w, partial.shape[1], _stream()), "stylex_lpips_tap_fwd")
+        norms.append((r0, r1))
+        off += nb
+    return partial.sum(dim=1), norms
+
+
+def lpips_tap_bwd(f0, f1, lin, r0, r1, gout, want0, want1):
+    lib = _ensure_device(f0)
+    b, c, h, w = f0.shape
+    g0 = torch.empty_like(f0) if want0 else None
+    g1 = torch.empty_like(f1) if want1 else None
+    _check(lib.stylex_lpips_tap_bwd(_ptr(f0), _ptr(f1), _ptr(lin), _ptr(r0), _ptr(r1), _ptr(gout), _ptr(g0), _ptr(g1), b, c, h * w,
+                                    _stream()), "stylex_lpips_tap_bwd")
+    return g0, g1
 
 
 def _bf16_matrix(w, scale=None):

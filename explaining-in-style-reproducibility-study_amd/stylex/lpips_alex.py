@@ -13,6 +13,8 @@ package (``net.slice*.N.weight`` / ``lin*.model.1.weight``).  Offline there is n
 way to fetch them, so by default seeded random weights of the published shapes
 are drawn (recorded as "parity unpinned" in DESIGN.md).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -57,9 +59,47 @@ class LPIPS(nn.Module):
     def forward(self, in0, in1):
         f0 = self._taps((in0 - self.shift) / self.scale)
         f1 = self._taps((in1 - self.shift) / self.scale)
+        if in0.is_cuda and f0[0].dtype == torch.float32 and os.environ.get("STYLEX_LPIPS_FUSE", "1") != "0":
+            # normalise / difference / 1x1 lin / spatial mean of all five taps: one kernel per tap (csrc/frozen_ew.hip)
+            lins = [w.reshape(-1) for w in self.lin]
+            return _LpipsDistance.apply(len(f0), *lins, *f0, *f1).view(-1, 1, 1, 1)
         total = 0
         for i in range(len(_ALEX)):
             n0 = f0[i] / (f0[i].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
             n1 = f1[i] / (f1[i].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
             total = total + F.conv2d((n0 - n1) ** 2, self.lin[i]).mean(dim=(2, 3), keepdim=True)
         return total
+
+
+class _LpipsDistance(torch.autograd.Function):
+    """sum over taps of spatial_average(lin(normalize(f0) - normalize(f1))^2) (lpips.py forward) on the fused
+    kernels; first-order gradients to the feature maps that require them (the lin weights are frozen)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        import hip_backend as hb
+
+        lins, f0s, f1s = args[:n], [t.contiguous() for t in args[n:2 * n]], [t.contiguous() for t in args[2 * n:]]
+        need = any(t.requires_grad for t in args[n:])
+        out, norms = hb.lpips_taps_fwd(f0s, f1s, lins, keep_norms=need)
+        ctx.n = n
+        if need:
+            ctx.save_for_backward(*lins, *f0s, *f1s, *[r for pair in norms for r in pair])
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        import hip_backend as hb
+
+        n, sv = ctx.n, ctx.saved_tensors
+        lins, f0s, f1s, rs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:]
+        gout = gout.contiguous().float()
+        g0s, g1s = [], []
+        for i in range(n):
+            w0, w1 = ctx.needs_input_grad[1 + n + i], ctx.needs_input_grad[1 + 2 * n + i]
+            g0, g1 = (None, None) if not (w0 or w1) else hb.lpips_tap_bwd(f0s[i], f1s[i], lins[i], rs[2 * i], rs[2 * i + 1],
+                                                                          gout, w0, w1)
+            g0s.append(g0)
+            g1s.append(g1)
+        return (None,) + (None,) * n + tuple(g0s) + tuple(g1s)

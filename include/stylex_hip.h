@@ -247,6 +247,18 @@ int stylex_affine_relu_maxpool_fwd(const float* x, const float* scale, const flo
 int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, const float* scale, float* gx, int64_t B, int64_t C,
                                    int64_t H, int64_t W, void* stream);
 
+/* ---- LPIPS distance of one feature tap -----------------------------------------------------------
+ * reconstruction_loss (reference stylex_train.py:404-438) calls lpips.LPIPS(net='alex') (lpips 0.1.4): per tap
+ *   n = f / (sqrt(sum_c f^2) + 1e-10),  d[b][p] = sum_c lin[c] * (n0 - n1)^2,  out[b] = mean_p d[b][p].
+ * f0, f1: dense fp32 [B][C][HW]; lin [C].  fwd writes per-block sums of d / HW to partial[b * partial_stride + block],
+ * block = 0 .. ceil(HW / 256) - 1 (the caller adds them up, over all taps at once, in fixed order) and the per-pixel
+ * norms sqrt(sum_c f^2) to r0 / r1 [B][HW] (NULL = not kept).  bwd: g0 / g1 (either may be NULL) = gout[b] * d out[b] / d f,
+ * the chain rule through both normalisations; an all-zero pixel yields NaN exactly like the reference's sqrt backward. */
+int stylex_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* partial, float* r0, float* r1, int64_t B,
+                         int64_t C, int64_t HW, int64_t partial_stride, void* stream);
+int stylex_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* r0, const float* r1, const float* gout,
+                         float* g0, float* g1, int64_t B, int64_t C, int64_t HW, void* stream);
+
 /* ---- modulated-conv coefficients (SURVEY §8(b) `demod_coeff` / `bwd_style`) --------------------
  * Conv2DMod.forward (reference stylex_train.py:650-656) in the batched form:
  *   s1[b][i] = style[b][i] + 1,   d[b][o] = rsqrt( sum_i s1[b][i]^2 * wsq[o][i] + eps ),

@@ -1083,6 +1083,36 @@ def test_frozen_classifier_fused_tails_match_plain_module():
     close(outs["0"][0], outs["1"][0].float(), 2e-5, "logits")
 
 
+def test_lpips_distance_kernels_vs_published_formula():
+    """LPIPS-AlexNet forward on the fused tap kernels (default on the GPU) against the published composition
+    (STYLEX_LPIPS_FUSE=0: unit-normalise, squared difference, non-negative 1x1 weights, spatial mean, sum over taps):
+    distances and the gradient reaching BOTH images, at an image size whose taps are not multiples of the block."""
+    from lpips_alex import LPIPS
+
+    torch.manual_seed(5)
+    net = LPIPS().to(DEV)
+    a, b = torch.rand(3, 3, 96, 80, device=DEV) * 2 - 1, torch.rand(3, 3, 96, 80, device=DEV) * 2 - 1
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["STYLEX_LPIPS_FUSE"] = mode
+        try:
+            x0, x1 = a.clone().requires_grad_(), b.clone().requires_grad_()
+            d = net(x0, x1)
+            assert d.shape == (3, 1, 1, 1)
+            g0, g1 = torch.autograd.grad((d.flatten() * torch.tensor([1.0, -0.5, 2.0], device=DEV)).sum(), [x0, x1])
+            x1b = b.clone().requires_grad_()  # the train step's case: only the generated image carries a gradient
+            g1b, = torch.autograd.grad(net(a, x1b).sum(), [x1b])
+            outs[mode] = (d.detach(), g0, g1, g1b)
+            if mode == "1":
+                assert "_LpipsDistance" in type(d.grad_fn.next_functions[0][0]).__name__ + type(d.grad_fn).__name__
+        finally:
+            os.environ.pop("STYLEX_LPIPS_FUSE", None)
+    close(outs["0"][0], outs["1"][0], 5e-6, "LPIPS distance")
+    close(outs["0"][1], outs["1"][1], 2e-5, "gradient to image 0")
+    close(outs["0"][2], outs["1"][2], 2e-5, "gradient to image 1")
+    close(outs["0"][3], outs["1"][3], 2e-5, "one-sided gradient")
+
+
 def test_pad_rgb8_kernel_all_input_layouts():
     """stylex_pad_rgb8: a 3-channel image in any of the layouts the Trainer hands to D / the encoder (fp32 NCHW from the
     loader, fp32 channels_last, the bf16 3-of-4-channel view the generator returns) -> bf16 NHWC with 8 channels, the last
