@@ -264,11 +264,15 @@ atexit.register(_release_at_exit)
 _CACHE_ON = os.environ.get("STYLEX_PACK_CACHE", "1") != "0"  # probe switch: 0 = repack on every use
 
 
-def _cache_hit(key, w):
-    """Cached packs may have been produced on another HIP stream (the Trainer forks independent branches over
-    side streams): make the consumer stream wait for the producing kernel and keep the block alive for it."""
+def _cache_hit(key, w, version=None):
+    """One entry per (parameter, operand variant): valid while the parameter's version counter (bumped by every
+    in-place update, i.e. by the optimiser step) is the one it was packed from.  Cached packs may have been produced
+    on another HIP stream (the Trainer forks independent branches over side streams, `prepack` runs on its own): make
+    the consumer stream wait for the producing kernel and keep the block alive for it."""
     hit = _PACK_CACHE.get(key) if _CACHE_ON else None
     if hit is None or hit[0]() is not w:  # same live Parameter object (its address cannot be recycled)
+        return None
+    if hit[5] != (w._version if version is None else version):
         return None
     cur = torch.cuda.current_stream()
     if hit[4] != cur.cuda_stream:
@@ -279,12 +283,57 @@ def _cache_hit(key, w):
     return hit[1], hit[2]
 
 
-def _cache_put(key, w_param, wf, wb):
+_PACK_RECIPES = {}  # key -> (weakref to the parameter, function that packs it again): what `prepack` replays
+
+
+def _cache_put(key, w_param, wf, wb, version=None, recipe=None):
     if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
         _PACK_CACHE.clear()
     ev = torch.cuda.Event()
     ev.record()
-    _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream)
+    _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream,
+                        w_param._version if version is None else version)
+    if recipe is not None:
+        if len(_PACK_RECIPES) >= 4 * _PACK_CACHE_MAX:
+            _PACK_RECIPES.clear()
+        _PACK_RECIPES[key] = (weakref.ref(w_param), recipe)
+
+
+_PREPACK_STREAMS = {}
+
+
+def prepack(params):
+    """Re-pack, on a side stream, every cached operand variant of `params` whose parameter has changed — called right
+    after an optimiser step, so that the ~20 tiny pack launches per network run under the following kernels instead of
+    in front of each layer's first use (they sat on the critical chain: 66 launches, 1.4 ms of kernel time per step).
+    Consumers synchronise through the cache entry's event (`_cache_hit`)."""
+    if not _CACHE_ON or not _PACK_RECIPES:
+        return
+    ids = {id(p) for p in params}
+    todo = []
+    for key, (ref, fn) in list(_PACK_RECIPES.items()):
+        w = ref()
+        if w is None:
+            del _PACK_RECIPES[key]
+            _PACK_CACHE.pop(key, None)
+        elif id(w) in ids and w.is_cuda:
+            todo.append((w, fn))
+    if not todo:
+        return
+    dev = todo[0][0].device
+    side = _PREPACK_STREAMS.get(dev)
+    if side is None:
+        side = _PREPACK_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))  # the optimiser's writes
+    with torch.cuda.stream(side):
+        for w, fn in todo:
+            fn(w)
+
+
+def prepack_join():
+    """Before parameters are modified again: every prepack read of them has been issued on the side stream."""
+    for dev, side in _PREPACK_STREAMS.items():
+        torch.cuda.current_stream(dev).wait_stream(side)
 
 
 def scaled_linear_params(w, b, lr_mul):
@@ -292,16 +341,18 @@ def scaled_linear_params(w, b, lr_mul):
     :585-586), cached until the optimiser modifies the parameters: the mapping network runs 2-4 times per step on the
     same weights, and each run used to issue the two multiplies again (8 layers x 2 launches per run)."""
     _ensure_device(w)
-    key = ("eql", w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(w.shape), float(lr_mul))
+    key = ("eql", w.data_ptr(), None if b is None else b.data_ptr(), tuple(w.shape), float(lr_mul))
     cacheable = isinstance(w, torch.nn.Parameter)
-    hit = _cache_hit(key, w) if cacheable else None
+    ver = (w._version, None if b is None else b._version)
+    hit = _cache_hit(key, w, ver) if cacheable else None
     if hit is not None:
         return hit
     with torch.no_grad():
         ws = w.detach() * lr_mul
         bs = None if b is None else b.detach() * lr_mul
     if cacheable:
-        _cache_put(key, w, ws, bs)
+        bref = None if b is None else weakref.ref(b)
+        _cache_put(key, w, ws, bs, ver, recipe=lambda p: scaled_linear_params(p, None if bref is None else bref(), lr_mul))
     return ws, bs
 
 
@@ -314,7 +365,7 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
     cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
     key = None
     if cacheable:
-        key = (w.data_ptr(), w._version, tuple(w.shape), precision, scale)
+        key = (w.data_ptr(), tuple(w.shape), precision, scale)
         hit = _cache_hit(key, w)
         if hit is not None and (hit[0] is not None or not want_fwd) and (hit[1] is not None or not want_bwd):
             return hit
@@ -333,7 +384,7 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
     _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
            "stylex_pack_weight")
     if key is not None:
-        _cache_put(key, w_param, wf, wb)
+        _cache_put(key, w_param, wf, wb, recipe=lambda p: pack_weight(p, want_fwd, want_bwd, precision, scale))
     return wf, wb
 
 
@@ -342,7 +393,7 @@ def pack_weight_s2d(w, scale=None):
     lib = _ensure_device(w)
     key = None
     if isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32:
-        key = (w.data_ptr(), w._version, tuple(w.shape), "s2d", scale)
+        key = (w.data_ptr(), tuple(w.shape), "s2d", scale)
         hit = _cache_hit(key, w)
         if hit is not None:
             return hit
@@ -356,7 +407,7 @@ def pack_weight_s2d(w, scale=None):
     _check(lib.stylex_pack_weight_s2d(_ptr(wc), _ptr(wf), _ptr(wb), _shape(n, c, 3, 3), _stream()),
            "stylex_pack_weight_s2d")
     if key is not None:
-        _cache_put(key, w, wf, wb)
+        _cache_put(key, w, wf, wb, recipe=lambda p: pack_weight_s2d(p, scale))
     return wf, wb
 
 
@@ -580,14 +631,14 @@ def _bf16_matrix(w, scale=None):
     cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
     key = None
     if cacheable:
-        key = (w.data_ptr(), w._version, tuple(w.shape), "bf16mat", scale)
+        key = (w.data_ptr(), tuple(w.shape), "bf16mat", scale)
         hit = _cache_hit(key, w)
         if hit is not None and hit[0] is not None:
             return hit[0]
     m = w.detach().reshape(w.shape[0], -1)
     m = (m * scale if scale is not None else m).to(torch.bfloat16).contiguous()
     if key is not None:
-        _cache_put(key, w, m, None)
+        _cache_put(key, w, m, None, recipe=lambda p: _bf16_matrix(p, scale))
     return m
 
 
@@ -621,7 +672,7 @@ def weight_sumsq(w):
     cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
     key = None
     if cacheable:
-        key = (w.data_ptr(), w._version, tuple(w.shape), "wsq", None)
+        key = (w.data_ptr(), tuple(w.shape), "wsq", None)
         hit = _cache_hit(key, w)
         if hit is not None and hit[0] is not None:
             return hit[0]
@@ -632,7 +683,7 @@ def weight_sumsq(w):
     wsq = _empty(o * c, dtype=torch.float32, device=w.device).view(o, c)
     _check(lib.stylex_weight_sumsq(_ptr(w), _ptr(wsq), o, c, k, _stream()), "stylex_weight_sumsq")
     if key is not None:
-        _cache_put(key, w_param, wsq, None)
+        _cache_put(key, w_param, wsq, None, recipe=weight_sumsq)
     return wsq
 
 

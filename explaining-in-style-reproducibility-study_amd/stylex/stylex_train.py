@@ -1115,15 +1115,14 @@ class Trainer:
             if self.is_ddp:
                 self._d_sync.all_reduce()
             self._resolve_losses()  # previous step's scalars: its copy finished long ago, the GPU keeps running
-            m.D_opt.step()
+            self._opt_step(m.D_opt)
             # ---------------- generator phase ----------------
             if self.alternating_training:
                 st["encoder_input"] = False
             self._g_phase(groups, None, apply_pl, gae, fuse, acc, st)
             if self.is_ddp:
                 self._g_sync.all_reduce()
-            m.G_opt.step()
-            self._bump_packs()
+            self._opt_step(m.G_opt)
             acc_host, has_gp = self._loss_stack(acc), acc["gp"] is not None
             if apply_pl and not np.isnan(acc["pl"]):  # EMA(0.99), reference :1128, :1471-1473
                 avg = float(acc["pl"])
@@ -1177,6 +1176,22 @@ class Trainer:
         is ~1100 kernel launches issued through ctypes/ATen (~70 ms of host time per step); captured once
         per step shape (with / without the gradient penalty) it replays with one hipGraphLaunch."""
         return self.graphs and self.device.type == "cuda"
+
+    def _opt_step(self, opt):
+        """Optimiser step of the eager path.  The packed operand copies of the weights (bf16 GEMM layouts, scaled
+        mapping-network weights, ...) are valid for one Parameter version, so nothing has to be cleared here: D's packs
+        survive the generator phase's optimiser step (+1 % step throughput against clearing the cache every step).
+        STYLEX_PREPACK=1 additionally rebuilds the invalidated ones right away on a side stream (hip_backend.prepack) —
+        measured 1 % SLOWER than packing at first use (803-806 vs 811-815 images/s, same box): the ~60 tiny launches
+        then compete with the start of the next forward pass instead of hiding under it; kept as an opt-in."""
+        if self.device.type != "cuda" or os.environ.get("STYLEX_PREPACK", "0") != "1":
+            opt.step()
+            return
+        import hip_backend as hb
+
+        hb.prepack_join()  # earlier prepacks have read the parameters
+        opt.step()
+        hb.prepack([p for g in opt.param_groups for p in g["params"]])
 
     def _bump_packs(self):
         import hip_backend as hb

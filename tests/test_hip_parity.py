@@ -1113,6 +1113,38 @@ def test_lpips_distance_kernels_vs_published_formula():
     close(outs["0"][3], outs["1"][3], 2e-5, "one-sided gradient")
 
 
+def test_operand_cache_follows_parameter_versions_and_prepack():
+    """The packed operand copies (hip_backend.pack_weight & co.) are cached per Parameter and valid for one version:
+    an in-place update (the optimiser step) invalidates them, `prepack` rebuilds them on a side stream, and a consumer on
+    another stream gets the NEW values (ordering through the entry's event) — never the stale pack."""
+    torch.manual_seed(2)
+    w = torch.nn.Parameter(torch.randn(64, 32, 3, 3, device=DEV))
+    x = cl(torch.randn(2, 32, 16, 16)).to(torch.bfloat16)
+
+    def conv():
+        return hb.conv2d_fwd(x, w, 1, 1, hb.BF16_ACT).float()
+
+    def ref():
+        return F.conv2d(x.float(), w.detach().to(torch.bfloat16).float(), padding=1)
+
+    close(ref(), conv(), 2e-2, "first pack")
+    n0 = len(hb._PACK_CACHE)
+    close(ref(), conv(), 2e-2, "cache hit")
+    assert len(hb._PACK_CACHE) == n0
+    with torch.no_grad():
+        w.mul_(-0.5)  # version bump without prepack: the stale entry must not be served
+    close(ref(), conv(), 2e-2, "after an in-place update")
+    assert len(hb._PACK_CACHE) == n0, "one entry per (parameter, variant): replaced, not accumulated"
+    with torch.no_grad():
+        w.add_(1.0)
+    hb.prepack([w])
+    key = next(k for k, v in hb._PACK_CACHE.items() if v[0]() is w)
+    assert hb._PACK_CACHE[key][5] == w._version and hb._PACK_CACHE[key][4] != torch.cuda.current_stream().cuda_stream, \
+        "prepack must have rebuilt the operand on its side stream"
+    close(ref(), conv(), 2e-2, "after prepack")
+    hb.prepack_join()
+
+
 def test_pad_rgb8_kernel_all_input_layouts():
     """stylex_pad_rgb8: a 3-channel image in any of the layouts the Trainer hands to D / the encoder (fp32 NCHW from the
     loader, fp32 channels_last, the bf16 3-of-4-channel view the generator returns) -> bf16 NHWC with 8 channels, the last
