@@ -854,6 +854,18 @@ class HipOps:
         if stride == 2 and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and x.shape[1] % 4 == 0:
             # 1x1 / stride 2 (conv_res): contiguous 1x1 / stride-1 GEMMs over the gathered even pixels
             x, stride = _Subsample2.apply(x), 1
+        if (not padded_out and not fast_enabled() and _PRECISION == hb.BF16_ACT and x.is_cuda and stride == 1
+                and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and residual is None and not lrelu
+                and x.dtype == torch.bfloat16 and os.environ.get("STYLEX_RES_GEMM", "1") != "0"):
+            # double-differentiable path (gradient-penalty steps), bf16 mode: a 1x1 conv is a plain GEMM — ATen ops on
+            # the [B*H*W, C] view (hipBLASLt; autograd differentiates them twice) instead of the generic implicit-GEMM
+            # kernel triad, which ran these at 17-130 TF/s (3.2 ms per penalty step).  Same arithmetic as the fused path's
+            # conv1x1_gemm_fwd: bf16 operands, fp32 accumulate, one rounding.
+            b, c, h, wd = x.shape
+            x2 = _cl(x).permute(0, 2, 3, 1).reshape(b * h * wd, c)
+            wm = weight.reshape(weight.shape[0], c).to(torch.bfloat16)
+            y2 = torch.mm(x2, wm.t()) if bias is None else torch.addmm(bias.to(torch.bfloat16), x2, wm.t())
+            return y2.view(b, h, wd, wm.shape[0]).permute(0, 3, 1, 2)
         if not padded_out:
             fn = _ConvBiasActFast if fast_enabled() else _ConvBiasActDD
             return fn.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)
