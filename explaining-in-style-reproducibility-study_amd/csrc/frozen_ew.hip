@@ -146,65 +146,148 @@ __global__ __launch_bounds__(256) void affine_relu_maxpool_bwd_kernel(const floa
 // sweep hits L2 / MALL.  Per-block sums of d / HW go to partial[b][block] (summed once over all taps by the caller, in
 // fixed order); the norms are kept for the backward.
 constexpr float LPIPS_EPS = 1e-10f;
+constexpr int LP_PIX = 64;  // pixels per block = one wave width; the block's 4 waves split the channels
 
+// Sum over the block's 4 waves (channel slices) of a per-lane value, in fixed order; every lane of every wave gets it.
+__device__ __forceinline__ float lp_cross_wave(float v, float (*buf)[LP_PIX], int wave, int lane) {
+    buf[wave][lane] = v;
+    __syncthreads();
+    const float r = (buf[0][lane] + buf[1][lane]) + (buf[2][lane] + buf[3][lane]);
+    __syncthreads();
+    return r;
+}
+
+// grid (ceil(HW / 64), B), block 256: lane = pixel (coalesced along HW), wave w takes channels w, w + 4, ...; the channel
+// loops are unrolled 8x so that 16 independent loads are in flight per lane (a one-lane-per-pixel loop over 384 channels
+// was pure load latency: 360 us per tap at 15x15).
 __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                             const float* __restrict__ lin, float* __restrict__ partial,
                                                             float* __restrict__ r0, float* __restrict__ r1, int C, int HW,
                                                             long partial_stride) {
-    __shared__ float red[4];
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    float d = 0.f;
-    if (p < HW) {
-        const float* a = f0 + (size_t)b * C * HW + p;
-        const float* q = f1 + (size_t)b * C * HW + p;
-        float s0 = 0.f, s1 = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
-            s0 = fmaf(x, x, s0);
-            s1 = fmaf(y, y, s1);
+    __shared__ float buf[4][LP_PIX];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * LP_PIX + lane;
+    const bool ok = p < HW;
+    const float* a = f0 + (size_t)b * C * HW + (ok ? p : 0);
+    const float* q = f1 + (size_t)b * C * HW + (ok ? p : 0);
+    float s0 = 0.f, s1 = 0.f;
+    int c = wave;
+    for (; c + 28 < C; c += 32) {
+        float x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = a[(size_t)(c + 4 * u) * HW];
+            y[u] = q[(size_t)(c + 4 * u) * HW];
         }
-        const float n0 = sqrtf(s0), n1 = sqrtf(s1);
-        if (r0) r0[(size_t)b * HW + p] = n0;
-        if (r1) r1[(size_t)b * HW + p] = n1;
-        const float i0 = 1.f / (n0 + LPIPS_EPS), i1 = 1.f / (n1 + LPIPS_EPS);
-        for (int c = 0; c < C; ++c) {
-            const float t = a[(size_t)c * HW] * i0 - q[(size_t)c * HW] * i1;
-            d = fmaf(lin[c] * t, t, d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s0 = fmaf(x[u], x[u], s0);
+            s1 = fmaf(y[u], y[u], s1);
         }
     }
-    // fixed-order block sum: lanes by xor shuffle, then the four waves in order
-    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)b * partial_stride + blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)HW;
+    for (; c < C; c += 4) {
+        const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
+        s0 = fmaf(x, x, s0);
+        s1 = fmaf(y, y, s1);
+    }
+    s0 = lp_cross_wave(s0, buf, wave, lane);
+    s1 = lp_cross_wave(s1, buf, wave, lane);
+    const float n0 = sqrtf(s0), n1 = sqrtf(s1);
+    if (ok && wave == 0) {
+        if (r0) r0[(size_t)b * HW + p] = n0;
+        if (r1) r1[(size_t)b * HW + p] = n1;
+    }
+    const float i0 = 1.f / (n0 + LPIPS_EPS), i1 = 1.f / (n1 + LPIPS_EPS);
+    float d = 0.f;
+    c = wave;
+    for (; c + 28 < C; c += 32) {
+        float x[8], y[8], l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = a[(size_t)(c + 4 * u) * HW];
+            y[u] = q[(size_t)(c + 4 * u) * HW];
+            l[u] = lin[c + 4 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = x[u] * i0 - y[u] * i1;
+            d = fmaf(l[u] * t, t, d);
+        }
+    }
+    for (; c < C; c += 4) {
+        const float t = a[(size_t)c * HW] * i0 - q[(size_t)c * HW] * i1;
+        d = fmaf(lin[c] * t, t, d);
+    }
+    d = lp_cross_wave(ok ? d : 0.f, buf, wave, lane);
+    if (wave == 0) {  // fixed-order sum over the block's 64 pixels
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (lane == 0) partial[(size_t)b * partial_stride + blockIdx.x] = d / (float)HW;
+    }
 }
 
 // d out[b] / d f1[c][p] = g[b] / HW * ( q_c / B - (sum_k q_k y_k) / (B^2 r1) * y_c ),  q_c = -2 lin_c (x_c / A - y_c / B),
 // A = r0 + eps, B = r1 + eps  (and symmetrically for f0).  A pixel whose features are all zero gives 0 / 0 = NaN, as the
-// reference's sqrt backward does.
+// reference's sqrt backward does.  Same thread layout as the forward.
 __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                             const float* __restrict__ lin, const float* __restrict__ r0,
                                                             const float* __restrict__ r1, const float* __restrict__ gout,
                                                             float* __restrict__ g0, float* __restrict__ g1, int C, int HW) {
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const size_t base = (size_t)b * C * HW + p;
+    __shared__ float buf[4][LP_PIX];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * LP_PIX + lane;
+    const bool ok = p < HW;
+    const size_t base = (size_t)b * C * HW + (ok ? p : 0);
     const float* a = f0 + base;
     const float* q = f1 + base;
-    const float n0 = r0[(size_t)b * HW + p], n1 = r1[(size_t)b * HW + p];
+    const float n0 = r0[(size_t)b * HW + (ok ? p : 0)], n1 = r1[(size_t)b * HW + (ok ? p : 0)];
     const float A = n0 + LPIPS_EPS, Bn = n1 + LPIPS_EPS;
     const float iA = 1.f / A, iB = 1.f / Bn;
     float dot0 = 0.f, dot1 = 0.f;  // sum_c lin_c t_c x_c, sum_c lin_c t_c y_c  (t = n0 - n1)
-    for (int c = 0; c < C; ++c) {
+    int c = wave;
+    for (; c + 28 < C; c += 32) {
+        float x[8], y[8], l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = a[(size_t)(c + 4 * u) * HW];
+            y[u] = q[(size_t)(c + 4 * u) * HW];
+            l[u] = lin[c + 4 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float lt = l[u] * (x[u] * iA - y[u] * iB);
+            dot0 = fmaf(lt, x[u], dot0);
+            dot1 = fmaf(lt, y[u], dot1);
+        }
+    }
+    for (; c < C; c += 4) {
         const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
         const float lt = lin[c] * (x * iA - y * iB);
         dot0 = fmaf(lt, x, dot0);
         dot1 = fmaf(lt, y, dot1);
     }
+    dot0 = lp_cross_wave(dot0, buf, wave, lane);
+    dot1 = lp_cross_wave(dot1, buf, wave, lane);
+    if (!ok) return;
     const float gs = gout[b] / (float)HW;
     // d/dx_c = 2 lin_c t_c / A - 2 dot0 / (A^2 n0) x_c ;  d/dy_c = -2 lin_c t_c / B + 2 dot1 / (B^2 n1) y_c
     const float k0 = 2.f * dot0 / (A * A * n0), k1 = 2.f * dot1 / (Bn * Bn * n1);
-    for (int c = 0; c < C; ++c) {
+    c = wave;
+    for (; c + 28 < C; c += 32) {
+        float x[8], y[8], l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = a[(size_t)(c + 4 * u) * HW];
+            y[u] = q[(size_t)(c + 4 * u) * HW];
+            l[u] = lin[c + 4 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float lt2 = 2.f * l[u] * (x[u] * iA - y[u] * iB);
+            if (g0) g0[base + (size_t)(c + 4 * u) * HW] = gs * (lt2 * iA - k0 * x[u]);
+            if (g1) g1[base + (size_t)(c + 4 * u) * HW] = gs * (k1 * y[u] - lt2 * iB);
+        }
+    }
+    for (; c < C; c += 4) {
         const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
         const float lt2 = 2.f * lin[c] * (x * iA - y * iB);
         if (g0) g0[base + (size_t)c * HW] = gs * (lt2 * iA - k0 * x);
@@ -274,7 +357,7 @@ int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, co
 int stylex_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* partial, float* r0, float* r1, int64_t B,
                          int64_t C, int64_t HW, int64_t partial_stride, void* stream) {
     if (!f0 || !f1 || !lin || !partial || B < 1 || B > 65535 || C < 1 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
-    const unsigned blocks = (unsigned)((HW + 255) / 256);
+    const unsigned blocks = (unsigned)((HW + LP_PIX - 1) / LP_PIX);
     if (partial_stride < (int64_t)blocks) return STYLEX_EINVAL;
     hipLaunchKernelGGL(lpips_tap_fwd_kernel, dim3(blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0, f1, lin, partial, r0,
                        r1, (int)C, (int)HW, (long)partial_stride);
@@ -286,7 +369,7 @@ int stylex_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, con
     if (!f0 || !f1 || !lin || !r0 || !r1 || !gout || (!g0 && !g1) || B < 1 || B > 65535 || C < 1 || HW < 1 ||
         B * C * HW > 0x7fffffffLL)
         return STYLEX_EINVAL;
-    hipLaunchKernelGGL(lpips_tap_bwd_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0,
+    hipLaunchKernelGGL(lpips_tap_bwd_kernel, dim3((unsigned)((HW + LP_PIX - 1) / LP_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0,
                        f1, lin, r0, r1, gout, g0, g1, (int)C, (int)HW);
     return (int)hipGetLastError();
 }

@@ -601,7 +601,7 @@ def lpips_taps_fwd(f0s, f1s, lins, keep_norms):
     """sum over the taps of mean_p sum_c lin[c] (n0 - n1)^2  ->  ([B] distances, saved per-pixel norms)."""
     lib = _ensure_device(f0s[0])
     b = f0s[0].shape[0]
-    blocks = [(f.shape[2] * f.shape[3] + 255) // 256 for f in f0s]
+    blocks = [(f.shape[2] * f.shape[3] + 63) // 64 for f in f0s]
     partial = torch.empty((b, sum(blocks)), dtype=torch.float32, device=f0s[0].device)
     norms, off = [], 0
     for f0, f1, lin, nb in zip(f0s, f1s, lins, blocks):

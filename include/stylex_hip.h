@@ -251,7 +251,7 @@ int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, co
  * reconstruction_loss (reference stylex_train.py:404-438) calls lpips.LPIPS(net='alex') (lpips 0.1.4): per tap
  *   n = f / (sqrt(sum_c f^2) + 1e-10),  d[b][p] = sum_c lin[c] * (n0 - n1)^2,  out[b] = mean_p d[b][p].
  * f0, f1: dense fp32 [B][C][HW]; lin [C].  fwd writes per-block sums of d / HW to partial[b * partial_stride + block],
- * block = 0 .. ceil(HW / 256) - 1 (the caller adds them up, over all taps at once, in fixed order) and the per-pixel
+ * block = 0 .. ceil(HW / 64) - 1 (the caller adds them up, over all taps at once, in fixed order) and the per-pixel
  * norms sqrt(sum_c f^2) to r0 / r1 [B][HW] (NULL = not kept).  bwd: g0 / g1 (either may be NULL) = gout[b] * d out[b] / d f,
  * the chain rule through both normalisations; an all-zero pixel yields NaN exactly like the reference's sqrt backward. */
 int stylex_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* partial, float* r0, float* r1, int64_t B,
