@@ -92,8 +92,22 @@ def _want_param_grad(ctx, i):
     return ctx.needs_input_grad[i] and not _INPUTS_ONLY
 
 
+def _gemm_1x1(t, w, stride, pad, s2d):
+    """A 1x1 / stride-1 conv in the bf16 mode is a plain GEMM: forward and data gradient of the composable
+    (double-differentiable) triad go to hipBLASLt like the fused DiscriminatorBlock's residual conv (17-130 TF/s on the
+    generic kernel, 3.2 ms per gradient-penalty step).  The WEIGHT gradient stays on the deterministic split-K kernel:
+    letting ATen differentiate an addmm instead made two identically seeded Trainers diverge (its K = B*H*W weight-
+    gradient GEMM takes a split-K algorithm with atomic accumulation; tools/determinism_check.py 4 of 4 runs)."""
+    return (not s2d and stride == 1 and pad == 0 and _PRECISION == hb.BF16_ACT and t.is_cuda and t.dtype == torch.bfloat16
+            and w.dim() == 4 and tuple(w.shape[2:]) == (1, 1) and os.environ.get("STYLEX_RES_GEMM", "1") != "0"
+            and os.environ.get("STYLEX_RES_GEMM_DD", "1") != "0")
+
+
 def _fwd(x, w, stride, pad, s2d, **epi):
     """conv forward; s2d = C of the original stride-2 conv when x is its space-to-depth image."""
+    if _gemm_1x1(x, w, stride, pad, s2d) and not any(v is not None and v is not False for k, v in epi.items()
+                                                      if k not in ("bias", "res_scale")):
+        return hb.conv1x1_gemm_fwd(_cl(x), w, epi.get("bias"))
     if s2d:
         wf2, _ = hb.pack_weight_s2d(w)
         return hb.conv2d_fwd(x, None, 1, 1, _PRECISION, packed=wf2, w_shape=(w.shape[0], 4 * s2d, 3, 3), s2d_c=s2d, **epi)
@@ -101,6 +115,8 @@ def _fwd(x, w, stride, pad, s2d, **epi):
 
 
 def _bwd_data(gy, w, x_shape, stride, pad, s2d):
+    if _gemm_1x1(gy, w, stride, pad, s2d):
+        return hb.conv1x1_gemm_bwd_data(_cl(gy), w)
     if s2d:
         _, wb2 = hb.pack_weight_s2d(w)
         return hb.conv2d_bwd_data(gy, None, x_shape, 1, 1, _PRECISION, packed=wb2, w_shape=(w.shape[0], 4 * s2d, 3, 3),
@@ -854,18 +870,6 @@ class HipOps:
         if stride == 2 and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and x.shape[1] % 4 == 0:
             # 1x1 / stride 2 (conv_res): contiguous 1x1 / stride-1 GEMMs over the gathered even pixels
             x, stride = _Subsample2.apply(x), 1
-        if (not padded_out and not fast_enabled() and _PRECISION == hb.BF16_ACT and x.is_cuda and stride == 1
-                and padding == 0 and tuple(weight.shape[2:]) == (1, 1) and residual is None and not lrelu
-                and x.dtype == torch.bfloat16 and os.environ.get("STYLEX_RES_GEMM", "1") != "0"):
-            # double-differentiable path (gradient-penalty steps), bf16 mode: a 1x1 conv is a plain GEMM — ATen ops on
-            # the [B*H*W, C] view (hipBLASLt; autograd differentiates them twice) instead of the generic implicit-GEMM
-            # kernel triad, which ran these at 17-130 TF/s (3.2 ms per penalty step).  Same arithmetic as the fused path's
-            # conv1x1_gemm_fwd: bf16 operands, fp32 accumulate, one rounding.
-            b, c, h, wd = x.shape
-            x2 = _cl(x).permute(0, 2, 3, 1).reshape(b * h * wd, c)
-            wm = weight.reshape(weight.shape[0], c).to(torch.bfloat16)
-            y2 = torch.mm(x2, wm.t()) if bias is None else torch.addmm(bias.to(torch.bfloat16), x2, wm.t())
-            return y2.view(b, h, wd, wm.shape[0]).permute(0, 3, 1, 2)
         if not padded_out:
             fn = _ConvBiasActFast if fast_enabled() else _ConvBiasActDD
             return fn.apply(x, weight, bias, residual, stride, padding, lrelu, res_scale)

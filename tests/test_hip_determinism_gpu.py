@@ -40,3 +40,19 @@ def test_two_runs_are_bit_identical_without_per_step_sync():
         os.chdir(cwd)
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert runs[0][1] == runs[1][1]
+
+
+def test_two_runs_are_bit_identical_at_the_benchmark_size():
+    """The same check at the size bench.py runs (256 px, B=32, GAE=2): library GEMMs choose their algorithm by shape, and
+    a split-K algorithm with atomic accumulation — run-to-run noise — only appeared at this size (K = B*H*W = 1M rows
+    in the weight gradient of a 1x1 conv that ATen was briefly allowed to differentiate)."""
+    import determinism_check
+
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        runs = determinism_check.run(steps=3, image_size=256, batch=32)  # step 0: gradient penalty, 1-2: ordinary
+    finally:
+        os.chdir(cwd)
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1]
