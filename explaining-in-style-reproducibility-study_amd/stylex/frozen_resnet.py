@@ -133,10 +133,15 @@ class FusedTailResNet(nn.Module):
         super().__init__()
         assert not model.training, "the classifier must be in eval mode (BatchNorm as an affine map)"
         self.model = model
-        self.aff = {}
-        for name, mod in model.named_modules():
-            if isinstance(mod, nn.BatchNorm2d):
-                self.aff[name] = _affine(mod)
+        self.bns = [(name, mod) for name, mod in model.named_modules() if isinstance(mod, nn.BatchNorm2d)]
+        self._build()
+
+    def _stamp(self):
+        return tuple(t._version for _, bn in self.bns for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+
+    def _build(self):
+        self.aff = {name: _affine(bn) for name, bn in self.bns}
+        self.stamp = self._stamp()
 
     @staticmethod
     def supports(model):
@@ -153,6 +158,8 @@ class FusedTailResNet(nn.Module):
 
     def forward(self, x):
         m = self.model
+        if self._stamp() != self.stamp:  # BatchNorm tensors were modified in place (a state dict loaded later)
+            self._build()
         x = x.float().contiguous()
         x = _AffineReluPool.apply(self._conv(x, m.conv1).contiguous(), *self.aff["bn1"])
         for li in range(1, 5):

@@ -1081,6 +1081,18 @@ def test_frozen_classifier_fused_tails_match_plain_module():
     assert e_fused[0] <= max(3 * e_plain[0], 2e-6), ("logits", e_fused, e_plain)
     assert e_fused[1] <= max(3 * e_plain[1], 2e-5), ("image gradient", e_fused, e_plain)
     close(outs["0"][0], outs["1"][0].float(), 2e-5, "logits")
+    with torch.no_grad():  # BatchNorm tensors changed in place after the fused module was built: it must follow
+        before = clf.classify_images(img)
+        clf.model.bn1.bias.add_(0.5)
+        after_fused = clf.classify_images(img)
+        os.environ["STYLEX_FROZEN_FUSE"] = "0"
+        try:
+            after_plain = clf.classify_images(img)
+        finally:
+            os.environ.pop("STYLEX_FROZEN_FUSE", None)
+        clf.model.bn1.bias.sub_(0.5)
+    assert (before - after_fused).abs().max() > 1e-4
+    close(after_plain, after_fused, 2e-5, "logits after an in-place BatchNorm update")
 
 
 def test_lpips_distance_kernels_vs_published_formula():
