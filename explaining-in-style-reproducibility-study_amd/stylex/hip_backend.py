@@ -388,6 +388,30 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
     return wf, wb
 
 
+def pack_weight_fwd_as_dgrad(w, precision):
+    """Operand that makes the DATA-GRADIENT entry point compute the FORWARD 3x3 conv of `w` (gp_tangent: the gate
+    epilogues live on that entry point).  The data-gradient kernels read their packed operand [C'][tap][N'] with the taps
+    mirrored; the forward conv of w [N][C][3][3] over an input with C channels is the data gradient of the conv whose
+    weight is w transposed and tap-mirrored — so the operand is the forward layout [N][tap][C] of the tap-mirrored w.
+    Cached per Parameter version like the other packs."""
+    lib = _ensure_device(w)
+    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+    key = None
+    if cacheable:
+        key = (w.data_ptr(), tuple(w.shape), precision, "fwd_as_dgrad")
+        hit = _cache_hit(key, w)
+        if hit is not None:
+            return hit[0]
+    wm = w.detach().float().flip(2, 3).contiguous()
+    n, c, kh, kw = wm.shape
+    dt = torch.float32 if precision == F32 else torch.bfloat16
+    wf = _empty(n * kh * kw * c, dtype=dt, device=w.device)
+    _check(lib.stylex_pack_weight(_ptr(wm), _ptr(wf), None, _shape(n, c, kh, kw), precision, _stream()), "stylex_pack_weight")
+    if key is not None:
+        _cache_put(key, w, wf, None, recipe=lambda p: pack_weight_fwd_as_dgrad(p, precision))
+    return wf
+
+
 def pack_weight_s2d(w, scale=None):
     """OIHW {N,C,3,3} parameter of a stride-2 conv -> bf16 operands of its space-to-depth form (cached)."""
     lib = _ensure_device(w)
@@ -891,8 +915,9 @@ def rowwise_sumsq(x2d):
     return out
 
 
-def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True):
-    """dx = dy*scale*lrelu'(y); returns (dx or None, per-channel sum over b,h,w [C] or None when not wanted)."""
+def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True, per_sample=False):
+    """dx = dy*scale*lrelu'(y); returns (dx or None, per-channel sum over b,h,w [C] or None when not wanted).
+    per_sample=True: the sums per sample, [B, C]."""
     lib = _ensure_device(dy)
     assert is_cl(dy) and (y is None or (is_cl(y) and y.dtype == dy.dtype))
     b, c, h, w = dy.shape
@@ -902,7 +927,7 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True):
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
     _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)),
                                      float(scale), _adt(dy), _stream()), "stylex_act_bwd_reduce")
-    return dx, (partial.sum(dim=(0, 1)) if want_sum else None)
+    return dx, ((partial.sum(dim=1) if per_sample else partial.sum(dim=(0, 1))) if want_sum else None)
 
 
 def modconv_bwd_prep(gy, y, noise, noise_w, noise_b, lrelu, gz_scale=None):

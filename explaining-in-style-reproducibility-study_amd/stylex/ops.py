@@ -794,6 +794,8 @@ class _DBlockFast(torch.autograd.Function):
         if want_b and gb2 is None:
             gb2 = _channel_sum(gz2)
         gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1, gate_mask=m1)  # + LeakyReLU derivative of y1
+        if getattr(ctx, "keep_gz", False):  # hand-driven backward (gp_tangent): the pre-activation gradients are reused
+            ctx.gz = (gz3, gz2, gz1, alg)
         gxs = None
         if want_w:
             gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec, want_bias_sum=fuse_b)

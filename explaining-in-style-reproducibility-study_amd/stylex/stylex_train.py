@@ -917,14 +917,23 @@ class Trainer:
         real = _cat(reals)
         n_fake = generated.shape[0]
         grad_norms = None
+        tangent_gp = False
         if apply_gp:
-            real = real.detach().requires_grad_()
+            import gp_tangent
+
+            # default architecture, bf16 mode: D(real) and ||dD/dx|| as ONE first-order node (the penalty's parameter
+            # gradient through a tangent pass instead of a double backward, gp_tangent.py)
+            tangent_gp = fuse and not new and gp_tangent.supported(m.D, real)
+            real = real.detach() if tangent_gp else real.detach().requires_grad_()
 
             def fake_branch():
                 ops.set_fast(True)  # the fake branch is only ever differentiated once
                 return D_call(generated, detach=True, probs=cond)
 
             def real_branch():
+                if tangent_gp:
+                    ops.set_fast(True)
+                    return gp_tangent.d_real_with_norms(m.D, real)
                 ops.set_fast(False)  # the gradient penalty differentiates the real branch twice
                 return D_call(real, probs=cond)
 
@@ -935,7 +944,10 @@ class Trainer:
             else:
                 fake_out, real_out = fake_branch(), real_branch()
             ops.set_fast(False)
-            grad_norms = gradient_norms(real, real_out)
+            if tangent_gp:
+                real_out, grad_norms = real_out
+            else:
+                grad_norms = gradient_norms(real, real_out)
         else:
             # D(fake) and D(real) are one pass over the concatenated batch
             ops.set_fast(True)

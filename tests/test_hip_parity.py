@@ -864,6 +864,56 @@ def test_fused_dblock_matches_composable_path(case, prec):
         close(a, b, tol, "dblock grad " + name)
 
 
+@pytest.mark.parametrize("prec,size", [("fp32", 64), ("bf16", 64), ("bf16", 256)])
+def test_gradient_penalty_tangent_pass_matches_double_backward(prec, size):
+    """gp_tangent (D(real) and ||dD/dx|| as one first-order node; the penalty's parameter gradient through a tangent
+    pass of the gated-linear network) against what it replaces: autograd's double backward through the composable ops
+    (reference gradient_penalty :296-303).  Loss = hinge-like term on D(real) + 10 * mean((norm - 1)^2): outputs, norms
+    and EVERY parameter gradient.  fp32: rounding only; bf16: the band of two bf16 evaluation orders."""
+    import gp_tangent
+
+    ops.set_precision(prec)
+    torch.manual_seed(21)
+    D = st.DiscriminatorE(size, network_capacity=16, fmap_max=512).to(DEV)
+    with torch.no_grad():
+        for p in D.parameters():  # biases away from zero, weights as initialised
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    b = 4 if size <= 64 else 2
+    real = torch.rand(b, 3, size, size, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    a = torch.tensor([1.0, 0.0, 1.0, 1.0][:b], device=DEV) / b  # hinge derivative: some samples inactive
+
+    def loss_of(out, norms):
+        return (out * a).sum() + 10 * ((norms - 1) ** 2).mean()
+
+    res = {}
+    os.environ["STYLEX_GP_TANGENT"] = "2"  # the tangent path in any precision
+    try:
+        for mode in ("double", "tangent"):
+            D.zero_grad()
+            if mode == "double":
+                ops.set_fast(False)
+                x = real.clone().requires_grad_()
+                out = D(x)
+                norms = st.gradient_norms(x, out)
+            else:
+                assert gp_tangent.supported(D, real)
+                ops.set_fast(True)
+                out, norms = gp_tangent.d_real_with_norms(D, real)
+            ops.set_fast(False)
+            loss_of(out.float(), norms).backward()
+            res[mode] = (out.detach().float(), norms.detach(), {n: p.grad.clone() for n, p in D.named_parameters()})
+    finally:
+        ops.set_fast(False)
+        os.environ.pop("STYLEX_GP_TANGENT", None)
+        ops.set_precision("fp32")
+    tol = 2e-4 if prec == "fp32" else 4e-2
+    close(res["double"][0], res["tangent"][0], 2e-5 if prec == "fp32" else 2e-2, "D(real)")
+    close(res["double"][1], res["tangent"][1], tol, "gradient norms")
+    for n in res["double"][2]:
+        close(res["double"][2][n], res["tangent"][2][n], tol, "grad " + n)
+
+
 def test_graph_replay_matches_eager(tmp_path):
     """Whole-step HIP-graph replay (Trainer(graphs=True)): the same seeds through the eager enqueue and through the
     captured graphs (static input buffers, device-side layer split, three graphs per step shape, both shapes) give the
