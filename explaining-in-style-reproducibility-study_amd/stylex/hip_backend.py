@@ -264,6 +264,19 @@ atexit.register(_release_at_exit)
 _CACHE_ON = os.environ.get("STYLEX_PACK_CACHE", "1") != "0"  # probe switch: 0 = repack on every use
 
 
+def _gen(t):
+    """Modification stamp of a parameter: torch's version counter AND our own generation counter.  The fused Adam
+    (torch._fused_adam_, the speed mode's optimiser) updates parameters WITHOUT bumping `_version` (measured: 0 -> 0
+    across a step, foreach / plain Adam 0 -> 1), so the Trainer stamps every parameter it steps (`mark_updated`)."""
+    return None if t is None else (t._version, getattr(t, "_stylex_gen", 0))
+
+
+def mark_updated(params):
+    """Call after an optimiser step that may not bump Parameter._version: invalidates the cached operand copies."""
+    for p in params:
+        p._stylex_gen = getattr(p, "_stylex_gen", 0) + 1
+
+
 def _cache_hit(key, w, version=None):
     """One entry per (parameter, operand variant): valid while the parameter's version counter (bumped by every
     in-place update, i.e. by the optimiser step) is the one it was packed from.  Cached packs may have been produced
@@ -272,7 +285,7 @@ def _cache_hit(key, w, version=None):
     hit = _PACK_CACHE.get(key) if _CACHE_ON else None
     if hit is None or hit[0]() is not w:  # same live Parameter object (its address cannot be recycled)
         return None
-    if hit[5] != (w._version if version is None else version):
+    if hit[5] != (_gen(w) if version is None else version):
         return None
     cur = torch.cuda.current_stream()
     if hit[4] != cur.cuda_stream:
@@ -292,7 +305,7 @@ def _cache_put(key, w_param, wf, wb, version=None, recipe=None):
     ev = torch.cuda.Event()
     ev.record()
     _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream,
-                        w_param._version if version is None else version)
+                        _gen(w_param) if version is None else version)
     if recipe is not None:
         if len(_PACK_RECIPES) >= 4 * _PACK_CACHE_MAX:
             _PACK_RECIPES.clear()
@@ -343,7 +356,7 @@ def scaled_linear_params(w, b, lr_mul):
     _ensure_device(w)
     key = ("eql", w.data_ptr(), None if b is None else b.data_ptr(), tuple(w.shape), float(lr_mul))
     cacheable = isinstance(w, torch.nn.Parameter)
-    ver = (w._version, None if b is None else b._version)
+    ver = (_gen(w), _gen(b))
     hit = _cache_hit(key, w, ver) if cacheable else None
     if hit is not None:
         return hit

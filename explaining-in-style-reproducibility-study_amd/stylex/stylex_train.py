@@ -939,7 +939,7 @@ class Trainer:
 
             # the two D passes of a penalty step are independent until the loss: two HIP streams when D_aug is
             # a pass-through (`fuse`; with augmentation the reference's fake-then-real draw order is kept)
-            if fuse:
+            if fuse and not (tangent_gp and os.environ.get("STYLEX_GP_FORK", "1") == "0"):
                 real_out, fake_out = self._fork([real_branch, fake_branch])
             else:
                 fake_out, real_out = fake_branch(), real_branch()
@@ -1196,14 +1196,21 @@ class Trainer:
         STYLEX_PREPACK=1 additionally rebuilds the invalidated ones right away on a side stream (hip_backend.prepack) —
         measured 1 % SLOWER than packing at first use (803-806 vs 811-815 images/s, same box): the ~60 tiny launches
         then compete with the start of the next forward pass instead of hiding under it; kept as an opt-in."""
-        if self.device.type != "cuda" or os.environ.get("STYLEX_PREPACK", "0") != "1":
+        if self.device.type != "cuda":
             opt.step()
             return
         import hip_backend as hb
 
-        hb.prepack_join()  # earlier prepacks have read the parameters
+        params = [p for g in opt.param_groups for p in g["params"]]
+        prepack = os.environ.get("STYLEX_PREPACK", "0") == "1"
+        if prepack:
+            hb.prepack_join()  # earlier prepacks have read the parameters
         opt.step()
-        hb.prepack([p for g in opt.param_groups for p in g["params"]])
+        # the fused Adam does not bump Parameter._version: stamp what it stepped, or every cached operand copy of
+        # these weights (bf16 GEMM layouts, scaled mapping-network weights, ...) would be served stale
+        hb.mark_updated(params)
+        if prepack:
+            hb.prepack(params)
 
     def _bump_packs(self):
         import hip_backend as hb
@@ -1255,11 +1262,11 @@ class Trainer:
             self._d_phase([group], [(reals, micro_d)], apply_gp, gae, True, acc)
             if self.is_ddp:
                 self._d_sync.all_reduce()
-            m.D_opt.step()
+            self._opt_step(m.D_opt)
             self._g_phase([group], [(micro_g, [])], False, gae, True, acc)
             if self.is_ddp:
                 self._g_sync.all_reduce()
-            m.G_opt.step()
+            self._opt_step(m.G_opt)
             self._bump_packs()
             return self._loss_stack(acc)
         if entry is None:
@@ -1292,13 +1299,13 @@ class Trainer:
                 self._d_sync.pack_all()  # captured: every replay refills the flat buckets the collectives run on
 
         def seg_g():
-            m.D_opt.step()
+            self._opt_step(m.D_opt)  # + stamp: the generator phase must re-pack D's updated weights inside the capture
             self._g_phase(groups, g_in, False, gae, True, acc)
             if self.is_ddp:
                 self._g_sync.pack_all()
 
         def seg_tail():
-            m.G_opt.step()
+            self._opt_step(m.G_opt)
             acc["out"] = self._loss_stack(acc)
 
         # always three graphs: each phase captures fine on its own, but D phase + G phase in ONE capture with the

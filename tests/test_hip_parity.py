@@ -1201,10 +1201,42 @@ def test_operand_cache_follows_parameter_versions_and_prepack():
         w.add_(1.0)
     hb.prepack([w])
     key = next(k for k, v in hb._PACK_CACHE.items() if v[0]() is w)
-    assert hb._PACK_CACHE[key][5] == w._version and hb._PACK_CACHE[key][4] != torch.cuda.current_stream().cuda_stream, \
+    assert hb._PACK_CACHE[key][5] == hb._gen(w) and hb._PACK_CACHE[key][4] != torch.cuda.current_stream().cuda_stream, \
         "prepack must have rebuilt the operand on its side stream"
     close(ref(), conv(), 2e-2, "after prepack")
     hb.prepack_join()
+    # the fused Adam updates parameters WITHOUT bumping Parameter._version: only the Trainer's stamp invalidates
+    opt = torch.optim.Adam([w], lr=0.5, fused=True)
+    w.grad = torch.ones_like(w)
+    before = hb._gen(w)
+    opt.step()
+    if w._version == before[0]:  # (if a later torch bumps the counter the stamp is merely redundant)
+        hb.mark_updated([w])
+    assert hb._gen(w) != before
+    close(ref(), conv(), 2e-2, "after a fused-Adam step + mark_updated")
+
+
+def test_generator_phase_sees_the_updated_discriminator(tmp_path):
+    """Reference :1356 / :1380-1440: D's optimiser step precedes the generator phase, whose loss is evaluated on the
+    UPDATED discriminator.  In the bf16 speed mode the optimiser is the fused Adam, which does not bump
+    Parameter._version — a cache of packed weights keyed on that counter alone served the generator phase D's
+    pre-update weights (found in round 3).  Two identically seeded Trainers, one with the operand cache switched off:
+    same losses, in particular the same first g_loss."""
+    g = load_golden("steps_gae2_alt")
+    rows = {}
+    for cache_on in (True, False):
+        prev = hb._CACHE_ON
+        hb._CACHE_ON = cache_on
+        hb.pack_cache_clear()
+        try:
+            ops.set_precision("bf16")
+            (tmp_path / ("c%d" % cache_on)).mkdir()
+            tr, n = make_trainer(g, tmp_path / ("c%d" % cache_on), device=torch.device(DEV))
+            rows[cache_on] = run_steps(tr, 3)
+        finally:
+            hb._CACHE_ON = prev
+            ops.set_precision("fp32")
+    np.testing.assert_allclose(rows[True], rows[False], rtol=1e-6, atol=1e-6, equal_nan=True)
 
 
 def test_pad_rgb8_kernel_all_input_layouts():

@@ -3,7 +3,7 @@ bench workload (256 px, B=32, GAE=2, bf16, HIP streams on); every loss scalar an
 bit-identical.  All our reductions are fixed-order, so a missing stream dependency shows up as run-to-run noise.
 The frozen classifier / LPIPS run on MIOpen, whose default algorithms are NOT run-to-run reproducible (measured:
 identical input, logits differing at 1e-7, amplified to 2e-3 in D's bf16 output) — the check pins them with
-torch.backends.cudnn.deterministic.      python tools/determinism_check.py [steps] [image_size]"""
+torch.backends.cudnn.deterministic.      python tools/determinism_check.py [steps] [image_size] [batch]"""
 import argparse
 import os
 import sys
@@ -71,7 +71,7 @@ if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     os.chdir(ROOT)
-    r = run(steps, size, trainers=int(os.environ.get("DET_TRAINERS", "2")))
+    r = run(steps, size, batch=int(sys.argv[3]) if len(sys.argv) > 3 else 32, trainers=int(os.environ.get("DET_TRAINERS", "2")))
     if len(r) > 2:
         print("all parameter checksums", [x[1] for x in r])
     for i, (x, y) in enumerate(zip(r[0][0], r[1][0])):
