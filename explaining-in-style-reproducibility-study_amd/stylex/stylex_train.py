@@ -1190,12 +1190,14 @@ class Trainer:
         return self.graphs and self.device.type == "cuda"
 
     def _opt_step(self, opt):
-        """Optimiser step of the eager path.  The packed operand copies of the weights (bf16 GEMM layouts, scaled
-        mapping-network weights, ...) are valid for one Parameter version, so nothing has to be cleared here: D's packs
-        survive the generator phase's optimiser step (+1 % step throughput against clearing the cache every step).
-        STYLEX_PREPACK=1 additionally rebuilds the invalidated ones right away on a side stream (hip_backend.prepack) —
-        measured 1 % SLOWER than packing at first use (803-806 vs 811-815 images/s, same box): the ~60 tiny launches
-        then compete with the start of the next forward pass instead of hiding under it; kept as an opt-in."""
+        """Optimiser step + invalidation of the cached operand copies of the weights it changed (bf16 GEMM layouts,
+        scaled mapping-network weights, ...).  The cache entries are valid for one modification stamp of their
+        parameter; the fused Adam of the speed mode does NOT bump Parameter._version, so the stamp is set here
+        (hb.mark_updated) — without it the generator phase evaluated D with its pre-update packs.
+        Parameters another optimiser owns keep their packs (D's survive the generator's step).
+        STYLEX_PREPACK=1 additionally rebuilds the invalidated copies right away on a side stream (hb.prepack) —
+        measured slower than packing at first use (the ~60 tiny launches then compete with the start of the next
+        forward pass instead of hiding under it); kept as an opt-in."""
         if self.device.type != "cuda":
             opt.step()
             return

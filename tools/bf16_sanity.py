@@ -1,5 +1,5 @@
 """Speed-mode sanity: N train() calls of the bench workload (256 px, B=32, GAE=2, bf16), losses every 10 steps and
-peak device memory — no NaN / blow-up, finite losses.  python tools/bf16_sanity.py [steps]"""
+peak device memory — no NaN / blow-up, finite losses.  python tools/bf16_sanity.py [steps] [bf16|fp32]"""
 import argparse
 import math
 import os
@@ -14,13 +14,14 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir="/tmp/sb", precision="bf16")
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"  # "fp32": the parity mode on the same workload, for comparison
+a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir="/tmp/sb", precision=prec)
 sys.path[:0] = [os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd", "stylex")]
 import hip_backend as hb  # noqa: E402
 import ops  # noqa: E402
 
 hb.load_library()
-ops.set_precision("bf16")
+ops.set_precision(prec)
 tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
 bad = 0
 for i in range(steps):
