@@ -608,16 +608,14 @@ def test_block_level_goldens_on_hip():
 
 
 def test_bf16_step_band_vs_reference_golden(tmp_path):
-    """The benchmarked mode (bf16 MFMA operands + bf16 activation tensors) against the fp32 reference trajectory
-    steps_gae2_alt.  Band for the first train() call: every conv rounds its two operands to bf16 (relative 2^-9
-    each); a loss scalar sits behind ~30 chained convs of forward (+ as many of backward for the penalty), a random
-    walk of sqrt(60)*2^-8 = 3e-2, so 5e-2 of max(1,|x|) for the hinge / rec / kl terms; the gradient penalty is a
-    squared norm of a double-rounded gradient: 1e-1.  g_loss is NOT in the band even on the first call: it is evaluated
-    after D's first Adam step, which is lr*sign(grad) element-wise (m/sqrt(v) = +-1 at t=1) — every gradient element
-    that is bf16-noise flips the update of its weight by 2*lr, and D(G(z)) through 37 M such weights moves by O(1)
-    (measured: -0.21 vs 3.88; the fp32 HIP path reproduces 3.88 to 2e-4, test_trainer_step_parity_gpu).  Later calls of
-    an untrained GAN are chaotic in any arithmetic (the reference against itself at another thread count leaves 1e-3
-    at call 4): finite, and of the golden's order of magnitude."""
+    """The benchmarked mode (bf16 MFMA operands + bf16 activation tensors, fused Adam) against the fp32 reference
+    trajectory steps_gae2_alt.  Band for the first train() call: every conv rounds its two operands to bf16 (relative
+    2^-9 each); a loss scalar sits behind ~30 chained convs of forward (+ as many of backward for the penalty), a random
+    walk of sqrt(60)*2^-8 = 3e-2, so 5e-2 of max(1,|x|) for d_loss / g_loss / rec / kl; the gradient penalty is a
+    squared norm of a double-rounded gradient: 1e-1.  g_loss is evaluated on the UPDATED discriminator: until round 3
+    this test excluded it ("measured -0.21 vs 3.88", blamed on Adam's sign-like first step) — that was the stale operand
+    cache under the fused Adam; with the fix the bf16 mode gives 3.89 vs 3.88.  Later calls: the band widens
+    by 1.6x per call (the untrained GAN amplifies any difference), capped at 30 %."""
     g = load_golden("steps_gae2_alt")
     ops.set_precision("bf16")
     try:
@@ -627,12 +625,12 @@ def test_bf16_step_band_vs_reference_golden(tmp_path):
         ops.set_precision("fp32")
     gold = g["scalars"]
     print("bf16 rows\n", rows, "\ngolden\n", gold)
-    cols = [0, 2, 3]  # d_loss, rec, kl: functions of the not-yet-updated weights
-    scale = np.maximum(1.0, np.abs(gold[0, cols]))
-    assert (np.abs(rows[0, cols] - gold[0, cols]) <= 5e-2 * scale).all(), (rows[0], gold[0])
-    assert abs(rows[0, 4] - gold[0, 4]) <= 1e-1 * max(1.0, abs(gold[0, 4])), (rows[0, 4], gold[0, 4])
     assert np.isfinite(rows[:, :5]).all()
-    assert np.abs(rows[:, :4]).max() <= 10 * np.abs(gold[:, :4]).max()
+    for i in range(n):
+        tol = min(0.3, 5e-2 * 1.6 ** i)
+        scale = np.maximum(1.0, np.abs(gold[i, :4]))
+        assert (np.abs(rows[i, :4] - gold[i, :4]) <= tol * scale).all(), (i, tol, rows[i], gold[i])
+    assert abs(rows[0, 4] - gold[0, 4]) <= 1e-1 * max(1.0, abs(gold[0, 4])), (rows[0, 4], gold[0, 4])
 
 
 def test_loss_curve_short_horizon_vs_reference():
