@@ -100,8 +100,6 @@ def _per_sample_channel_sums(g):
 class _DRealPenalty(torch.autograd.Function):
     @staticmethod
     def forward(ctx, real, layout, *params):
-        if "f" in os.environ.get("STYLEX_GP_SYNC", ""):
-            torch.cuda.synchronize()
         prec = ops._PRECISION
         nb = len(layout)
         blocks = [params[8 * i:8 * i + 8] for i in range(nb)]
@@ -127,15 +125,11 @@ class _DRealPenalty(torch.autograd.Function):
         norms = hb.rowwise_sumsq(u.reshape(bsz, -1)).sqrt()
         ctx.layout, ctx.ctxs, ctx.nb = layout, ctxs, nb
         ctx.save_for_backward(u, norms, xf, g_yf, flat, *params)
-        if "F" in os.environ.get("STYLEX_GP_SYNC", ""):
-            torch.cuda.synchronize()
         return out, norms
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out, g_norm):
-        if "b" in os.environ.get("STYLEX_GP_SYNC", ""):
-            torch.cuda.synchronize()
         prec = ops._PRECISION
         u, norms, xf, g_yf, flat = ctx.saved_tensors[:5]
         params = ctx.saved_tensors[5:]
@@ -227,8 +221,4 @@ class _DRealPenalty(torch.autograd.Function):
         gwfc = (wsum(flat) + tflat.sum(0)).reshape(wfc.shape)
         gbfc = s.sum().reshape(bfc.shape)
         grads += [gwf, gbf, gwfc, gbfc]
-        if "B" in os.environ.get("STYLEX_GP_SYNC", ""):
-            torch.cuda.synchronize()
-        if os.environ.get("STYLEX_GP_CLONE") == "1":
-            grads = [None if g is None else g.clone() for g in grads]
         return (None, None) + tuple(grads)

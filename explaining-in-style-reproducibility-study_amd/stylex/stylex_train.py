@@ -939,7 +939,7 @@ class Trainer:
 
             # the two D passes of a penalty step are independent until the loss: two HIP streams when D_aug is
             # a pass-through (`fuse`; with augmentation the reference's fake-then-real draw order is kept)
-            if fuse and not (tangent_gp and os.environ.get("STYLEX_GP_FORK", "1") == "0"):
+            if fuse:
                 real_out, fake_out = self._fork([real_branch, fake_branch])
             else:
                 fake_out, real_out = fake_branch(), real_branch()
