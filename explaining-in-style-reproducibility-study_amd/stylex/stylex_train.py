@@ -509,6 +509,9 @@ class StylEx(nn.Module):
         for ma, cur in ((self.SE, self.S), (self.GE, self.G)):
             for p_cur, p_ma in zip(cur.parameters(), ma.parameters()):
                 p_ma.data = p_ma.data * self.ema_beta + (1 - self.ema_beta) * p_cur.data
+                # `.data =` rebinds the storage without touching the version counter, and the allocator may hand back
+                # the address of an older average: stamp the parameter so no cached operand copy of it can match
+                p_ma._stylex_gen = getattr(p_ma, "_stylex_gen", 0) + 1
 
     def reset_parameter_averaging(self):
         self.SE.load_state_dict(self.S.state_dict())
