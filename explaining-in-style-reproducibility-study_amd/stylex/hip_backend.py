@@ -142,8 +142,25 @@ def _check(rc, what):
         raise StylexHipError("%s failed with code %d" % (what, rc))
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_RAW_ON = os.environ.get("STYLEX_RAW_STREAM", "1") != "0"
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Stream object
+    through four Python layers (8 us; 800 launches per step = 6-7 ms of host time, tools/host_profile.py); the two C
+    calls underneath return the same handle."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None and _RAW_ON:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _stream_id():
+    """The same handle as an int (0 = the default stream), comparable with torch's Stream.cuda_stream."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None and _RAW_ON:
+        return int(_RAW_STREAM(_RAW_DEVICE()))
+    return int(torch.cuda.current_stream().cuda_stream)
 
 
 def _ensure_device(t):
@@ -287,8 +304,8 @@ def _cache_hit(key, w, version=None):
         return None
     if hit[5] != (_gen(w) if version is None else version):
         return None
-    cur = torch.cuda.current_stream()
-    if hit[4] != cur.cuda_stream:
+    if hit[4] != _stream_id():  # raw handles first: building a Stream object costs more than the whole lookup
+        cur = torch.cuda.current_stream()
         cur.wait_event(hit[3])
         for t in (hit[1], hit[2]):
             if t is not None:
@@ -304,7 +321,7 @@ def _cache_put(key, w_param, wf, wb, version=None, recipe=None):
         _PACK_CACHE.clear()
     ev = torch.cuda.Event()
     ev.record()
-    _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, torch.cuda.current_stream().cuda_stream,
+    _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, _stream_id(),
                         _gen(w_param) if version is None else version)
     if recipe is not None:
         if len(_PACK_RECIPES) >= 4 * _PACK_CACHE_MAX:

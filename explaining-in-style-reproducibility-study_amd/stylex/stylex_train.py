@@ -1104,7 +1104,8 @@ class Trainer:
         if not exists(self.StylEx):
             self.init_StylEx()
         m = self.StylEx
-        m.train()
+        if not m.training:  # Module.train() walks ~500 submodules: only when evaluate() / a caller left eval mode on
+            m.train()
         gae = self.gradient_accumulate_every
         apply_gp = self.steps % self.gp_every == 0
         apply_pl = (not self.no_pl_reg) and self.steps > self.pl_after and self.steps % self.pl_every == 0
