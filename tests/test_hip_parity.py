@@ -653,12 +653,14 @@ def test_loss_curve_short_horizon_vs_reference():
     assert err[2].max() <= 2e-2, err  # third call: losses of order 1e4, still within 2 %
 
 
-def test_config2_full_size_bf16_train_calls(tmp_path):
-    """BASELINE config 2 whole, as bench.py builds it: 256 px, batch 32, GAE 2, ResNet-18 classifier, bf16 — two
-    train() calls (the first is a gradient-penalty step) through every full-size kernel path of the step.  Asserted:
-    all scalars finite, every parameter finite, and the first call's losses inside the band an untrained StylEx
-    produces on uniform-noise batches with these seeds (measured: d 13.97, g 9.30, rec 3.54, kl 1.30, gp 12.49; the
-    second call already shows the untrained GAN's excursions, g 2e4, which is why only call 0 is banded)."""
+def test_config2_full_size_bf16_tracks_fp32(tmp_path):
+    """BASELINE config 2 whole, as bench.py builds it: 256 px, batch 32, GAE 2, ResNet-18 classifier — two train() calls
+    (the first is a gradient-penalty step) through every full-size kernel path of the step, in the bf16 speed mode AND
+    in the fp32 parity mode from the same seeds.  Asserted: everything finite, and the first call of the speed mode
+    inside the bf16 band of the parity mode for EVERY scalar — d_loss, g_loss (evaluated on the discriminator D's
+    optimiser step has just updated: 1020 vs 1038; a stale operand cache gave 9.3 here until round 3), rec, kl within
+    5e-2, the penalty within 1e-1.  The second call already shows the untrained GAN's excursions and is only required
+    to be finite."""
     import argparse
     import os
     import sys
@@ -668,23 +670,32 @@ def test_config2_full_size_bf16_train_calls(tmp_path):
         sys.path.insert(0, root)
     import bench
 
-    ops.set_precision("bf16")
+    res = {}
     try:
-        a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir=str(tmp_path), precision="bf16")
-        tr = bench.build_trainer(a, torch.device(DEV), 0, 1)
-        rows = []
-        for _ in range(2):
-            tr.train()
-            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss, tr.last_gp_loss])
-        torch.cuda.synchronize()
-        rows = np.array(rows, dtype=np.float64)
-        print("config 2, two calls:", rows)
-        assert np.isfinite(rows).all(), rows
-        assert all(bool(torch.isfinite(p).all()) for p in tr.StylEx.parameters())
-        d0, g0, rec0, kl0, gp0 = rows[0]
-        assert 7.0 < d0 < 28.0 and 1.7 < rec0 < 7.0 and 0.0 <= kl0 < 5.0 and 3.0 < gp0 < 50.0, rows[0]
+        for prec in ("bf16", "fp32"):
+            ops.set_precision(prec)
+            hb.pack_cache_clear()
+            a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir=str(tmp_path / prec),
+                                   precision=prec)
+            bench.seed_all(42)
+            tr = bench.build_trainer(a, torch.device(DEV), 0, 1)
+            rows = []
+            for _ in range(2):
+                tr.train()
+                rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss, tr.last_gp_loss])
+            torch.cuda.synchronize()
+            assert all(bool(torch.isfinite(p).all()) for p in tr.StylEx.parameters())
+            res[prec] = np.array(rows, dtype=np.float64)
+            del tr
+            torch.cuda.empty_cache()
     finally:
         ops.set_precision("fp32")
+    print("config 2, two calls:", res)
+    assert np.isfinite(res["bf16"]).all() and np.isfinite(res["fp32"]).all(), res
+    lo, ref = res["bf16"][0], res["fp32"][0]
+    scale = np.maximum(1.0, np.abs(ref))
+    assert (np.abs(lo[:4] - ref[:4]) <= 5e-2 * scale[:4]).all(), (lo, ref)
+    assert abs(lo[4] - ref[4]) <= 1e-1 * scale[4], (lo, ref)
 
 
 def test_loss_curve_inside_reference_envelope():
