@@ -134,7 +134,7 @@ def cpu_baseline(args):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import stylex_oracle as so
     from lpips_standin import LPIPSStandIn
-    from ref_shim import TinyClassifier
+    from standins import TinyClassifier
 
     # the oracle's grouped convolutions stop scaling (and collapse under oversubscription) beyond a
     # handful of threads: 256 threads on the GPU box measured 60x SLOWER than 8.  Use <= 16.

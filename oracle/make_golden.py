@@ -3,7 +3,7 @@ container: it imports the reference (/root/reference) through ``ref_shim`` and
 writes input/expected-output vectors to ``tests/golden/*.npz``.  The vectors are
 data; no reference source travels.
 
-    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,newarch,diffaug,curve,evalsurface,envelope]
+    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,resnet,newarch,diffaug,curve,evalsurface,envelope]
 
 Conventions: every fixture stores the seeds needed to regenerate weights
 (``torch.manual_seed(seed)`` then construct ``StylEx(...)``), all inputs that are
@@ -318,6 +318,39 @@ def gen_cfg4(st):
          logits_batch0=logits)
 
 
+def gen_resnet(st):
+    """A16 — the reference's own ``ResNet`` wrapper (stylex/resnet_classifier.py:29-71: torchvision ``resize`` of the
+    tensor batch to 224x224, ImageNet normalisation, ResNet-18 with a 2-logit head, eval mode, frozen parameters,
+    gradient still flowing to the images) on seeded weights: logits and the input gradient of ``sum(logits * coef)``
+    at 32 and 64 px, with and without normalisation."""
+    mod = ref_shim.import_reference_resnet()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "trained_classifiers"))
+    cls_seed = 55
+    torch.save(ref_shim.seeded_resnet_state(cls_seed), os.path.join(tmp, "trained_classifiers", "rn18_seed55.pth"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    out = {}
+    try:
+        for size in (32, 64):
+            for norm in (True, False):
+                clf = mod.ResNet("rn18_seed55.pth", 0, output_size=2, image_size=size, normalize=norm)
+                assert not clf.model.training and all(not p.requires_grad for p in clf.model.parameters())
+                gd = torch.Generator().manual_seed(100 + size)
+                x = (torch.rand(3, 3, size, size, generator=gd) * 1.5 - 0.25).requires_grad_(True)  # G's range is not [0,1]
+                coef = torch.randn(3, 2, generator=gd)
+                logits = clf.classify_images(x)
+                gx, = torch.autograd.grad((logits * coef).sum(), x)
+                tag = "%d_%s" % (size, "norm" if norm else "raw")
+                out["logits_" + tag] = logits.detach()
+                out["gx_" + tag] = gx
+                out["coef_" + tag] = coef
+                print("resnet", tag, logits.detach().numpy().ravel(), float(gx.abs().sum()))
+    finally:
+        os.chdir(cwd)
+    save("resnet_wrapper", cls_seed=cls_seed, sizes=np.array([32, 64]), batch=3, data_seed_base=100, **out)
+
+
 def gen_newarch(st):
     """N4: the reference's second architecture (stylex/stylex_train_new.py, cli.py:17-22): init parity, conditional-D
     forward, and Trainer.train() x 3 (GAE=2 alternating; step 0 carries the gradient penalty)."""
@@ -503,7 +536,7 @@ def main():
     st = ref_shim.import_reference()
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
-                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
+                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("resnet", gen_resnet), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
                      ("curve", gen_curve), ("evalsurface", gen_evalsurface), ("envelope", gen_envelope)):
         if name in todo:
             if name == "steps" and a.step_cases:

@@ -18,7 +18,7 @@ import attfind_oracle  # noqa: E402
 import ops  # noqa: E402
 import stylex_train as st  # noqa: E402
 from cpu_ops import CpuOracleOps  # noqa: E402
-from ref_shim import TinyClassifier  # noqa: E402
+from standins import TinyClassifier  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden", "attfind_16.npz")
 

@@ -78,7 +78,7 @@ def test_new_architecture_switch_and_evaluate(tmp_path, monkeypatch):
     import stylex_train as st
     import stylex_train_new as stn
     from lpips_standin import LPIPSStandIn
-    from ref_shim import TinyClassifier
+    from standins import TinyClassifier
 
     monkeypatch.setenv("STYLEX_NEW_ARCHITECTURE", "1")
     try:

@@ -35,7 +35,7 @@ def _worker(rank, world, port, tmp, q):
         import stylex_train as st
         from cpu_ops import CpuOracleOps
         from lpips_standin import LPIPSStandIn
-        from ref_shim import TinyClassifier
+        from standins import TinyClassifier
 
         ops.use_impl(CpuOracleOps)
         # (a) GradSync
@@ -239,7 +239,7 @@ def _nan_worker(rank, world, port, tmp, q, on_save_step=False):
         import stylex_train as st
         from cpu_ops import CpuOracleOps
         from lpips_standin import LPIPSStandIn
-        from ref_shim import TinyClassifier
+        from standins import TinyClassifier
 
         ops.use_impl(CpuOracleOps)
         size = 16

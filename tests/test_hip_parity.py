@@ -1154,6 +1154,37 @@ def test_frozen_classifier_fused_tails_match_plain_module():
     close(after_plain, after_fused, 2e-5, "logits after an in-place BatchNorm update")
 
 
+def test_resnet_wrapper_vs_reference_golden_on_hip(tmp_path):
+    """A16 on the GPU: ResNet.classify_images (the classifier of the headline benchmark configuration) against what
+    the REFERENCE's own wrapper class produced (tests/golden/resnet_wrapper.npz from stylex/resnet_classifier.py:29-71
+    on seeded weights): logits and the gradient reaching the images, with the fused elementwise tails (the GPU
+    default) and with the plain module.  Tolerance: the library's fp32 convolutions (Winograd on MIOpen) against the
+    CPU's direct ones through 20 layers — 1e-4 of the logits in the L2 sense; the image gradient can additionally see
+    a ReLU whose input is ~0 flip its gate, hence 5e-3."""
+    from test_host_logic_cpu import make_resnet_wrapper
+    from test_oracle_vs_golden import resnet_wrapper_cases
+
+    def rel(a, ref):
+        ref = torch.as_tensor(np.asarray(ref)).double()
+        return ((a.detach().double().cpu() - ref).norm() / ref.norm()).item()
+
+    g = load_golden("resnet_wrapper")
+    for tag, size, norm, x, coef, logits, gx in resnet_wrapper_cases(g):
+        clf = make_resnet_wrapper(g, tmp_path, size, norm)
+        assert next(clf.model.parameters()).is_cuda
+        for fuse in ("1", "0"):
+            os.environ["STYLEX_FROZEN_FUSE"] = fuse
+            try:
+                xd = x.to(DEV).requires_grad_(True)
+                out = clf.classify_images(xd)
+                got, = torch.autograd.grad((out * coef.to(DEV)).sum(), xd)
+            finally:
+                os.environ.pop("STYLEX_FROZEN_FUSE", None)
+            e = (rel(out, logits), rel(got, gx))
+            assert e[0] <= 1e-4 and e[1] <= 5e-3, (tag, "fuse=" + fuse, e)
+    assert type(clf._net(xd)).__name__ == "FusedTailResNet"
+
+
 def test_lpips_distance_kernels_vs_published_formula():
     """LPIPS-AlexNet forward on the fused tap kernels (default on the GPU) against the published composition
     (STYLEX_LPIPS_FUSE=0: unit-normalise, squared difference, non-negative 1x1 weights, spatial mean, sum over taps):

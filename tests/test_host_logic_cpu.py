@@ -14,7 +14,7 @@ import ops
 import stylex_train as st
 from cpu_ops import CpuOracleOps
 from lpips_standin import LPIPSStandIn
-from ref_shim import TinyClassifier
+from standins import TinyClassifier
 from conftest import load_golden
 from test_oracle_vs_golden import assert_same_stats, close, close_stats, stats, build_nets_model
 
@@ -114,7 +114,7 @@ def make_cfg4_trainer(g, tmp_path, device=None):
     ./trained_classifiers (seeded stand-in weights, oracle/ref_shim.py), path-length + R1 step."""
     import os
 
-    from ref_shim import seeded_mobilenet_state
+    from standins import seeded_mobilenet_state
 
     size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
     os.makedirs(os.path.join(str(tmp_path), "trained_classifiers"), exist_ok=True)
@@ -453,3 +453,37 @@ def test_newarch_step_parity_cpu(tmp_path):
     np.testing.assert_allclose(rows[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
     np.testing.assert_allclose(rows, gold, rtol=1e-3, atol=1e-3, equal_nan=True)
     assert_param_stats(tr, g)
+
+
+def make_resnet_wrapper(g, tmp_path, size, norm):
+    """The product's ResNet wrapper loading the A16 fixture's seeded checkpoint from ./trained_classifiers, the way
+    Trainer(classifier_name='resnet') does (reference resnet_classifier.py:16-26)."""
+    import os
+
+    import resnet_classifier as rc
+    from standins import seeded_resnet_state
+
+    os.makedirs(os.path.join(str(tmp_path), "trained_classifiers"), exist_ok=True)
+    torch.save(seeded_resnet_state(int(g["cls_seed"])), os.path.join(str(tmp_path), "trained_classifiers", "rn18.pth"))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        return rc.ResNet("rn18.pth", 0, output_size=2, image_size=size, normalize=norm)
+    finally:
+        os.chdir(cwd)
+
+
+def test_resnet_wrapper_vs_reference_golden_cpu(tmp_path):
+    """A16 on the CPU double: ResNet.classify_images of the product against the reference wrapper's own logits and
+    input gradient (tests/golden/resnet_wrapper.npz)."""
+    from test_oracle_vs_golden import close, resnet_wrapper_cases
+
+    g = load_golden("resnet_wrapper")
+    for tag, size, norm, x, coef, logits, gx in resnet_wrapper_cases(g):
+        clf = make_resnet_wrapper(g, tmp_path, size, norm)
+        assert not clf.model.training and all(not p.requires_grad for p in clf.model.parameters())
+        x = x.clone().requires_grad_(True)
+        out = clf.classify_images(x)
+        close(logits, out, 1e-5)
+        got, = torch.autograd.grad((out * coef).sum(), x)
+        close(gx, got, 1e-5)

@@ -69,7 +69,7 @@ def test_trainer_with_device_pipeline_and_device_rng_gpu(tmp_path):
     batches the Trainer consumes equal the host pipeline's for training-size images."""
     import ops
     from lpips_standin import LPIPSStandIn
-    from ref_shim import TinyClassifier
+    from standins import TinyClassifier
 
     dev = torch.device("cuda:0")
     folder = make_folder(tmp_path, [(32, 32)] * 8)

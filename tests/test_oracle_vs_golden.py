@@ -10,7 +10,7 @@ import torch
 
 import stylex_oracle as so
 from lpips_standin import LPIPSStandIn
-from ref_shim import TinyClassifier
+from standins import TinyClassifier
 from conftest import load_golden
 
 TOL = 2e-5
@@ -242,12 +242,12 @@ def test_step_parity(tag):
 def test_step_parity_config4_mobilenet():
     """BASELINE config 4 in miniature (MobileNetV2 wrapper, R1 + path-length step): the oracle, with its restatement
     of MobileNet.classify_images, reproduces what the reference's Trainer + its own wrapper class produced."""
-    import ref_shim
+    import standins
 
     g = load_golden("steps_cfg4")
-    net = ref_shim._tv_models().MobileNetV2()
+    net = standins._tv_models().MobileNetV2()
     net.classifier[1] = torch.nn.Linear(1280, 2)
-    net.load_state_dict(ref_shim.seeded_mobilenet_state(int(g["cls_seed"])))
+    net.load_state_dict(standins.seeded_mobilenet_state(int(g["cls_seed"])))
     cls = so.OFrozenClassifier(net, "mobilenet", image_size=int(g["config"][0]))
     gd = torch.Generator().manual_seed(int(g["data_seed"]))
     first = torch.rand(int(g["config"][3]), 3, int(g["config"][0]), int(g["config"][0]), generator=gd)
@@ -259,3 +259,35 @@ def test_step_parity_config4_mobilenet():
     params = dict(tr.model.named_parameters())
     for n, gs in zip(g["param_names"], g["param_stats"]):
         close_stats(gs, params[str(n)], 2e-3, head_atol=1e-4)
+
+
+def resnet_wrapper_cases(g):
+    """(tag, size, normalize, images, coef, logits, gx) of tests/golden/resnet_wrapper.npz (A16: captured from the
+    reference's own ResNet wrapper class, stylex/resnet_classifier.py:29-71)."""
+    for size in (int(v) for v in g["sizes"]):
+        for norm in (True, False):
+            tag = "%d_%s" % (size, "norm" if norm else "raw")
+            gd = torch.Generator().manual_seed(int(g["data_seed_base"]) + size)
+            x = torch.rand(int(g["batch"]), 3, size, size, generator=gd) * 1.5 - 0.25
+            coef = torch.randn(int(g["batch"]), 2, generator=gd)
+            np.testing.assert_array_equal(coef.numpy(), g["coef_" + tag])
+            yield tag, size, norm, x, coef, g["logits_" + tag], g["gx_" + tag]
+
+
+def test_resnet_wrapper_oracle_vs_reference_golden():
+    """A16: the oracle's restatement of ResNet.classify_images (bilinear resize to 224 without antialias, ImageNet
+    normalisation, eval-mode frozen ResNet-18) against the reference wrapper's logits AND the gradient it sends back
+    to the images."""
+    import standins
+
+    g = load_golden("resnet_wrapper")
+    net = standins._tv_models().ResNet18()
+    net.fc = torch.nn.Linear(512, 2)
+    net.load_state_dict(standins.seeded_resnet_state(int(g["cls_seed"])))
+    for tag, size, norm, x, coef, logits, gx in resnet_wrapper_cases(g):
+        cls = so.OFrozenClassifier(net, "resnet", image_size=size, normalize=norm)
+        x = x.clone().requires_grad_(True)
+        out = cls.classify_images(x)
+        close(logits, out, 1e-5)
+        got, = torch.autograd.grad((out * coef).sum(), x)
+        close(gx, got, 1e-5)

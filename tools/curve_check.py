@@ -13,7 +13,7 @@ sys.path[:0] = [os.path.join(ROOT, "explaining-in-style-reproducibility-study_am
 import ops  # noqa: E402
 import stylex_train as st  # noqa: E402
 from lpips_standin import LPIPSStandIn  # noqa: E402
-from ref_shim import TinyClassifier  # noqa: E402
+from standins import TinyClassifier  # noqa: E402
 
 
 def run(n=100, precision="fp32", fast=None):
