@@ -51,11 +51,16 @@ def collate_raw(items):
 
 
 def target_geometry(h, w, s):
-    """(resized_h, resized_w, top, left) of Resize(s) + CenterCrop(s): shorter side -> s (aspect kept, rounded), crop
-    offsets floor((side - s) / 2) — the same arithmetic as stylex_train.Dataset.__getitem__."""
-    scale = s / min(w, h)
-    rw, rh = max(s, round(w * scale)), max(s, round(h * scale))
-    return rh, rw, (rh - s) // 2, (rw - s) // 2
+    """(resized_h, resized_w, top, left) of Resize(s) + CenterCrop(s) — the arithmetic of stylex_train.Dataset
+    (= torchvision 0.11.1 on PIL images: shorter side -> s, longer side int(s * long / short) TRUNCATED, an image whose
+    shorter side already is s untouched; crop offsets int(round((side - s) / 2.0)), round-half-to-even)."""
+    short, long = (w, h) if w <= h else (h, w)
+    if short == s:
+        rw, rh = w, h
+    else:
+        new_long = int(s * long / short)
+        rw, rh = (s, new_long) if w <= h else (new_long, s)
+    return rh, rw, int(round((rh - s) / 2.0)), int(round((rw - s) / 2.0))
 
 
 class DevicePreprocessor:

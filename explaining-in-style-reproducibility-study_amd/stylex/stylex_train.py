@@ -389,7 +389,58 @@ def classifier_kl_loss(real_classifier_logits, fake_classifier_logits):
 # ------------------------------------------------------------------------------------------
 
 
+def resize_geometry(w, h, s):
+    """Size after the reference's ``resize_to_minimum_size`` + ``transforms.Resize(s)`` (:480-483, :535-536) on a PIL
+    image, i.e. torchvision 0.11.1 ``functional_pil.resize`` with an int size: the SHORTER side becomes s, the longer
+    one int(s * long / short) (truncated, not rounded), and an image whose shorter side already is s is returned
+    untouched.  (The minimum-size step resizes a too-small image the same way, after which Resize is the identity.)"""
+    short, long = (w, h) if w <= h else (h, w)
+    if short == s:
+        return w, h
+    new_long = int(s * long / short)
+    return (s, new_long) if w <= h else (new_long, s)
+
+
+def center_crop_offsets(w, h, s):
+    """(left, top) of ``transforms.CenterCrop(s)``: torchvision computes int(round((side - s) / 2.0)) with Python's
+    round-half-to-even (a 37-wide image is cropped from column 2, a 35-wide one from column 2 as well)."""
+    return int(round((w - s) / 2.0)), int(round((h - s) / 2.0))
+
+
+def random_resized_crop_box(w, h, scale=(0.5, 1.0), ratio=(0.98, 1.02)):
+    """(top, left, height, width) of ``transforms.RandomResizedCrop.get_params`` (torchvision 0.11.1) with the
+    reference's arguments (:537): up to 10 attempts, each drawing an area fraction and a log-uniform aspect ratio from
+    torch's GLOBAL generator (``torch.empty(1).uniform_``), the first box that fits gets ``torch.randint`` offsets;
+    otherwise the central fallback box."""
+    area = h * w
+    log_ratio = torch.log(torch.tensor(ratio))
+    for _ in range(10):
+        target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        aspect = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+        cw = int(round(math.sqrt(target_area * aspect)))
+        ch = int(round(math.sqrt(target_area / aspect)))
+        if 0 < cw <= w and 0 < ch <= h:
+            top = torch.randint(0, h - ch + 1, size=(1,)).item()
+            left = torch.randint(0, w - cw + 1, size=(1,)).item()
+            return top, left, ch, cw
+    in_ratio = float(w) / float(h)
+    if in_ratio < min(ratio):
+        cw, ch = w, int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        ch, cw = h, int(round(h * max(ratio)))
+    else:
+        cw, ch = w, h
+    return (h - ch) // 2, (w - cw) // 2, ch, cw
+
+
 class Dataset(data.Dataset):
+    """Reference ``Dataset`` (:520-547) without torchvision: the transform chain is spelled out on PIL — mode
+    conversion (:443-452), Resize, ``RandomApply(aug_prob, RandomResizedCrop(scale=(0.5, 1), ratio=(0.98, 1.02)),
+    CenterCrop)`` (ONE Python ``random()`` per item even at aug_prob 0, :96 — with ``num_workers=0``, the DDP
+    default :1238, those draws interleave with the Trainer's own), ToTensor (bytes / 255 in float32).  After the mode
+    conversion the channel count always matches, so ``expand_greyscale`` (:455-477) is the identity.  Pinned by
+    tests/golden/dataset_items.npz, captured from the reference class."""
+
     def __init__(self, folder, image_size, transparent=False, aug_prob=0.):
         super().__init__()
         self.folder, self.image_size, self.transparent, self.aug_prob = folder, image_size, transparent, aug_prob
@@ -402,16 +453,23 @@ class Dataset(data.Dataset):
     def __getitem__(self, index):
         from PIL import Image
 
-        img = Image.open(self.paths[index]).convert("RGBA" if self.transparent else "RGB")
+        img = Image.open(self.paths[index])
+        mode = "RGBA" if self.transparent else "RGB"
+        if img.mode != mode:
+            img = img.convert(mode)
         s = self.image_size
+        size = resize_geometry(*img.size, s)
+        if size != img.size:
+            img = img.resize(size, Image.BILINEAR)
         w, h = img.size
-        scale = s / min(w, h)  # Resize(image_size): shorter side -> image_size
-        img = img.resize((max(s, round(w * scale)), max(s, round(h * scale))), Image.BILINEAR)
-        w, h = img.size
-        left, top = (w - s) // 2, (h - s) // 2
-        img = img.crop((left, top, left + s, top + s))  # CenterCrop (aug_prob=0 path)
-        arr = np.asarray(img, dtype=np.float32) / 255.0
-        return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
+        if random() < self.aug_prob:
+            top, left, ch, cw = random_resized_crop_box(w, h)
+            img = img.crop((left, top, left + cw, top + ch)).resize((s, s), Image.BILINEAR)
+        else:
+            left, top = center_crop_offsets(w, h, s)
+            img = img.crop((left, top, left + s, top + s))
+        arr = np.array(img, dtype=np.uint8)
+        return torch.from_numpy(arr).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
 
 
 class MNIST_1vA(data.Dataset):

@@ -3,7 +3,7 @@ container: it imports the reference (/root/reference) through ``ref_shim`` and
 writes input/expected-output vectors to ``tests/golden/*.npz``.  The vectors are
 data; no reference source travels.
 
-    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,resnet,newarch,diffaug,curve,evalsurface,envelope]
+    python oracle/make_golden.py [--only init,ops,nets,losses,steps,cfg4,resnet,dataset,newarch,diffaug,curve,calm,evalsurface,envelope]
 
 Conventions: every fixture stores the seeds needed to regenerate weights
 (``torch.manual_seed(seed)`` then construct ``StylEx(...)``), all inputs that are
@@ -351,6 +351,57 @@ def gen_resnet(st):
     save("resnet_wrapper", cls_seed=cls_seed, sizes=np.array([32, 64]), batch=3, data_seed_base=100, **out)
 
 
+DATASET_IMAGES = [
+    # (mode, height, width): the training size is 32
+    ("RGB", 32, 32), ("RGB", 48, 40), ("RGB", 40, 64), ("RGB", 70, 33), ("RGB", 33, 70), ("RGB", 32, 57),
+    ("RGB", 37, 32), ("RGB", 20, 14), ("L", 45, 36), ("RGBA", 40, 40), ("LA", 36, 50), ("P", 64, 64),
+]
+
+
+def gen_dataset(st):
+    """N2 — the reference's ``Dataset`` (stylex_train.py:520-547) run on PNG files of assorted sizes and modes:
+    mode conversion, ``resize_to_minimum_size`` (:480-483), ``Resize`` + ``RandomApply(aug_prob, RandomResizedCrop,
+    CenterCrop)`` (one Python ``random()`` per item even at aug_prob 0), ``ToTensor``, ``expand_greyscale``.  The
+    torchvision 0.11.1 calls underneath are the restatements of ``ref_shim`` (package absent offline).  The fixture
+    stores the PNG FILES (bytes) as inputs and the tensors ``__getitem__`` returned, for aug_prob 0 and 1 and for
+    ``transparent=True``; plus the state of Python's ``random`` after the items, which pins the draw count."""
+    import io
+
+    from PIL import Image
+
+    size = 32
+    rng = np.random.RandomState(11)
+    tmp = tempfile.mkdtemp()
+    out = {}
+    for i, (mode, h, w) in enumerate(DATASET_IMAGES):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 100 * np.sin(xx / 5.0 + i), 127 + 100 * np.cos(yy / 4.0), (7 * xx + 3 * yy) % 256,
+                         255 * ((xx + yy) % 7 > 2)], axis=-1)
+        base = np.clip(base + rng.randint(-20, 20, base.shape), 0, 255).astype(np.uint8)
+        img = {"RGB": lambda: Image.fromarray(base[..., :3], "RGB"), "RGBA": lambda: Image.fromarray(base, "RGBA"),
+               "L": lambda: Image.fromarray(base[..., 0], "L"),
+               "LA": lambda: Image.fromarray(np.ascontiguousarray(base[..., [0, 3]]), "LA"),
+               "P": lambda: Image.fromarray(base[..., :3], "RGB").quantize(16)}[mode]()
+        buf = io.BytesIO()
+        img.save(buf, format="PNG")
+        out["png_%02d" % i] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+        with open(os.path.join(tmp, "%02d.png" % i), "wb") as f:
+            f.write(buf.getvalue())
+    for tag, kw in (("p0", dict(aug_prob=0.)), ("p1", dict(aug_prob=1.)), ("half", dict(aug_prob=0.5)),
+                    ("transparent", dict(transparent=True))):
+        ds = st.Dataset(tmp, size, **kw)
+        order = sorted(range(len(ds)), key=lambda k: ds.paths[k].name)
+        seed_all(5)
+        items = [ds[k] for k in order]
+        assert all(t.shape == (4 if tag == "transparent" else 3, size, size) for t in items), [t.shape for t in items]
+        out["items_" + tag] = torch.stack(items)
+        out["pyrandom_after_" + tag] = random.random()
+        out["torchrand_after_" + tag] = torch.rand(()).item()
+        print("dataset", tag, float(out["items_" + tag].sum()))
+    save("dataset_items", image_size=size, modes=np.array([m for m, _, _ in DATASET_IMAGES]),
+         shapes=np.array([[h, w] for _, h, w in DATASET_IMAGES]), seed=5, **out)
+
+
 def gen_newarch(st):
     """N4: the reference's second architecture (stylex/stylex_train_new.py, cli.py:17-22): init parity, conditional-D
     forward, and Trainer.train() x 3 (GAE=2 alternating; step 0 carries the gradient penalty)."""
@@ -446,6 +497,52 @@ def gen_curve(st, n=100):
          threads=torch.get_num_threads())
 
 
+def gen_curve_calm(st, n=100, lr=1e-6, start=4960):
+    """X1 — a 100-call scalar trajectory of the reference in a NON-chaotic regime: config-1 shape (64 px, capacity 16,
+    B=4) at GAE=2 with lr = 1e-6, so that Adam's sign-like steps (<= lr per element and call) stay far below the
+    amplification threshold of the untrained GAN and the trajectory is a function of the schedule and the random
+    draws, not of rounding.  The window starts at step 4960 so that the 100 calls contain everything ``train()``
+    schedules by step count (stylex_train.py:1272-1274, 1471-1479): the gradient penalty on every 4th call, the
+    path-length penalty + ``pl_mean`` EMA at 5024 and 5056 (> 5000 and % 32 == 0, not 4992),
+    ``reset_parameter_averaging`` at 5002, the noise / encoder alternation and the rec / KL cadence, and the RNG draw
+    order of all of them.  Run twice — 8 and 4 intra-op threads — so the fixture carries the reference's own
+    summation-order spread next to the trajectory (the tests hold 1e-3 on EVERY call; the spread shows that the
+    reference holds it against itself here)."""
+    size, cap, fmax, bs, gae = 64, 16, 512, 4, 2
+    out, keep = {}, torch.get_num_threads()
+    for threads in (8, 4):
+        torch.set_num_threads(threads)
+        cls = ref_shim.TinyClassifier(seed=99)
+        gd = torch.Generator().manual_seed(7)
+        batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+        seed_all(42)
+        tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), cls, batches, image_size=size,
+                                             network_capacity=cap, fmap_max=fmax, batch_size=bs,
+                                             gradient_accumulate_every=gae, lr=lr, ttur_mult=1.5, rec_scaling=1,
+                                             kl_scaling=1)
+        tr.init_StylEx()
+        tr.steps = start
+        rows, t0 = [], time.time()
+        for i in range(n):
+            tr.train()
+            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                         tr.last_gp_loss if tr.last_gp_loss is not None else np.nan,
+                         tr.pl_mean if tr.pl_mean is not None else np.nan])
+            if i % 10 == 0 or tr.steps - 1 in (5024, 5056):
+                print("calm t%d" % threads, tr.steps - 1, rows[-1], "%.0fs" % (time.time() - t0), flush=True)
+        out["scalars_t%d" % threads] = np.array(rows, dtype=np.float64)
+        if threads == 8:
+            names, pst = param_stats(tr.StylEx)
+            out.update(param_names=names, param_stats=pst)
+    torch.set_num_threads(keep)
+    a, b = out["scalars_t8"], out["scalars_t4"]
+    rel = np.nanmax(np.abs(a - b) / np.maximum(np.abs(a), 1e-3), axis=1)
+    print("reference vs itself (8 vs 4 threads), max relative difference per call: max %.3e, at call %d"
+          % (rel.max(), int(rel.argmax())))
+    save("curve_64_calm", config=np.array([size, cap, fmax, bs, gae, 1, n, start]), lr=lr, seed=42, data_seed=7,
+         cls_seed=99, lpips_seed=4242, scalars=out.pop("scalars_t8"), self_rel=rel, **out)
+
+
 def gen_envelope(st, n=12):
     """X1 — the reference against ITSELF: the curve_64 run (config-1 shape, 8 threads) repeated with 4 and with 2
     intra-op threads.  Only the summation order of the CPU kernels changes, yet the untrained GAN amplifies it
@@ -536,8 +633,8 @@ def main():
     st = ref_shim.import_reference()
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
-                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("resnet", gen_resnet), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
-                     ("curve", gen_curve), ("evalsurface", gen_evalsurface), ("envelope", gen_envelope)):
+                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("resnet", gen_resnet), ("dataset", gen_dataset), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
+                     ("curve", gen_curve), ("calm", gen_curve_calm), ("evalsurface", gen_evalsurface), ("envelope", gen_envelope)):
         if name in todo:
             if name == "steps" and a.step_cases:
                 fn(st, set(a.step_cases.split(",")))

@@ -73,6 +73,14 @@ class _Compose:
         return x
 
 
+class _Lambda:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, x):
+        return self.fn(x)
+
+
 class _Normalize:
     def __init__(self, mean, std):
         self.mean = torch.tensor(mean).view(1, -1, 1, 1)
@@ -80,6 +88,116 @@ class _Normalize:
 
     def __call__(self, x):
         return (x - self.mean.to(x)) / self.std.to(x)
+
+
+# ---- torchvision==0.11.1 transforms on PIL images, restated (package absent offline: "parity unpinned" at this
+# boundary; the REFERENCE's use of them — order, arguments, RandomApply draw, mode conversion — is what the Dataset
+# fixture pins).  Each function names the torchvision function it restates.
+
+def _tv_resize(img, size):
+    """torchvision.transforms.functional.resize: tensors -> F.interpolate(bilinear, align_corners=False, no antialias)
+    (functional_tensor.resize, used by resnet_classifier.py:61); PIL images -> functional_pil.resize: an int size
+    scales the SHORTER side to `size` and the longer one to int(size * long / short) (truncation), returns the image
+    unchanged when the shorter side already equals `size`; a (h, w) pair resizes to exactly that.  PIL bilinear."""
+    if isinstance(img, torch.Tensor):
+        return F.interpolate(img, size=size, mode="bilinear", align_corners=False)
+    from PIL import Image
+
+    if isinstance(size, (list, tuple)) and len(size) == 1:
+        size = size[0]
+    if isinstance(size, int):
+        w, h = img.size
+        short, long = (w, h) if w <= h else (h, w)
+        if short == size:
+            return img
+        new_short, new_long = size, int(size * long / short)
+        new_w, new_h = (new_short, new_long) if w <= h else (new_long, new_short)
+        return img.resize((new_w, new_h), Image.BILINEAR)
+    return img.resize(tuple(size[::-1]), Image.BILINEAR)
+
+
+class _Resize:
+    def __init__(self, size, *a, **k):
+        self.size = size
+
+    def __call__(self, img):
+        return _tv_resize(img, self.size)
+
+
+class _CenterCrop:
+    """transforms.CenterCrop(int) -> functional.center_crop: offsets int(round((side - crop) / 2.0)) — Python's
+    round-half-to-even — after zero-padding an image smaller than the crop."""
+
+    def __init__(self, size):
+        self.size = (int(size), int(size)) if isinstance(size, int) else tuple(size)
+
+    def __call__(self, img):
+        from PIL import ImageOps
+
+        ch, cw = self.size
+        w, h = img.size
+        if cw > w or ch > h:
+            l, t = (cw - w) // 2 if cw > w else 0, (ch - h) // 2 if ch > h else 0
+            r, b = (cw - w + 1) // 2 if cw > w else 0, (ch - h + 1) // 2 if ch > h else 0
+            img = ImageOps.expand(img, border=(l, t, r, b), fill=0)
+            w, h = img.size
+            if (cw, ch) == (w, h):
+                return img
+        top, left = int(round((h - ch) / 2.0)), int(round((w - cw) / 2.0))
+        return img.crop((left, top, left + cw, top + ch))
+
+
+class _RandomResizedCrop:
+    """transforms.RandomResizedCrop(size, scale, ratio): get_params draws (torch global RNG) up to 10 x
+    [uniform area fraction, log-uniform aspect ratio], takes the first box that fits with randint offsets, else the
+    central fallback; forward = functional.resized_crop = crop, then resize to (size, size) bilinear."""
+
+    def __init__(self, size, scale=(0.08, 1.0), ratio=(3. / 4., 4. / 3.)):
+        self.size = (int(size), int(size)) if isinstance(size, int) else tuple(size)
+        self.scale, self.ratio = scale, ratio
+
+    @staticmethod
+    def get_params(img, scale, ratio):
+        import math
+
+        width, height = img.size
+        area = height * width
+        log_ratio = torch.log(torch.tensor(ratio))
+        for _ in range(10):
+            target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+            aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+            w = int(round(math.sqrt(target_area * aspect_ratio)))
+            h = int(round(math.sqrt(target_area / aspect_ratio)))
+            if 0 < w <= width and 0 < h <= height:
+                i = torch.randint(0, height - h + 1, size=(1,)).item()
+                j = torch.randint(0, width - w + 1, size=(1,)).item()
+                return i, j, h, w
+        in_ratio = float(width) / float(height)
+        if in_ratio < min(ratio):
+            w = width
+            h = int(round(w / min(ratio)))
+        elif in_ratio > max(ratio):
+            h = height
+            w = int(round(h * max(ratio)))
+        else:
+            w, h = width, height
+        return (height - h) // 2, (width - w) // 2, h, w
+
+    def __call__(self, img):
+        i, j, h, w = self.get_params(img, self.scale, self.ratio)
+        return _tv_resize(img.crop((j, i, j + w, i + h)), self.size)
+
+
+class _ToTensor:
+    """transforms.ToTensor -> functional.to_tensor for 8-bit PIL modes: HWC bytes -> CHW float32, .div(255)."""
+
+    def __call__(self, pic):
+        import numpy as np
+
+        arr = np.array(pic, np.uint8, copy=True)
+        if arr.ndim == 2:
+            arr = arr[:, :, None]
+        return torch.from_numpy(arr).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
 
 
 def _install_stubs():
@@ -100,14 +218,14 @@ def _install_stubs():
     kf = mod("kornia.filters", filter2d=_filter2d)
     mod("kornia", filters=kf)
 
-    tf = mod("torchvision.transforms.functional",
-             resize=lambda x, s: F.interpolate(x, size=s, mode="bilinear", align_corners=False))
-    tr_attrs = dict(Compose=_Compose, Lambda=_Identity, Resize=_Identity, RandomResizedCrop=_Identity,
-                    CenterCrop=_Identity, ToTensor=_Identity, Normalize=_Normalize, ToPILImage=_Identity,
+    tf = mod("torchvision.transforms.functional", resize=_tv_resize)
+    tr_attrs = dict(Compose=_Compose, Lambda=_Lambda, Resize=_Resize, RandomResizedCrop=_RandomResizedCrop,
+                    CenterCrop=_CenterCrop, ToTensor=_ToTensor, Normalize=_Normalize, ToPILImage=_Identity,
                     functional=tf)
     tt = mod("torchvision.transforms", **tr_attrs)
     tt.transforms = tt  # `from torchvision.transforms import transforms`
     tv = mod("torchvision", transforms=tt)
+    tv.transforms.functional = tf  # `torchvision.transforms.functional.resize` (stylex_train.py:482)
     tv.utils = types.SimpleNamespace(save_image=lambda *a, **k: None, make_grid=lambda x, **k: x)
     tv.datasets = types.SimpleNamespace()
     mod("retry", api=None)

@@ -27,7 +27,7 @@ def make_folder(tmp_path, sizes):
 
 def run(device, tmp_path):
     s = 32
-    sizes = [(32, 32), (32, 32), (48, 40), (40, 64), (70, 33), (32, 57)]
+    sizes = [(32, 32), (32, 32), (48, 40), (40, 64), (70, 33), (32, 57), (37, 32)]
     folder = make_folder(tmp_path, sizes)
     host = st.Dataset(str(folder), s)
     raw = ip.RawImageFolder(str(folder), s)
@@ -43,9 +43,13 @@ def run(device, tmp_path):
         else:
             assert float((got - want).abs().max()) <= 1.5 / 255 + 1e-6, (i, float((got - want).abs().max()))
     # geometry: the crop window of a non-square image is the host path's
-    assert ip.target_geometry(70, 33, 32) == (68, 32, 18, 0)
+    assert ip.target_geometry(70, 33, 32) == (67, 32, 18, 0)  # int(32 * 70 / 33) = 67 (truncated); round(17.5) = 18
+    assert ip.target_geometry(37, 32, 32) == (37, 32, 2, 0)  # shorter side already 32: untouched; round(2.5) = 2
+    for h, w in sizes:
+        rh, rw, top, left = ip.target_geometry(h, w, s)
+        assert (rw, rh) == st.resize_geometry(w, h, s) and (left, top) == st.center_crop_offsets(rw, rh, s)
     # prefetcher: same batches, same order as the plain loader
-    batches = [[raw[i] for i in range(j, j + 2)] for j in range(0, 6, 2)]
+    batches = [[raw[i] for i in range(j, j + 2)] for j in range(0, 6, 2)]  # the first six images
     pf = ip.Prefetcher(iter(batches), pre, device, depth=2)
     got = list(pf)
     assert len(got) == 3
@@ -91,3 +95,70 @@ def test_trainer_with_device_pipeline_and_device_rng_gpu(tmp_path):
     finally:
         st._Staging.DEVICE_RNG = prev
         ops.set_precision("fp32")
+
+
+def load_dataset_fixture(tmp_path):
+    """tests/golden/dataset_items.npz -> (folder with the fixture's PNG files, fixture).  The PNG bytes are the INPUT
+    data of the fixture; the expected tensors come from the reference's own Dataset class (oracle/make_golden.py
+    gen_dataset)."""
+    from conftest import load_golden
+
+    g = load_golden("dataset_items")
+    d = tmp_path / "fixture_imgs"
+    d.mkdir()
+    for i in range(len(g["modes"])):
+        (d / ("%02d.png" % i)).write_bytes(g["png_%02d" % i].tobytes())
+    return d, g
+
+
+@pytest.mark.parametrize("tag,kw", [("p0", dict(aug_prob=0.)), ("p1", dict(aug_prob=1.)), ("half", dict(aug_prob=0.5)),
+                                    ("transparent", dict(transparent=True))])
+def test_dataset_getitem_vs_reference_golden(tmp_path, tag, kw):
+    """N2, host leg: Dataset.__getitem__ against the tensors the REFERENCE's Dataset (stylex_train.py:520-547)
+    returned for the same PNG files — RGB / greyscale / palette / alpha modes, sizes that exercise the truncated
+    longer side, the round-half-even crop offset, the shorter-side-already-right shortcut and the minimum-size
+    resize; aug_prob 0 / 0.5 / 1 (RandomResizedCrop parameters from torch's global generator), transparent=True —
+    bit for bit, and the Python / torch generators end in the same state (same number of draws)."""
+    import random
+
+    folder, g = load_dataset_fixture(tmp_path)
+    ds = st.Dataset(str(folder), int(g["image_size"]), **kw)
+    order = sorted(range(len(ds)), key=lambda k: ds.paths[k].name)
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    items = torch.stack([ds[k] for k in order])
+    want = torch.from_numpy(g["items_" + tag])
+    assert items.shape == want.shape
+    bad = [i for i in range(len(order)) if not torch.equal(items[i], want[i])]
+    assert not bad, ("items differing from the reference's", bad, [tuple(g["shapes"][i]) for i in bad])
+    assert random.random() == float(g["pyrandom_after_" + tag])
+    assert torch.rand(()).item() == float(g["torchrand_after_" + tag])
+
+
+def check_device_pipeline_vs_reference(device, tmp_path):
+    folder, g = load_dataset_fixture(tmp_path)
+    s = int(g["image_size"])
+    raw = ip.RawImageFolder(str(folder), s)
+    order = sorted(range(len(raw)), key=lambda k: raw.paths[k].name)
+    pre = ip.DevicePreprocessor(s, device)
+    want = torch.from_numpy(g["items_p0"])
+    for pos, k in enumerate(order):
+        h, w = (int(v) for v in g["shapes"][pos])
+        got = pre([raw[k]])[0].cpu()
+        if min(h, w) == s:  # no resampling on either side: bit-identical to the reference's tensor
+            assert torch.equal(got, want[pos]), (pos, h, w)
+        else:  # the host path rounds to bytes after ITS resize; PIL's fixed-point bilinear vs the float one
+            assert float((got - want[pos]).abs().max()) <= 1.5 / 255 + 1e-6, (pos, h, w)
+
+
+def test_device_pipeline_vs_reference_golden_cpu(tmp_path):
+    """N2, device leg against the REFERENCE's tensors (not against the product's own host Dataset)."""
+    check_device_pipeline_vs_reference(torch.device("cpu"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_device_pipeline_vs_reference_golden_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    check_device_pipeline_vs_reference(torch.device("cuda:0"), tmp_path)
