@@ -41,6 +41,15 @@ struct StylexPipeArgs {
     int dbg;                         // ablation switches of tools/bench_pipe.py (STYLEX_PIPE_DBG): 1 no stores, 2 every halo from tile 0, 4 every weight tile from n0 = 0, 8 do not wait for the epilogue stores, 16 store full 128-byte lines (8 and 16: WRONG results, timing ablations only)
 };
 
+// The ablation switches (some of which give WRONG results by design) exist only in a -DSTYLEX_PIPE_ABLATION build
+// (`make ABLATION=1`, used by tools/bench_pipe.py); the production kernel compiles them out.
+#ifdef STYLEX_PIPE_ABLATION
+#define PIPE_DBG (pa.dbg)
+#else
+#define PIPE_DBG 0
+#endif
+
+
 namespace {
 
 typedef StylexPipeArgs PipeArgs;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
     if (bslot >= xn) return;
     // de-phase the CUs (experiment, dbg >> 8 = units of ~0.5 us): all blocks start together and every tile takes the same
     // time, so without it all 256 CUs issue their 128 KiB of output stores in the same microsecond
-    for (int i = (bslot & 3) * (pa.dbg >> 8); i > 0; --i) __builtin_amdgcn_s_sleep(16);
+    for (int i = (bslot & 3) * (PIPE_DBG >> 8); i > 0; --i) __builtin_amdgcn_s_sleep(16);
     const int my_tiles = (xn - bslot + nslots - 1) / nslots;
     const int nchunks = C >> 4;
     const int total = my_tiles * nchunks;
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                         v.z = gatem(v.z, m >> 4);
                         v.w = gatem(v.w, m >> 6);
                     }
-                    if (mask_out && !(pa.dbg & 1))  // one byte per 8 channels, addressed in the pre-transpose layout
+                    if (mask_out && !(PIPE_DBG & 1))  // one byte per 8 channels, addressed in the pre-transpose layout
                         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)stylex_sign_bits8(v), rmask,
                                                              ((row_ok ? g_off : OOB) >> 4) + (j * 4 + q * 2), soff >> 4, 0);
                     R[2 * j + q] = u32x4{v.x, v.y, v.z, v.w};
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
                     R[q][d] = r[0];
                     R[2 + q][d] = r[1];
                 }
-            if (!(pa.dbg & 1)) {
+            if (!(PIPE_DBG & 1)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {  // register k = 2 * (pixel bit 4) + (pixel bit 3): pixels 8k .. 8k + 7
                     const unsigned voff = (row_ok && x0 + 8 * k + (lane & 7) < W) ? lane_off : OOB;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
             h_ch = 0;
             if (++h_k < my_tiles) {
                 decode(h_k, hb, hy0, hx0, hn0);
-                if (pa.dbg & 2) hb = 0, hy0 = 0, hx0 = 0;
+                if (PIPE_DBG & 2) hb = 0, hy0 = 0, hx0 = 0;
                 halo_voff(hb, hy0, hx0);
             }
         }
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
             if (++w_k < my_tiles) {
                 int b_, y_, x_;
                 decode(w_k, b_, y_, x_, w_n0);
-                if (pa.dbg & 4) w_n0 = 0;
+                if (PIPE_DBG & 4) w_n0 = 0;
             }
         }
     };
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
     __builtin_amdgcn_sched_barrier(0);
 #define PIPE_LAST(AVC, BVC, AVN, BVN, BNEXT)                   \
     lds_wait(AVC, BVC);                                        \
-    if (pa.dbg & 8) wait_vmcnt<HP_MAX + 16>();                 \
+    if (PIPE_DBG & 8) wait_vmcnt<HP_MAX + 16>();                 \
     else wait_vmcnt<HP_MAX>();                                 \
     __builtin_amdgcn_s_barrier();                              \
     asm volatile("" ::: "memory");                             \
@@ -556,7 +565,11 @@ int launch_pipe(const ConvKParams& p, hipStream_t s) {
     pa.m_ntiles = magic_of(n_tiles);
     pa.m_tpi = magic_of(tiles_x * tiles_y);
     pa.m_tx = magic_of(tiles_x);
+#ifdef STYLEX_PIPE_ABLATION
     pa.dbg = getenv("STYLEX_PIPE_DBG") ? atoi(getenv("STYLEX_PIPE_DBG")) : 0;
+#else
+    pa.dbg = 0;
+#endif
     hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, EPI>), dim3((unsigned)g_num_cus), dim3(512), Cfg::SMEM, s, p, pa);
     return (int)hipGetLastError();
 }
@@ -586,12 +599,17 @@ int stylex_launch_pipe(const ConvKParams& p, hipStream_t s) {
     if ((long)p.B * p.Ho * p.Wo * p.Ck * 2 >= (1l << 31) || (long)p.N * 9 * p.Ck * 2 >= (1l << 31) ||
         (long)p.B * p.Ho * p.Wo * p.N * 2 >= (1l << 31))
         return STYLEX_NOT_APPLICABLE;
-    if (p.dry) return 0;
+    // every eligibility decision comes BEFORE the dry-run return, so that stylex_conv_mask_supported() (a dry launch)
+    // reports exactly what a real launch would do
     const bool n128 = p.N % 128 == 0 && !(env && env[0] == '6');
+    if (!n128) {
+        if (p.Ho < 32 && !(env && env[0] == '6')) return STYLEX_NOT_APPLICABLE;  // 32x32 px tiles
+        // measured (tools/bench_pipe.py, B = 128): on the 64-channel-output tiles the per-tile kernel keeps a 3-6 % edge
+        // when the epilogue reads a whole gate TENSOR or stores nothing but the plain 64 -> 64 data gradient
+        if (!(env && env[0] == '6') && ((p.flags & STYLEX_EPI_GATE) || (p.flip_taps && !p.flags && p.Ck == 64)))
+            return STYLEX_NOT_APPLICABLE;
+    }
+    if (p.dry) return 0;
     if (n128) return launch_pipe_epi<128>(p, s);
-    if (p.Ho < 32 && !(env && env[0] == '6')) return STYLEX_NOT_APPLICABLE;  // 32x32 px tiles
-    // measured (tools/bench_pipe.py, B = 128): on the 64-channel-output tiles the per-tile kernel keeps a 3-6 % edge when
-    // the epilogue reads a whole gate TENSOR or stores nothing but the plain 64 -> 64 data gradient
-    if (!(env && env[0] == '6') && ((p.flags & STYLEX_EPI_GATE) || (p.flip_taps && !p.flags && p.Ck == 64))) return STYLEX_NOT_APPLICABLE;
     return launch_pipe_epi<64>(p, s);
 }

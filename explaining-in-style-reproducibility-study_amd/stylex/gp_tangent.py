@@ -140,7 +140,10 @@ class _DRealPenalty(torch.autograd.Function):
         s = g_out.detach().float().reshape(bsz)  # dLoss / dD(x_b)
         cinv = 1 / math.sqrt(2)
         # v = dLoss/du = g_norm_b * u_b / ||u_b||   (d||u|| / du = u / ||u||)
-        v = u * (g_norm.detach().float().reshape(bsz) / norms).view(bsz, 1, 1, 1)
+        # a sample whose input gradient is exactly zero: autograd's norm backward uses the subgradient 0 there (the
+        # double backward this pass replaces), never 0 / 0
+        gn = g_norm.detach().float().reshape(bsz)
+        v = u * torch.where(norms > 0, gn / norms.clamp_min(1e-30), torch.zeros_like(gn)).view(bsz, 1, 1, 1)
         adt = hb.act_dtype(prec)
         s4 = s.view(bsz, 1, 1, 1).to(adt)
 

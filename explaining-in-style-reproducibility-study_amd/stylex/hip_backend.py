@@ -258,6 +258,16 @@ def empty_cl(shape, like, dtype=None):
 
 _PACK_CACHE = {}
 _PACK_CACHE_MAX = 512
+# STYLEX_CACHE_CHECK=1 (debug; costs a host sync per lookup): every cache entry remembers a checksum of the parameter
+# it was packed from, and a hit whose parameter no longer has that checksum raises — the failure mode of round 3's
+# stale-operand bug (an update path that bumps neither Parameter._version nor the `mark_updated` stamp).
+_CACHE_CHECK = os.environ.get("STYLEX_CACHE_CHECK", "0") == "1"
+
+
+def _checksum(w):
+    w = w.detach().double()
+    return (float(w.sum()), float(w.abs().sum()))
+
 
 
 def pack_cache_clear():
@@ -304,6 +314,11 @@ def _cache_hit(key, w, version=None):
         return None
     if hit[5] != (_gen(w) if version is None else version):
         return None
+    if _CACHE_CHECK and hit[6] is not None:  # debug: a hit whose source changed without a stamp is a stale operand
+        now = _checksum(w)
+        if now != hit[6]:
+            raise RuntimeError("stale operand pack served for %r: the parameter changed (checksum %r -> %r) without "
+                               "Parameter._version / hb.mark_updated() advancing" % (key, hit[6], now))
     if hit[4] != _stream_id():  # raw handles first: building a Stream object costs more than the whole lookup
         cur = torch.cuda.current_stream()
         cur.wait_event(hit[3])
@@ -322,7 +337,7 @@ def _cache_put(key, w_param, wf, wb, version=None, recipe=None):
     ev = torch.cuda.Event()
     ev.record()
     _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, _stream_id(),
-                        _gen(w_param) if version is None else version)
+                        _gen(w_param) if version is None else version, _checksum(w_param) if _CACHE_CHECK else None)
     if recipe is not None:
         if len(_PACK_RECIPES) >= 4 * _PACK_CACHE_MAX:
             _PACK_RECIPES.clear()

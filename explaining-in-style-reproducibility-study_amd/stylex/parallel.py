@@ -2,10 +2,14 @@
 over xGMI on ROCm; "gloo" in the CPU tests).
 
 The reference's multi-GPU path is vestigial (DDP wrappers around S/G/D only, the encoder is never
-wrapped — stylex/stylex_train.py:1188-1193, README.md:81).  Here gradient exchange is explicit:
-the gradients of a phase live in persistent flat 32 MB buckets (every .grad is a view) that are all-reduced in place (averaging done by the collective,
-ReduceOp.AVG on RCCL) from inside the last backward of the phase, bucket by bucket as they complete (class GradSync).  Non-final micro-steps never communicate
-(== ``no_sync``, :274-285).
+wrapped — stylex/stylex_train.py:1188-1193, README.md:81).  Here gradient exchange is explicit
+(class GradSync): the gradients of a phase live in persistent flat fp32 buckets (every .grad is a
+view after the bucket's pack) that are all-reduced in place, averaged by the collective itself
+(ReduceOp.AVG on RCCL).  DEFAULT: 128 MB buckets issued AFTER the last backward of the phase.
+Opt-in (``STYLEX_DDP_OVERLAP=1`` / ``GradSync(overlap=True)``): 32 MB buckets launched from
+autograd hooks inside that backward, strictly in index order on every rank — covered by the gloo
+tests and a 1-rank RCCL run, not yet by a >= 2-GPU RCCL run, hence not the default.  Non-final
+micro-steps never communicate (== ``no_sync``, :274-285).
 """
 import torch
 import torch.distributed as dist
@@ -21,9 +25,15 @@ def broadcast_parameters(module, src=0):
     """Make every rank start from rank-``src`` weights and buffers."""
     if not is_dist():
         return
+    import hip_backend as hb  # pure-Python stamp; the library itself is only loaded by the first kernel call
+
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src)
+        ts = list(module.parameters()) + list(module.buffers())
+        for t in ts:
+            dist.broadcast(t.detach(), src=src)  # detach() shares the version counter (t.data has its own)
+    # the broadcast writes through a detached alias: stamp the parameters so that no cached operand pack made from the
+    # pre-broadcast weights can be served (hip_backend._gen)
+    hb.mark_updated(ts)
 
 
 class GradSync:
@@ -129,9 +139,14 @@ class GradSync:
     def pack_all(self):
         """Move every gradient into its bucket and bind .grad to the views, without communicating.  Used at the end of
         a CAPTURED phase: the copies become part of the HIP graph (a replay recomputes the gradients into the
-        capture-time tensors and these copies refill the buckets), the collectives are issued eagerly afterwards."""
+        capture-time tensors and these copies refill the buckets), the collectives are issued eagerly afterwards.
+        A parameter WITHOUT a gradient in the captured phase keeps ``.grad = None`` (its bucket slice is zeroed inside
+        the graph for the collective), so the optimiser step captured next skips it exactly as the eager path and a
+        single GPU do — binding the zeroed view would make the captured Adam advance its step count and decay its
+        moments on every replay."""
+        captured = bool(self.flats) and self.flats[0].is_cuda and torch.cuda.is_current_stream_capturing()
         for bi in range(len(self.buckets)):
-            self._pack(bi)
+            self._pack(bi, bind_nograd=not captured)
 
     @torch.no_grad()
     def _launch(self, bi):
@@ -147,12 +162,14 @@ class GradSync:
         self._next += 1
 
     @torch.no_grad()
-    def _pack(self, bi):
+    def _pack(self, bi, bind_nograd=True):
         dst, src = [], []
         for p in self.buckets[bi]:
             v = self._views[id(p)]
             if p.grad is None:  # no gradient this phase: contributes zeros to the collective ...
                 v.zero_()
+                if not bind_nograd:
+                    continue
                 self._nograd.append(p)  # ... and goes back to None afterwards (all_reduce), as on one GPU
             elif p.grad is not v:
                 dst.append(v)

@@ -1565,6 +1565,7 @@ class Trainer:
             self.steps, self.pl_mean = extra["steps"], extra["pl_mean"]
         if self.is_ddp:
             parallel.broadcast_parameters(self.StylEx)
+        hb.mark_updated(self.StylEx.parameters())  # belt and braces: no operand pack of the pre-load weights survives
 
 
 def grid_to_pil(images, nrow=8, padding=2):

@@ -271,6 +271,54 @@ def gen_steps(st, only=None):
              scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst, aug_prob=aug)
 
 
+def gen_steps_envelope(st):
+    """The reference against ITSELF on the step fixtures: every STEP_CASES run repeated (a) with 2 intra-op threads
+    (CPU summation order) and (b) twice with the loader batches perturbed by a relative 1e-6 (two noise seeds) — the size
+    of an fp32 kernel's summation-order difference.  The per-call spread of the loss scalars around the golden
+    trajectory is what ``tests/test_hip_parity.py::assert_trajectory`` scales its tolerance by (instead of a free
+    growth factor): an implementation that is correct but rounds differently cannot be expected inside a band
+    narrower than the one the reference leaves around itself."""
+    size, cap, fmax, bs = 32, 4, 64, 2
+    out = {}
+    keep = torch.get_num_threads()
+    for tag, case in STEP_CASES.items():
+        (gae, alt, n, start, pl0), aug = case[:5], (case[5] if len(case) > 5 else 0.)
+        runs = []
+        for variant in ("gold", "t2", "eps1", "eps2"):
+            torch.set_num_threads(2 if variant == "t2" else keep)
+            cls = ref_shim.TinyClassifier(seed=99)
+            gd = torch.Generator().manual_seed(7)
+            batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+            if variant.startswith("eps"):
+                ge = torch.Generator().manual_seed(1000 + int(variant[3:]))
+                batches = [b * (1 + 1e-6 * torch.randn(b.shape, generator=ge)) for b in batches]
+            seed_all(42)
+            tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), cls, batches, image_size=size,
+                                                 network_capacity=cap, fmap_max=fmax, batch_size=bs,
+                                                 gradient_accumulate_every=gae, alternating_training=alt, lr=2e-4,
+                                                 ttur_mult=1.5, rec_scaling=1, kl_scaling=1, aug_prob=aug)
+            tr.init_StylEx()
+            tr.steps = start
+            tr.pl_mean = pl0
+            rows = []
+            for i in range(n):
+                tr.train()
+                rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                             tr.last_gp_loss if tr.last_gp_loss is not None else np.nan,
+                             tr.pl_mean if tr.pl_mean is not None else np.nan])
+            runs.append(np.array(rows, dtype=np.float64))
+        torch.set_num_threads(keep)
+        gold = runs[0]
+        committed = np.load(os.path.join(OUT, "steps_%s.npz" % tag))["scalars"]
+        assert np.array_equal(gold, committed, equal_nan=True), "the gold variant must reproduce the committed fixture"
+        dev = np.stack([np.abs(r - gold) / np.maximum(np.abs(gold), 1e-2) for r in runs[1:]])  # [variant, call, scalar]
+        spread = np.nanmax(dev, axis=(0, 2))
+        print("envelope", tag, "per-call max relative spread:", " ".join("%.2e" % v for v in spread))
+        out["spread_" + tag] = spread
+        out["dev_" + tag] = dev
+    save("steps_envelope", variants=np.array(["t2", "eps1", "eps2"]), eps=1e-6, **out)
+
+
 def gen_cfg4(st):
     """BASELINE config 4 in miniature: MobileNetV2 classifier through the reference's own wrapper
     (stylex/mobilenet_classifier.py:57-73: nearest interpolate to image_size, ImageNet normalise), R1 every 4th
@@ -633,7 +681,7 @@ def main():
     st = ref_shim.import_reference()
     todo = a.only.split(",")
     for name, fn in (("init", gen_init), ("ops", gen_ops), ("nets", gen_nets), ("losses", gen_losses),
-                     ("steps", gen_steps), ("cfg4", gen_cfg4), ("resnet", gen_resnet), ("dataset", gen_dataset), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
+                     ("steps", gen_steps), ("stepsenv", gen_steps_envelope), ("cfg4", gen_cfg4), ("resnet", gen_resnet), ("dataset", gen_dataset), ("newarch", gen_newarch), ("diffaug", gen_diffaug),
                      ("curve", gen_curve), ("calm", gen_curve_calm), ("evalsurface", gen_evalsurface), ("envelope", gen_envelope)):
         if name in todo:
             if name == "steps" and a.step_cases:
