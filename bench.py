@@ -11,7 +11,9 @@ encoder micro-step per phase; steps start at 0 so one call in four carries the g
 Inputs are device-resident before the timed region.  images/s counts B*GAE images per call.
 
 Prints ONE JSON line (rank 0) with the contract keys plus
-  roofline     — dominant conv kernel class, algorithmic FLOPs / hipEvent time, vs the dense MFMA peak
+  roofline     — dominant conv KERNEL (rocprofv3 name), algorithmic FLOPs / hipEvent time, vs the dense MFMA peak;
+                 its kernel class, the per-kernel table and the per-layer mixed roofline beside it
+  fp32_parity_mode — the same workload in the exact-fp32 mode (images/s, fraction of the fp32 MFMA peak)
   cpu_baseline — the CPU oracle ("port") timed on the host cores on a bounded sample (N=1 only)
 """
 import argparse
@@ -48,10 +50,11 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def load_traffic(class_name, precision):
-    """HBM bytes per launch of a conv kernel class from the newest profiles/r*_pmc_traffic.json that was collected on
-    EXACTLY these kernel sources (tools/collect_traffic.py stamps the file with csrc_sha16); None otherwise — a stale
-    counter file is never quoted."""
+def load_traffic(class_name, precision, kernel=None):
+    """HBM bytes per launch from the newest profiles/r*_pmc_traffic.json that was collected on EXACTLY these kernel
+    sources (tools/collect_traffic.py stamps the file with csrc_sha16); None otherwise — a stale counter file is never
+    quoted.  With `kernel` (a rocprofv3 kernel name) the per-kernel entry of the file's "kernels" table, else the
+    figure of the whole class."""
     import glob
 
     want = csrc_sha16()
@@ -60,7 +63,14 @@ def load_traffic(class_name, precision):
             tj = json.load(open(f))
         except Exception:
             continue
-        if tj.get("csrc_sha16") == want and class_name in tj and precision in tj.get("command", ""):
+        if tj.get("csrc_sha16") != want or precision not in tj.get("command", ""):
+            continue
+        if kernel is not None:
+            for name, row in tj.get("kernels", {}).items():
+                if kernel in name:
+                    return round(row["bytes_per_launch"]), os.path.basename(f)
+            continue
+        if class_name in tj:
             return round(tj[class_name]["bytes_per_launch"]), os.path.basename(f)
     return None, None
 
@@ -129,6 +139,60 @@ def build_trainer(args, device, rank, world):
     return tr
 
 
+def fp32_record(args, device, tr_old):
+    """The exact-fp32 parity mode (the mode every golden-vector test runs in) on the same workload: images/s over
+    `--fp32-steps` calls starting on a gradient-penalty step, and the conv class fraction of the fp32 MFMA peak."""
+    import copy
+
+    import hip_backend as hb
+    import ops
+
+    del tr_old
+    torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.graphs = 0
+    prev = ops._PRECISION
+    ops.set_precision("fp32")
+    try:
+        tr = build_trainer(a, device, 0, 1)
+        for _ in range(2):
+            tr.train()
+        tr.steps = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.fp32_steps):
+            tr.train()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prev_streams = os.environ.get("STYLEX_STREAMS")
+        os.environ["STYLEX_STREAMS"] = "0"
+        hb.timing_enable(1)
+        tr.steps = 1
+        tr.train()
+        torch.cuda.synchronize()
+        rep = hb.timing_report()
+        hb.timing_enable(0)
+        if prev_streams is None:
+            os.environ.pop("STYLEX_STREAMS", None)
+        else:
+            os.environ["STYLEX_STREAMS"] = prev_streams
+        del tr
+        torch.cuda.empty_cache()
+    finally:
+        ops.set_precision(prev)
+    ms = rep["fwd"]["ms"] + rep["bwd_data"]["ms"]
+    fl = rep["fwd"]["flops"] + rep["bwd_data"]["flops"]
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    value = args.batch * args.gae * args.fp32_steps / dt
+    return {"value": round(value, 2), "unit": "images/sec", "steps": args.fp32_steps,
+            "ms_per_step": round(dt / args.fp32_steps * 1e3, 2), "dtype": "fp32",
+            "class_achieved_tflops": round(ach, 2), "peak": PEAK_TFLOPS["fp32"],
+            "class_frac": round(ach / PEAK_TFLOPS["fp32"], 4),
+            "whole_step_frac": round(algorithmic_gflop_per_image(args.gae) * value / 1e3 / PEAK_TFLOPS["fp32"], 4),
+            "note": "same workload in the exact-fp32 MFMA mode of the parity tests; class = forward + data-gradient conv "
+                    "launches of one plain instrumented step"}
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/stylex_oracle.py, a port of the reference's CPU path) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -190,6 +254,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--roofline-steps", type=int, default=4)
+    ap.add_argument("--fp32-steps", type=int, default=4,
+                    help="timed train() calls of the fp32 parity mode for the fp32_parity_mode sub-record (0 = skip)")
     ap.add_argument("--graphs", type=int, default=int(os.environ.get("STYLEX_GRAPHS", "0")),
                     help="1 = replay the step as captured HIP graphs after the eager warm-up calls (0 = eager enqueue, "
                          "the default: at 256 px the step is GPU-bound and the capture of the multi-stream step is not "
@@ -221,7 +287,10 @@ def main():
     # The frozen classifier / LPIPS convolutions run on stock MIOpen.  On a fresh box its immediate mode picks slower
     # kernels than a search does (measured on one box: 641 images/s cold, 682 after one search had filled the user
     # find-db); let the untimed warm-up steps do that search (cudnn.benchmark), as any training job on a warm machine
-    # would have.  ~60 s of extra warm-up.  The Trainer itself keeps the reference's setting (benchmark off).
+    # would have.  ~60 s of extra warm-up.  The Trainer does the same by default in the bf16 speed mode (stylex_train.py,
+    # STYLEX_MIOPEN_BENCHMARK), so a `cli.py` training run and this benchmark use the same MIOpen kernels;
+    # --no-miopen-find measures the reference's immediate-mode setting (cli.py:38) instead.
+    os.environ["STYLEX_MIOPEN_BENCHMARK"] = "0" if args.no_miopen_find else "1"
     torch.backends.cudnn.benchmark = not args.no_miopen_find
     tr = build_trainer(args, device, rank, world)
 
@@ -271,6 +340,7 @@ def main():
         torch.cuda.synchronize()
         rep = hb.timing_report()
         layers = hb.timing_layers()
+        kernels = hb.timing_kernels()
         hb.timing_enable(0)
         if prev_streams is None:
             os.environ.pop("STYLEX_STREAMS", None)
@@ -288,20 +358,55 @@ def main():
         # profiles/); null when no measurement exists for the class / precision
         traffic, traffic_file = load_traffic(name, args.precision)
         cls_layers = [L for L in layers if (L["cls"] == "bwd_weight") == (name == "bwd_weight")]
-        roof = {"bound": "mfma", "kernel": "conv_%s (implicit-GEMM MFMA)" % name, "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                "launches": r["launches"], "avg_launch_ms": round(r["ms"] / max(1, r["launches"]), 4),
-                "algorithmic_bytes": round(r["bytes"] / max(1, r["launches"])),
-                "note": "per launch of the class over %d instrumented steps, stream concurrency off; traffic: %s"
-                        % (args.roofline_steps, ("PMC passes in profiles/%s (same kernel sources, csrc_sha16 %s)"
-                                                 % (traffic_file, csrc_sha16())) if traffic is not None else
-                           "null — no PMC file under profiles/ was collected on these kernel sources (csrc_sha16 %s)"
+        # the dominant KERNEL (most hipEvent time over the instrumented steps; forward and data-gradient launches of one
+        # kernel are one row), named as rocprofv3 --kernel-trace --stats prints it so that its average launch duration
+        # can be checked against profiles/r*_kernel_stats_bench_*.csv; the class it belongs to stays beside it
+        by_kernel = {}
+        for K in kernels:
+            if not K["kernel"]:
+                continue
+            a = by_kernel.setdefault(K["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            for f in ("ms", "flops", "bytes", "launches"):
+                a[f] += K[f]
+        ktable = sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])
+        kname, kr = ktable[0] if ktable else ("conv_%s" % name, r)
+        k_ach = kr["flops"] / (kr["ms"] * 1e-3) / 1e12 if kr["ms"] > 0 else 0.0
+        k_traffic, k_file = load_traffic(name, args.precision, kernel=kname)
+        what = "PMC passes in profiles/%s (same kernel sources, csrc_sha16 %s)"
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(k_ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(k_ach / peak, 4), "traffic": k_traffic, "launches": kr["launches"],
+                "avg_launch_ms": round(kr["ms"] / max(1, kr["launches"]), 4),
+                "algorithmic_bytes": round(kr["bytes"] / max(1, kr["launches"])),
+                "ms_per_step": round(kr["ms"] / args.roofline_steps, 3),
+                "note": "dominant kernel by hipEvent time on the launch stream over %d instrumented steps (stream "
+                        "concurrency off), name as rocprofv3 prints it; achieved = algorithmic FLOPs of its launches / "
+                        "their summed duration; traffic: %s.  `class` = every launch of the kernel class it belongs to "
+                        "(the figure rounds 1-3 reported as roofline.frac), `whole_step_frac` = algorithmic conv FLOPs "
+                        "of a step / step time / peak"
+                        % (args.roofline_steps, (what % (k_file, csrc_sha16())) if k_traffic is not None else
+                           "null — no per-kernel PMC entry under profiles/ for these kernel sources (csrc_sha16 %s)"
                            % csrc_sha16()),
+                "class": {"name": "conv_%s (implicit-GEMM MFMA)" % name, "achieved": round(ach, 2),
+                          "frac": round(ach / peak, 4), "traffic": traffic, "launches": r["launches"],
+                          "avg_launch_ms": round(r["ms"] / max(1, r["launches"]), 4),
+                          "algorithmic_bytes": round(r["bytes"] / max(1, r["launches"])),
+                          "traffic_source": (what % (traffic_file, csrc_sha16())) if traffic is not None else None},
+                "kernels": [{"kernel": kn, "ms_per_step": round(v["ms"] / args.roofline_steps, 3),
+                             "launches_per_step": round(v["launches"] / args.roofline_steps, 1),
+                             "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4),
+                             "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                             "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)} for kn, v in ktable[:12]],
                 "per_layer": layer_roofline(cls_layers, args.precision),
                 "classes": {k: {"tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "ms": round(v["ms"], 2),
                                 "launches": v["launches"]} for k, v in rep.items()}}
     if world > 1:
         dist.barrier()
+
+    # ---- the fp32 parity mode on the same workload (N = 1 only): images/s and the class fraction of the fp32 MFMA peak
+    fp32_rec = None
+    if rank == 0 and world == 1 and args.fp32_steps > 0 and args.precision != "fp32":
+        fp32_rec = fp32_record(args, device, tr)
+        tr = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -321,12 +426,15 @@ def main():
                        "image_size": args.image_size, "batch_per_gpu": args.batch,
                        "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
                        "parallelism": "dp%d" % world,
-                       "frozen_nets": "stock MIOpen fp32, algorithms searched during the warm-up steps"
-                                      if not args.no_miopen_find else "stock MIOpen fp32, immediate mode"},
+                       "frozen_nets": "stock MIOpen fp32, algorithms searched during the warm-up steps (the Trainer's "
+                                      "default in the bf16 mode, same as a cli.py run)"
+                                      if not args.no_miopen_find else "stock MIOpen fp32, immediate mode (reference cli.py:38)"},
             "algorithmic_conv_gflop_per_image": round(gf, 1),
             "step_conv_tflops": round(gf * value / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "fp32_parity_mode": fp32_rec,
         }
+        if roof is not None:
+            roof["whole_step_frac"] = round(gf * value / 1e3 / PEAK_TFLOPS[args.precision], 4)
     else:
         line = None
     # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (seen after the line when

@@ -298,6 +298,7 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
     g.ksplit = ks;
     g.stages_per_split = per;
     const long tiles = (long)g.m_tiles * ((p.N + GBN - 1) / GBN);
+    stylex_note_kernel("conv_gather_kernel");
     hipLaunchKernelGGL(conv_gather_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), SMEM_BYTES, s, g);
     p.ksplit = direct ? 0 : ks;  // 0: output complete, the caller skips the split-K epilogue
     p.kt_per_split = per;

@@ -440,6 +440,8 @@ int launch_halo(const ConvKParams& p, hipStream_t s) {
     }
     long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
     long blocks = tiles * ((p.N + BN - 1) / BN);
+    stylex_note_kernel("conv3x3_halo_bf16_kernel<%d, %d, %s, %s, %s>", TW, TN, ABF ? "true" : "false", S2D ? "true" : "false",
+                       EPIX ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), sm, s, p);
     return (int)hipGetLastError();
 }

@@ -388,6 +388,7 @@ static int launch_dma(const ConvKParams& p, hipStream_t s) {
     }
     long tiles = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
     long blocks = tiles * ((p.N + DmaCfg<TNJ>::BN - 1) / DmaCfg<TNJ>::BN);
+    stylex_note_kernel("conv3x3_halo_dma_kernel<%d, %s>", TNJ, S2D ? "true" : "false");
     hipLaunchKernelGGL((conv3x3_halo_dma_kernel<TNJ, S2D>), dim3((unsigned)blocks), dim3(256), DmaCfg<TNJ>::SMEM_BYTES, s, p);
     return (int)hipGetLastError();
 }

@@ -960,6 +960,8 @@ int launch_igemm(const ConvKParams& p, hipStream_t s) {
         attr_done = true;
     }
     long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    stylex_note_kernel("conv_igemm_kernel<%d, %d, %d, %d, %s, %s, %d, %s>", WM, WN, TM, TN, VEC4 ? "true" : "false",
+                       BF16 ? "true" : "false", BKT, ABF ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), dim3(256), sm, s, p);
     return (int)hipGetLastError();
 }
@@ -994,6 +996,7 @@ int launch_wgrad(const ConvKParams& p, int blocks, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
+    stylex_note_kernel("conv_wgrad_kernel<%d, %d, %s, %s>", TN_, TC_, VEC4 ? "true" : "false", BF16 ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), sm, s, p);
     return (int)hipGetLastError();
 }

@@ -570,6 +570,7 @@ int launch_pipe(const ConvKParams& p, hipStream_t s) {
 #else
     pa.dbg = 0;
 #endif
+    stylex_note_kernel("conv3x3_pipe_kernel<%d, %d>", NT, EPI);
     hipLaunchKernelGGL((conv3x3_pipe_kernel<NT, EPI>), dim3((unsigned)g_num_cus), dim3(512), Cfg::SMEM, s, p, pa);
     return (int)hipGetLastError();
 }

@@ -151,6 +151,7 @@ int stylex_launch_rgb(const ConvKParams& p, hipStream_t s) {
         attr = true;
     }
     const long blocks = (long)p.B * ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    stylex_note_kernel("conv3x3_rgb_kernel");
     hipLaunchKernelGGL(conv3x3_rgb_kernel, dim3((unsigned)blocks), dim3(256), SMEM_BYTES, s, p);
     return (int)hipGetLastError();
 }

@@ -485,6 +485,7 @@ static int launch_wgrad_halo(const ConvKParams& p, int blocks, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
+    stylex_note_kernel("conv3x3_wgrad_halo_kernel<%d, %s, %s>", TW, ABF ? "true" : "false", S2D ? "true" : "false");
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), Geom<TW>::SMEM_BYTES, s, p);
     return (int)hipGetLastError();
 }
@@ -511,6 +512,7 @@ int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* 
             if (e != hipSuccess) return (int)e;
             attr_done[v] = true;
         }
+        stylex_note_kernel("conv3x3_wgrad_halo_dma_kernel<%s, %d>", v == 1 ? "true" : "false", v == 2 ? 8 : 4);
         hipLaunchKernelGGL(k, dim3(blocks), dim3(v == 2 ? 512 : 256), GeomDma::SMEM_BYTES, s, p);
         return (int)hipGetLastError();
     }

@@ -231,6 +231,7 @@ int launch_tr(const ConvKParams& p, int blocks, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
+    stylex_note_kernel("conv_wgrad_tr_kernel<%d, %d, %s>", TN_, TC_, C8 ? "true" : "false");
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), smem_bytes, s, p);
     return (int)hipGetLastError();
 }

@@ -2,11 +2,14 @@
 // Argument checking, GEMM-view parameter construction, launch, optional hipEvent timing.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <array>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "stylex_internal.h"
@@ -20,12 +23,15 @@ struct TimedLaunch {
     double flops;
     double bytes;  // algorithmic HBM bytes of the launch: operands in + result out, each once
     LayerKey key;
+    char kernel[112];  // rocprof name of the kernel the call launched (stylex_note_kernel), "" when none was noted
 };
 struct LayerAcc {
     int64_t launches = 0;
     double ms = 0, flops = 0, bytes = 0;
 };
 std::map<LayerKey, LayerAcc> g_layers;
+std::map<std::pair<int, std::string>, LayerAcc> g_kernels;  // (class, kernel name) -> totals
+thread_local char t_kernel[112] = "";
 std::mutex g_mu;
 bool g_timing = false;
 std::vector<TimedLaunch> g_pending;
@@ -46,6 +52,7 @@ struct ScopedTimer {
         t.bytes = bytes;
         t.key = LayerKey{cls, 0, 0, 0, 0, 0, 0, 0, 0};
         if (sh) t.key = LayerKey{cls, sh[0], sh[1], sh[2], sh[3], sh[4], sh[5], sh[7], s2d};
+        t_kernel[0] = 0;
         (void)hipEventCreate(&t.start);
         (void)hipEventCreate(&t.stop);
         (void)hipEventRecord(t.start, s);
@@ -53,6 +60,7 @@ struct ScopedTimer {
     ~ScopedTimer() {
         if (!on) return;
         (void)hipEventRecord(t.stop, s);
+        memcpy(t.kernel, t_kernel, sizeof(t.kernel));
         std::lock_guard<std::mutex> lk(g_mu);
         g_pending.push_back(t);
     }
@@ -73,6 +81,11 @@ void drain_pending() {
         la.ms += ms;
         la.flops += t.flops;
         la.bytes += t.bytes;
+        LayerAcc& ka = g_kernels[std::make_pair(t.cls, std::string(t.kernel))];
+        ka.launches += 1;
+        ka.ms += ms;
+        ka.flops += t.flops;
+        ka.bytes += t.bytes;
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
@@ -112,6 +125,14 @@ void fill_common(ConvKParams& p, const int64_t* sh) {
 
 }  // namespace
 
+void stylex_note_kernel(const char* fmt, ...) {
+    if (!g_timing) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_kernel, sizeof(t_kernel), fmt, ap);
+    va_end(ap);
+}
+
 extern "C" {
 
 const char* stylex_version(void) { return "stylex-hip 0.1 (gfx950)"; }
@@ -133,8 +154,30 @@ int stylex_timing_enable(int on) {
             g_bytes[i] = 0;
         }
         g_layers.clear();
+        g_kernels.clear();
     }
     return 0;
+}
+
+// Per-KERNEL view of the same measurements: one row per (class, kernel name as rocprofv3 prints it).  names = cap
+// slots of 112 bytes (NUL-terminated), meta[r] = {cls, launches}, vals[r] = {total ms, total algorithmic FLOPs, total
+// algorithmic bytes}.  Returns the number of rows written (<= cap).
+int stylex_timing_kernels(char* names, int64_t* meta, double* vals, int64_t cap) {
+    if (!names || !meta || !vals) return STYLEX_EINVAL;
+    drain_pending();
+    std::lock_guard<std::mutex> lk(g_mu);
+    int64_t r = 0;
+    for (const auto& kv : g_kernels) {
+        if (r >= cap) break;
+        snprintf(names + r * 112, 112, "%s", kv.first.second.c_str());
+        meta[r * 2 + 0] = kv.first.first;
+        meta[r * 2 + 1] = kv.second.launches;
+        vals[r * 3 + 0] = kv.second.ms;
+        vals[r * 3 + 1] = kv.second.flops;
+        vals[r * 3 + 2] = kv.second.bytes;
+        ++r;
+    }
+    return (int)r;
 }
 
 // Per-layer view of the same measurements: one row per (class, conv shape).  meta[r] = {cls, B, Hi, Wi, C, N, KH,

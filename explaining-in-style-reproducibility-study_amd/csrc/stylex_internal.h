@@ -52,6 +52,11 @@ int stylex_launch_pack(const float* w, void* wf, void* wb, int N, int C, int T, 
 
 #define STYLEX_NOT_APPLICABLE (-100)
 
+// Timing hook (stylex_timing_kernels): a launcher names the kernel it is about to launch, as rocprofv3 prints it
+// (printf-style; thread-local, no allocation).  A timed C-ABI call attributes its hipEvent interval to the LAST name
+// noted inside it (the main kernel of a multi-launch call notes itself last).
+void stylex_note_kernel(const char* fmt, ...);
+
 #ifdef __HIPCC__
 // bit k = (bf16 element k of the 16-byte vector > 0), with the float comparison the tensor-gate path uses
 __device__ __forceinline__ unsigned stylex_sign_bits8(uint4 v) {

@@ -107,6 +107,7 @@ SIGNATURES = {
     "stylex_torgb_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_layers": (ctypes.c_int, [_i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
+    "stylex_timing_kernels": (ctypes.c_int, [ctypes.c_char_p, _i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
@@ -1066,6 +1067,19 @@ def timing_report():
         lib.stylex_timing_report(cls, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
         out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
     return out
+
+
+def timing_kernels(cap=256):
+    """Per-(class, kernel) rows of the instrumented launches: dicts with cls, kernel (rocprofv3 spelling), launches,
+    ms, flops, bytes (totals)."""
+    lib = load_library()
+    names = ctypes.create_string_buffer(cap * 112)
+    meta = (ctypes.c_int64 * (cap * 2))()
+    vals = (ctypes.c_double * (cap * 3))()
+    n = lib.stylex_timing_kernels(names, meta, vals, cap)
+    cls = ("fwd", "bwd_data", "bwd_weight")
+    return [dict(cls=cls[meta[r * 2]], kernel=names.raw[r * 112:(r + 1) * 112].split(b"\0", 1)[0].decode(),
+                 launches=meta[r * 2 + 1], ms=vals[r * 3], flops=vals[r * 3 + 1], bytes=vals[r * 3 + 2]) for r in range(n)]
 
 
 def timing_layers(cap=512):

@@ -333,6 +333,11 @@ int stylex_timing_report(int kernel_class, int64_t* launches, double* total_ms, 
  * stride, s2d_c, launches}, vals[r][3] = {total ms, total algorithmic FLOPs, total algorithmic bytes}.  Returns the
  * number of rows written (<= cap).  bench.py builds the per-layer mixed (HBM / MFMA) roofline from it. */
 int stylex_timing_layers(int64_t* meta, double* vals, int64_t cap);
+/* Per-kernel view: one row per (class, name of the kernel the call launched, spelled as rocprofv3 prints it — e.g.
+ * "conv3x3_pipe_kernel<128, 0>").  names = cap slots of 112 bytes, meta[r][2] = {class, launches}, vals[r][3] as above.
+ * bench.py names the dominant kernel of its roofline record from it, so that the record can be checked against the
+ * rocprofv3 --kernel-trace --stats summary under profiles/. */
+int stylex_timing_kernels(char* names, int64_t* meta, double* vals, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -43,10 +43,10 @@ def run_pass(counter, bench_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
     ap.add_argument("--precision", default="bf16")
     a = ap.parse_args()
-    bench_args = ["--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--roofline-steps", "0", "--precision", a.precision]
+    bench_args = ["--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--roofline-steps", "0", "--fp32-steps", "0", "--precision", a.precision]
     fetch, cnt = run_pass("FETCH_SIZE", bench_args)
     write, _ = run_pass("WRITE_SIZE", bench_args)
     per_kernel = {}
@@ -54,7 +54,8 @@ def main():
         if "anonymous namespace" not in k:
             continue
         per_kernel[k[:110]] = {"dispatches": cnt[k], "fetch_KiB_raw": fetch.get(k, 0.0), "write_KiB": write.get(k, 0.0),
-                               "bytes_corrected": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0}
+                               "bytes_corrected": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0,
+                               "bytes_per_launch": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 / max(1, cnt[k])}
     main_disp = sum(v["dispatches"] for k, v in per_kernel.items() if any(w in k for w in WGRAD))
     fam_bytes = sum(v["bytes_corrected"] for k, v in per_kernel.items() if any(w in k for w in WGRAD + WGRAD_AUX))
     fwd_disp = sum(v["dispatches"] for k, v in per_kernel.items() if any(w in k for w in FWD))
