@@ -151,7 +151,7 @@ def fp32_record(args, device, tr_old):
     torch.cuda.empty_cache()
     a = copy.copy(args)
     a.graphs = 0
-    prev = ops._PRECISION
+    prev = ops.get_precision()
     ops.set_precision("fp32")
     try:
         tr = build_trainer(a, device, 0, 1)

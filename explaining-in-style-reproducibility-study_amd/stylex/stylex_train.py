@@ -684,7 +684,7 @@ class Trainer:
         # step throughput slower than the searched ones, and bench.py's headline number is measured with the search —
         # a real `cli.py` run now gets the same kernels.  STYLEX_MIOPEN_BENCHMARK=0 / 1 overrides either way.
         mb = os.environ.get("STYLEX_MIOPEN_BENCHMARK")
-        if mb == "1" or (mb is None and ops._PRECISION != "fp32" and torch.cuda.is_available()):
+        if mb == "1" or (mb is None and ops.get_precision() != "fp32" and torch.cuda.is_available()):
             torch.backends.cudnn.benchmark = True
         self.save_training_state = save_training_state
         self.device = _dev(device if device is not None else rank)
@@ -1572,6 +1572,8 @@ class Trainer:
             self.steps, self.pl_mean = extra["steps"], extra["pl_mean"]
         if self.is_ddp:
             parallel.broadcast_parameters(self.StylEx)
+        import hip_backend as hb
+
         hb.mark_updated(self.StylEx.parameters())  # belt and braces: no operand pack of the pre-load weights survives
 
 

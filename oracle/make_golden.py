@@ -271,49 +271,106 @@ def gen_steps(st, only=None):
              scalars=np.array(rows, dtype=np.float64), param_names=names, param_stats=pst, aug_prob=aug)
 
 
+def _env_batches(variant, bs=2, size=32):
+    gd = torch.Generator().manual_seed(7)
+    batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
+    if variant.startswith("eps"):
+        ge = torch.Generator().manual_seed(1000 + int(variant[3:]))
+        batches = [b * (1 + 1e-6 * torch.randn(b.shape, generator=ge)) for b in batches]
+    return batches
+
+
+def _env_rows(tr, n):
+    rows = []
+    for _ in range(n):
+        tr.train()
+        rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
+                     tr.last_gp_loss if tr.last_gp_loss is not None else np.nan,
+                     tr.pl_mean if tr.pl_mean is not None else np.nan])
+    return np.array(rows, dtype=np.float64)
+
+
 def gen_steps_envelope(st):
-    """The reference against ITSELF on the step fixtures: every STEP_CASES run repeated (a) with 2 intra-op threads
-    (CPU summation order) and (b) twice with the loader batches perturbed by a relative 1e-6 (two noise seeds) — the size
-    of an fp32 kernel's summation-order difference.  The per-call spread of the loss scalars around the golden
-    trajectory is what ``tests/test_hip_parity.py::assert_trajectory`` scales its tolerance by (instead of a free
-    growth factor): an implementation that is correct but rounds differently cannot be expected inside a band
-    narrower than the one the reference leaves around itself."""
+    """The reference against ITSELF on the step fixtures: every STEP_CASES run (and the config-4 and second-architecture
+    runs) repeated (a) with 2 intra-op threads (CPU summation order) and (b) twice with the loader batches perturbed by
+    a relative 1e-6 (two noise seeds) — the size of an fp32 kernel's summation-order difference.  The per-call spread
+    of the loss scalars around the golden trajectory is what ``tests/test_hip_parity.py::assert_trajectory`` scales its
+    tolerance by (instead of a free growth factor): an implementation that is correct but rounds differently cannot
+    be expected inside a band narrower than the one the reference leaves around itself."""
     size, cap, fmax, bs = 32, 4, 64, 2
-    out = {}
     keep = torch.get_num_threads()
-    for tag, case in STEP_CASES.items():
+
+    def build_step(tag):
+        case = STEP_CASES[tag]
         (gae, alt, n, start, pl0), aug = case[:5], (case[5] if len(case) > 5 else 0.)
-        runs = []
-        for variant in ("gold", "t2", "eps1", "eps2"):
-            torch.set_num_threads(2 if variant == "t2" else keep)
-            cls = ref_shim.TinyClassifier(seed=99)
-            gd = torch.Generator().manual_seed(7)
-            batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
-            if variant.startswith("eps"):
-                ge = torch.Generator().manual_seed(1000 + int(variant[3:]))
-                batches = [b * (1 + 1e-6 * torch.randn(b.shape, generator=ge)) for b in batches]
+
+        def run(variant):
             seed_all(42)
-            tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), cls, batches, image_size=size,
-                                                 network_capacity=cap, fmap_max=fmax, batch_size=bs,
-                                                 gradient_accumulate_every=gae, alternating_training=alt, lr=2e-4,
-                                                 ttur_mult=1.5, rec_scaling=1, kl_scaling=1, aug_prob=aug)
+            tr = ref_shim.make_reference_trainer(st, tempfile.mkdtemp(), ref_shim.TinyClassifier(seed=99),
+                                                 _env_batches(variant), image_size=size, network_capacity=cap,
+                                                 fmap_max=fmax, batch_size=bs, gradient_accumulate_every=gae,
+                                                 alternating_training=alt, lr=2e-4, ttur_mult=1.5, rec_scaling=1,
+                                                 kl_scaling=1, aug_prob=aug)
             tr.init_StylEx()
             tr.steps = start
             tr.pl_mean = pl0
-            rows = []
-            for i in range(n):
-                tr.train()
-                rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss,
-                             tr.last_gp_loss if tr.last_gp_loss is not None else np.nan,
-                             tr.pl_mean if tr.pl_mean is not None else np.nan])
-            runs.append(np.array(rows, dtype=np.float64))
+            return _env_rows(tr, n)
+        return run
+
+    def run_cfg4(variant):
+        mod = ref_shim.import_reference_mobilenet()
+        tmp = tempfile.mkdtemp()
+        os.makedirs(os.path.join(tmp, "trained_classifiers"))
+        torch.save(ref_shim.seeded_mobilenet_state(77), os.path.join(tmp, "trained_classifiers", "mnv2_seed77.pth"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            st.MobileNet = mod.MobileNet
+            seed_all(42)
+            tr = st.Trainer(name="gold", base_dir=tmp, classifier_name="mobilenet", classifier_path="mnv2_seed77.pth",
+                            tensorboard_dir=None, evaluate_every=10 ** 9, save_every=10 ** 9, image_size=size,
+                            network_capacity=cap, fmap_max=fmax, batch_size=bs, gradient_accumulate_every=2,
+                            alternating_training=True, lr=2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1)
+            seed_all(42)
+            tr.loader = st.cycle(_env_batches(variant))
+            tr.dataset = list(range(1000))
+            tr.save = tr.evaluate = lambda *a, **k: None
+            tr.init_StylEx()
+            tr.steps = 5024
+            tr.pl_mean = 0.05
+            return _env_rows(tr, 2)
+        finally:
+            os.chdir(cwd)
+
+    def run_newarch(variant):
+        stn = ref_shim.import_reference_new()
+        seed_all(42)
+        tr = ref_shim.make_reference_trainer(stn, tempfile.mkdtemp(), ref_shim.TinyClassifier(seed=99),
+                                             _env_batches(variant), image_size=size, network_capacity=cap,
+                                             fmap_max=fmax, batch_size=bs, gradient_accumulate_every=2,
+                                             alternating_training=True, lr=2e-4, ttur_mult=1.5, rec_scaling=1,
+                                             kl_scaling=1)
+        tr.init_StylEx()
+        rows = _env_rows(tr, 3)
+        rows[:, 5] = np.nan  # the fixture records no pl_mean for this module
+        return rows
+
+    runners = {tag: build_step(tag) for tag in STEP_CASES}
+    runners["cfg4"] = run_cfg4
+    runners["newarch"] = run_newarch
+    out = {}
+    for tag, run in runners.items():
+        runs = []
+        for variant in ("gold", "t2", "eps1", "eps2"):
+            torch.set_num_threads(2 if variant == "t2" else keep)
+            runs.append(run(variant))
         torch.set_num_threads(keep)
         gold = runs[0]
         committed = np.load(os.path.join(OUT, "steps_%s.npz" % tag))["scalars"]
-        assert np.array_equal(gold, committed, equal_nan=True), "the gold variant must reproduce the committed fixture"
+        assert np.array_equal(gold, committed, equal_nan=True), ("the gold variant must reproduce the committed fixture", tag)
         dev = np.stack([np.abs(r - gold) / np.maximum(np.abs(gold), 1e-2) for r in runs[1:]])  # [variant, call, scalar]
         spread = np.nanmax(dev, axis=(0, 2))
-        print("envelope", tag, "per-call max relative spread:", " ".join("%.2e" % v for v in spread))
+        print("envelope", tag, "per-call max relative spread:", " ".join("%.2e" % v for v in spread), flush=True)
         out["spread_" + tag] = spread
         out["dev_" + tag] = dev
     save("steps_envelope", variants=np.array(["t2", "eps1", "eps2"]), eps=1e-6, **out)
@@ -545,11 +602,13 @@ def gen_curve(st, n=100):
          threads=torch.get_num_threads())
 
 
-def gen_curve_calm(st, n=100, lr=1e-6, start=4960):
+def gen_curve_calm(st, n=100, lr=1e-8, start=4960):
     """X1 — a 100-call scalar trajectory of the reference in a NON-chaotic regime: config-1 shape (64 px, capacity 16,
-    B=4) at GAE=2 with lr = 1e-6, so that Adam's sign-like steps (<= lr per element and call) stay far below the
+    B=4) at GAE=2 with lr = 1e-8, so that Adam's sign-like steps (<= lr per element and call) stay far below the
     amplification threshold of the untrained GAN and the trajectory is a function of the schedule and the random
-    draws, not of rounding.  The window starts at step 4960 so that the 100 calls contain everything ``train()``
+    draws, not of rounding.  (Measured here first with lr = 1e-6: the reference at 8 vs 4 threads is 1e-3 apart at
+    call 3 and 1e-1 apart from call 35 on — a +-1e-6 step on the noise-dominated share of 1e7 parameters already
+    moves these losses by 1e-3.)  The window starts at step 4960 so that the 100 calls contain everything ``train()``
     schedules by step count (stylex_train.py:1272-1274, 1471-1479): the gradient penalty on every 4th call, the
     path-length penalty + ``pl_mean`` EMA at 5024 and 5056 (> 5000 and % 32 == 0, not 4992),
     ``reset_parameter_averaging`` at 5002, the noise / encoder alternation and the rec / KL cadence, and the RNG draw

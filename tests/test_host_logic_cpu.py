@@ -93,8 +93,9 @@ def make_trainer(g, tmp_path, device=None, trainer_cls=None):
     np.random.seed(seed)
     random.seed(seed)
     aug = float(g["aug_prob"]) if "aug_prob" in g.files else 0.
+    lr = float(g["lr"]) if "lr" in g.files else 2e-4
     tr = (trainer_cls or st.Trainer)(name="t", base_dir=str(tmp_path), image_size=size, network_capacity=cap, fmap_max=fmax,
-                                     batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4,
+                                     batch_size=bs, gradient_accumulate_every=gae, alternating_training=bool(alt), lr=lr,
                                      ttur_mult=1.5, rec_scaling=1, kl_scaling=1, classifier=cls, lpips_fn=lp,
                                      classifier_name="resnet", evaluate_every=10 ** 9, save_every=10 ** 9, device=device,
                                      aug_prob=aug)
@@ -104,7 +105,7 @@ def make_trainer(g, tmp_path, device=None, trainer_cls=None):
     tr.evaluate = lambda *a, **k: None
     tr.init_StylEx()
     tr.steps = start
-    pl0 = float(g["pl_mean0"])
+    pl0 = float(g["pl_mean0"]) if "pl_mean0" in g.files else float("nan")
     tr.pl_mean = None if np.isnan(pl0) else pl0
     return tr, n
 

@@ -191,8 +191,9 @@ def test_loss_parity():
     close(g["rec/value"], so.reconstruction_loss(lp, i1, i2, w2, w1), 1e-6)
 
 
-def run_oracle_steps(g, cls=None):
+def run_oracle_steps(g, cls=None, calls=None):
     size, cap, fmax, bs, gae, alt, n, start = (int(v) for v in g["config"])
+    n = calls or n
     cls = cls or TinyClassifier(seed=int(g["cls_seed"]))
     gd = torch.Generator().manual_seed(int(g["data_seed"]))
     batches = [torch.rand(bs, 3, size, size, generator=gd) for _ in range(8)]
@@ -208,10 +209,10 @@ def run_oracle_steps(g, cls=None):
     np.random.seed(seed)
     random.seed(seed)
     tr = so.OracleTrainer(cls, lp, cyc(), image_size=size, network_capacity=cap, fmap_max=fmax, batch_size=bs,
-                          gradient_accumulate_every=gae, alternating_training=bool(alt), lr=2e-4, ttur_mult=1.5,
-                          rec_scaling=1, kl_scaling=1)
+                          gradient_accumulate_every=gae, alternating_training=bool(alt),
+                          lr=float(g["lr"]) if "lr" in g.files else 2e-4, ttur_mult=1.5, rec_scaling=1, kl_scaling=1)
     tr.steps = start
-    pl0 = float(g["pl_mean0"])
+    pl0 = float(g["pl_mean0"]) if "pl_mean0" in g.files else float("nan")
     tr.pl_mean = None if np.isnan(pl0) else pl0
     rows = []
     for _ in range(n):
@@ -291,3 +292,36 @@ def test_resnet_wrapper_oracle_vs_reference_golden():
         close(logits, out, 1e-5)
         got, = torch.autograd.grad((out * coef).sum(), x)
         close(gx, got, 1e-5)
+
+
+def assert_calm_rows(rows, g, first=0):
+    """X1: every call of the 100-call reference trajectory to 1e-3 (north_star's loss-curve bound; relative, with an
+    absolute floor of 1e-3 for the scalars that pass through zero)."""
+    gold = g["scalars"][first:first + len(rows)]
+    for k in range(len(rows)):
+        np.testing.assert_allclose(rows[k], gold[k], rtol=1e-3, atol=1e-3, equal_nan=True,
+                                   err_msg="train() call %d (step %d)" % (first + k, int(g["config"][7]) + first + k))
+
+
+def test_calm_curve_reference_holds_itself_and_oracle_first_calls():
+    """X1 fixture (tests/golden/curve_64_calm.npz: 100 train() calls of the reference from step 4960 at lr 1e-8).
+    (a) The regime is non-chaotic: the reference at 4 threads stays within 1e-3 of the reference at 8 threads on every
+    one of the 100 calls — so the bound CAN be asked of another implementation.  (b) The window really contains the
+    scheduled events: the gradient penalty on the calls with step % 4 == 0 only, the first pl_mean at 5024 and its
+    EMA update at 5056.  (c) The oracle reproduces the first calls (the whole curve takes minutes on the CPU:
+    tools/curve_check.py --calm runs it; the GPU suite runs all 100 calls on the HIP path)."""
+    g = load_golden("curve_64_calm")
+    a, b = g["scalars"], g["scalars_t4"]
+    assert a.shape == (100, 6)
+    for k in range(100):
+        np.testing.assert_allclose(b[k], a[k], rtol=1e-3, atol=1e-3, equal_nan=True, err_msg="reference vs itself, call %d" % k)
+    start = int(g["config"][7])
+    steps = start + np.arange(100)
+    gp = a[:, 4]  # last_gp_loss: written on the calls with step % 4 == 0 (the window starts on one), kept in between
+    assert start % 4 == 0 and all(gp[k] == gp[k - k % 4] for k in range(100)), "penalty value must persist between penalty calls"
+    assert len(set(gp[::4])) == 25, "every 4th call computes a new penalty"
+    pl = a[:, 5]
+    assert np.all(np.isnan(pl[steps < 5024])) and not np.isnan(pl[steps == 5024][0])
+    assert pl[steps == 5055][0] == pl[steps == 5024][0] != pl[steps == 5056][0]
+    tr, rows = run_oracle_steps(g, calls=5)
+    assert_calm_rows(rows, g)
