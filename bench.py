@@ -260,7 +260,14 @@ def main():
                     help="1 = replay the step as captured HIP graphs after the eager warm-up calls (0 = eager enqueue, "
                          "the default: at 256 px the step is GPU-bound and the capture of the multi-stream step is not "
                          "stable on ROCm 7.2, see DESIGN.md)")
+    ap.add_argument("--host-share", type=int, default=int(os.environ.get("STYLEX_HOST_SHARE", "1")),
+                    help="emulate the host share of one rank on an N-GPU node: pin this process (before anything touches "
+                         "the GPU; no re-exec) to 1/N of the cores it may run on")
     args = ap.parse_args()
+    if args.host_share > 1:
+        cores = sorted(os.sched_getaffinity(0))
+        keep = cores[:max(1, len(cores) // args.host_share)]
+        os.sched_setaffinity(0, keep)  # threads started later (autograd engine, prefetch, BLAS pools) inherit it
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -426,6 +433,7 @@ def main():
                        "image_size": args.image_size, "batch_per_gpu": args.batch,
                        "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
                        "parallelism": "dp%d" % world,
+                       "host_cores": len(os.sched_getaffinity(0)),
                        "frozen_nets": "stock MIOpen fp32, algorithms searched during the warm-up steps (the Trainer's "
                                       "default in the bf16 mode, same as a cli.py run)"
                                       if not args.no_miopen_find else "stock MIOpen fp32, immediate mode (reference cli.py:38)"},

@@ -421,10 +421,9 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
             if ((p.flags & STYLEX_EPI_RESIDUAL) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15)))
                 return STYLEX_NOT_APPLICABLE;
         }
-        // 128-channel tiles (one block per CU) halve the L2 -> LDS halo traffic per MFMA of these DMA-rate-bound
-        // launches (1 - 4 taps of MFMA work per staged 20 KB halo chunk); opt-in until measured: STYLEX_S2D_WIDE=1
-        static const bool wide = getenv("STYLEX_S2D_WIDE") && getenv("STYLEX_S2D_WIDE")[0] == '1';
-        if (wide && p.s2d_c % 128 == 0 && p.N % 128 == 0) return p.dry ? 0 : launch_dma<4, true>(p, s);
+        // (round 4: the 128-channel tile <4, true> at one block per CU was measured on these launches — 683 vs 815
+        // images/s on the step, profiles/r04_b_ab_s2d_wide.txt: the masked chunk loops with 256 accumulator registers
+        // spill — so the 64-channel tile at two blocks per CU stays)
         return p.dry ? 0 : launch_dma<2, true>(p, s);
     }
     // Measured at B = 64 (fwd / dgrad ms, 128-channel tiles at one block per CU -> 64-channel tiles at two):

@@ -701,7 +701,16 @@ class Trainer:
         self.device_pipeline = (os.environ.get("STYLEX_DEVICE_PIPELINE", "0") == "1") if device_pipeline is None \
             else bool(device_pipeline)
         # per-instance (a class-level switch leaked into every later Trainer of the process and broke their CPU-RNG parity)
-        self.device_rng = _Staging.ENV_DEVICE_RNG if device_rng is None else bool(device_rng)
+        # Under data parallelism the latents / noise planes are drawn on the GPU generator by default: every rank shares
+        # ONE host with the others (an 8-GPU node leaves each rank 1/8 of the cores), the CPU-generator draws of the four
+        # noise planes cost ~13 ms of host time per step, and there is no reference random stream to keep — the
+        # reference's multi-GPU path never worked (README.md:81) and the ranks draw from rank-distinct seeds anyway.
+        # Single-GPU runs keep the reference's CPU draw order (the parity default).  STYLEX_DEVICE_RNG=0 / 1 or
+        # Trainer(device_rng=...) override.
+        if device_rng is None:
+            env = os.environ.get("STYLEX_DEVICE_RNG")
+            device_rng = (env == "1") if env is not None else (bool(is_ddp) and torch.cuda.is_available())
+        self.device_rng = bool(device_rng)
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
         if classifier is not None:
@@ -748,6 +757,10 @@ class Trainer:
             self._d_sync = parallel.GradSync(list(m.D.parameters()))
             self._g_sync = parallel.GradSync(list(m.G.parameters()) + list(m.S.parameters())
                                              + list(m.encoder.parameters()))
+            if self.device_rng and self.device.type == "cuda":
+                # device-side draws: every rank gets its own latent / noise stream (cli.set_seed seeds all ranks alike,
+                # like the reference's cli.py:49 — with the CPU draws that makes every rank see the same z)
+                torch.cuda.manual_seed(torch.cuda.initial_seed() + 7919 * self.rank)
 
     def write_config(self):
         self.config_path.write_text(json.dumps(self.config()))

@@ -1691,3 +1691,23 @@ def test_first_layer_rgb_kernel(case):
     close(ref.float(), got.float(), 1e-2, "rgb kernel vs generic")
     want = F.leaky_relu(F.conv2d(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), bias.double(), padding=1), 0.2)
     close(want, got.double(), 1e-2, "rgb kernel vs fp64 definition")
+
+
+def test_gradsync_on_one_rank_rccl_is_bit_identical_to_single_gpu():
+    """the gradient exchange on the REAL RCCL code path (a 1-rank process group): GradSync with the
+    collectives after the backward and with the in-backward bucket launch (overlap=True) both end three train() calls
+    with parameters and loss scalars BIT-IDENTICAL to the plain single-GPU Trainer (tools/ddp_overlap_identity.py; a
+    subprocess, so that the process group cannot leak into the other tests)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_overlap_identity.py"), "3"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep["identical_to_single"] == {"post": True, "overlap": True}, rep
+    assert rep["n_params"] > 100
