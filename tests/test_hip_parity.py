@@ -521,6 +521,9 @@ def assert_trajectory(rows, gold, tag, floor=2e-3, factor=4.0, cap=5e-2):
     above `cap` — instead of the free 4x-per-call growth this test used in round 3."""
     rows, gold = np.asarray(rows, dtype=np.float64), np.asarray(gold, dtype=np.float64)
     spread = load_golden("steps_envelope")["spread_" + tag]
+    dev = np.nanmax(np.abs(rows - gold) / np.maximum(np.abs(gold), 1e-2), axis=1)
+    print("trajectory %s: HIP-vs-reference deviation per call %s | reference-vs-itself spread %s"
+          % (tag, " ".join("%.1e" % v for v in dev), " ".join("%.1e" % v for v in spread)))
     for k in range(len(gold)):
         tol = min(cap, max(floor, factor * float(spread[min(k, len(spread) - 1)])))
         np.testing.assert_allclose(rows[k], gold[k], rtol=tol, atol=tol, equal_nan=True,
