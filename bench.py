@@ -129,7 +129,8 @@ def build_trainer(args, device, rank, world):
                     alternating_training=True, classifier_name=args.classifier, classifier_path=None,
                     evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None,
                     is_ddp=world > 1 or os.environ.get("STYLEX_FORCE_DDP") == "1", rank=rank,
-                    world_size=world, device=device, graphs=bool(getattr(args, "graphs", 0)))
+                    world_size=world, device=device, graphs=bool(getattr(args, "graphs", 0)),
+                    pl_every=int(getattr(args, "pl_every", 32)))
     tr.loader = st.cycle(ring)
     tr.dataset = list(range(10 ** 6))
     tr.save = lambda *a, **k: None
@@ -260,6 +261,12 @@ def main():
                     help="1 = replay the step as captured HIP graphs after the eager warm-up calls (0 = eager enqueue, "
                          "the default: at 256 px the step is GPU-bound and the capture of the multi-stream step is not "
                          "stable on ROCm 7.2, see DESIGN.md)")
+    ap.add_argument("--pl-every", type=int, default=32,
+                    help="path-length regularisation interval (reference: 32; BASELINE config 4 says 16); active from "
+                         "--start-step > 5000 on")
+    ap.add_argument("--start-step", type=int, default=0,
+                    help="Trainer.steps at the start of the timed region (0: one call in 4 carries the gradient penalty, "
+                         "no path-length steps; 5024: path-length steps every --pl-every calls as well)")
     ap.add_argument("--host-share", type=int, default=int(os.environ.get("STYLEX_HOST_SHARE", "1")),
                     help="emulate the host share of one rank on an N-GPU node: pin this process (before anything touches "
                          "the GPU; no re-exec) to 1/N of the cores it may run on")
@@ -315,7 +322,9 @@ def main():
     while tr.graphs and len(tr._graph_cache) < 2 and extra < 12:
         tr.train()
         extra += 1
-    tr.steps = 0  # the timed region starts on a GP step: 1 call in 4 carries the penalty
+    tr.steps = args.start_step  # the timed region starts on a GP step: 1 call in 4 carries the penalty
+    if args.start_step > 5000 and tr.pl_mean is None:
+        tr.pl_mean = 1.0  # as after the first path-length step of a real run
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -430,7 +439,8 @@ def main():
             "config": {"workload": "FFHQ-shaped %dx%d StylEx, batch %d/GPU, GAE=%d (noise+encoder micro-steps), GP every "
                                    "4th step, %s classifier" % (args.image_size, args.image_size, args.batch, args.gae,
                                                                 "ResNet-18" if args.classifier == "resnet" else "MobileNetV2"),
-                       "image_size": args.image_size, "batch_per_gpu": args.batch,
+                       "image_size": args.image_size, "batch_per_gpu": args.batch, "start_step": args.start_step,
+                       "pl_every": args.pl_every if args.start_step > 5000 else None,
                        "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
                        "parallelism": "dp%d" % world,
                        "host_cores": len(os.sched_getaffinity(0)),

@@ -134,8 +134,39 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("STYLEX_SYNC_TRACE", "0") == "1":
+        lib = _SyncTraced(lib)
     _lib = lib
     return lib
+
+
+class _SyncTraced:
+    """STYLEX_SYNC_TRACE=1 (debug): every C-ABI call is announced on stderr BEFORE it is issued and followed by a
+    device synchronisation and an "ok" — a GPU memory fault (reported asynchronously by the runtime, as an abort without
+    a Python frame) then sits between the announcement of the call that caused it and its "ok"; an abort after an "ok"
+    comes from a kernel that is not ours."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("stylex_") or name.endswith("_bytes") or name in (
+                "stylex_reduce_chunks", "stylex_conv_mask_supported", "stylex_version"):
+            return fn
+        import sys
+
+        def traced(*args):
+            desc = " ".join(str(list(a)[:11]) if hasattr(a, "_length_") else "" for a in args).strip()
+            sys.stderr.write("-> %s %s\n" % (name, desc))
+            sys.stderr.flush()
+            rc = fn(*args)
+            torch.cuda.synchronize()
+            sys.stderr.write("   ok %s rc=%s\n" % (name, rc))
+            sys.stderr.flush()
+            return rc
+
+        return traced
 
 
 def _check(rc, what):

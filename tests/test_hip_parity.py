@@ -705,6 +705,59 @@ def test_config2_full_size_bf16_tracks_fp32(tmp_path):
     assert abs(lo[4] - ref[4]) <= 1e-1 * scale[4], (lo, ref)
 
 
+def test_config4_full_size_bf16_tracks_fp32_and_is_deterministic(tmp_path):
+    """BASELINE config 4 at FULL size, as `bench.py --image-size 128 --classifier mobilenet --pl-every 16 --start-step
+    5024` builds it: 128 px, batch 32, GAE 2, MobileNetV2 classifier, starting on step 5024 — a call that carries BOTH
+    the gradient penalty (5024 % 4 == 0) and the path-length penalty (> 5000, % 16 == 0; the double backward through
+    the generator) — followed by a plain call.  Asserted: everything finite; the first call of the bf16 speed mode inside
+    the bf16 band of the fp32 parity mode for every scalar (5e-2; the two penalties 1e-1) and pl_mean likewise; and the
+    speed mode run twice from the same seeds gives bit-identical scalars and parameters (fixed-order reductions, also
+    through the path-length step)."""
+    import argparse
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+
+    def run(prec, tag):
+        ops.set_precision(prec)
+        hb.pack_cache_clear()
+        a = argparse.Namespace(batch=32, image_size=128, gae=2, classifier="mobilenet", workdir=str(tmp_path / tag),
+                               precision=prec, pl_every=16)
+        bench.seed_all(42)
+        tr = bench.build_trainer(a, torch.device(DEV), 0, 1)
+        assert type(tr.classifier).__name__ == "MobileNet" and tr.pl_every == 16
+        tr.steps, tr.pl_mean = 5024, 1.0
+        rows = []
+        for _ in range(2):
+            tr.train()
+            rows.append([tr.d_loss, tr.g_loss, tr.total_rec_loss, tr.total_kl_loss, tr.last_gp_loss, tr.pl_mean])
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(p).all()) for p in tr.StylEx.parameters())
+        sums = [float(p.detach().double().sum()) for p in tr.StylEx.parameters()]
+        del tr
+        torch.cuda.empty_cache()
+        return np.array(rows, dtype=np.float64), sums
+
+    try:
+        run("bf16", "warm")  # the first Trainer of a process orders its double backward differently (DESIGN §3)
+        lo, sums_a = run("bf16", "a")
+        lo2, sums_b = run("bf16", "b")
+        ref, _ = run("fp32", "f")
+    finally:
+        ops.set_precision("fp32")
+    print("config 4, two calls (d, g, rec, kl, gp, pl_mean):", lo, ref)
+    assert np.isfinite(lo).all() and np.isfinite(ref).all(), (lo, ref)
+    assert lo[0][5] != 1.0, "the first call must have been a path-length step (pl_mean moved)"
+    assert np.array_equal(lo, lo2) and sums_a == sums_b, "bf16 mode: two identically seeded runs must be bit-identical"
+    scale = np.maximum(1.0, np.abs(ref[0]))
+    assert (np.abs(lo[0][:4] - ref[0][:4]) <= 5e-2 * scale[:4]).all(), (lo[0], ref[0])
+    assert (np.abs(lo[0][4:] - ref[0][4:]) <= 1e-1 * scale[4:]).all(), (lo[0], ref[0])
+
+
 def test_100_call_trajectory_vs_reference_golden(tmp_path):
     """X1 — north_star's "loss curves matching the CPU reference to 1e-3 over 100 steps", asserted on EVERY call: the
     HIP fp32 path against the reference's own 100-call trajectory in a regime the reference holds against itself
