@@ -4,6 +4,19 @@ This is the only place the Python host touches native code.  There is NO
 fallback: if the shared library is missing or a kernel returns an error the
 call raises.  PyTorch is used for device memory and the current HIP stream only.
 """
+import os as _os
+
+# MIOpen's asm implicit-GEMM backward-data solver for NHWC (ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC, kernels
+# igemm_bwd_gtcx35_nhwc_fp32_*) reads outside its buffers on this stack (ROCm 7.2, MIOpen 3.5.0, gfx950) for the
+# small-batch backward convolutions of the frozen classifier: root cause of the aborts this project logged since round 1
+# (SIGABRT without a message inside the generator phase's backward of the 64 px CLI test, ~2 of 45 suite runs) — with
+# torch.backends.cudnn.benchmark the exhaustive search reaches a faulting tuning candidate EVERY time ("Memory access
+# fault by GPU node-2 ... on address 0x....e00000", always a 2 MiB boundary; profiles/r04_c_abort_*; DESIGN §3 round 4).
+# The frozen networks stay on stock MIOpen, minus that one solver; MIOpen reads the variable when it is first used, so it
+# is set before torch runs any convolution.  STYLEX_MIOPEN_ALLOW_BWD_GTC=1 leaves MIOpen's solver list untouched.
+if _os.environ.get("STYLEX_MIOPEN_ALLOW_BWD_GTC", "0") != "1":
+    _os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+
 import atexit
 import ctypes
 import os

@@ -677,14 +677,13 @@ class Trainer:
             # noise source of a step is MIOpen's default algorithm choice for the frozen classifier / LPIPS.  Pinning
             # it makes a whole training run reproducible for about 1 % of step throughput.
             torch.backends.cudnn.deterministic = True
-        # MIOpen algorithm choice for the frozen classifier / LPIPS convolutions.  The reference's cli.py:38 sets
-        # cudnn.benchmark = False (immediate mode) and the fp32 parity mode keeps that.  In the bf16 speed mode the
-        # Trainer lets MIOpen SEARCH during the first calls (benchmark = True, still restricted to deterministic
-        # algorithms when cli.set_seed asked for them): on a fresh machine the immediate-mode picks are up to 6 % of
-        # step throughput slower than the searched ones, and bench.py's headline number is measured with the search —
-        # a real `cli.py` run now gets the same kernels.  STYLEX_MIOPEN_BENCHMARK=0 / 1 overrides either way.
-        mb = os.environ.get("STYLEX_MIOPEN_BENCHMARK")
-        if mb == "1" or (mb is None and ops.get_precision() != "fp32" and torch.cuda.is_available()):
+        # MIOpen algorithm choice for the frozen classifier / LPIPS convolutions: the reference's setting, immediate
+        # mode (cli.py:38 cudnn.benchmark = False) — also what bench.py measures.  STYLEX_MIOPEN_BENCHMARK=1 lets
+        # MIOpen search instead; PyTorch then asks for an EXHAUSTIVE search, which on this ROCm 7.2 / gfx950 stack runs
+        # tuning candidates of ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC that fault on small batches (see the
+        # head of hip_backend.py: that solver is disabled by default), and measured no faster than immediate mode (818 vs 805-814
+        # images/s, profiles/r04_c_ab_miopen_modes.txt).
+        if os.environ.get("STYLEX_MIOPEN_BENCHMARK") == "1":
             torch.backends.cudnn.benchmark = True
         self.save_training_state = save_training_state
         self.device = _dev(device if device is not None else rank)
