@@ -121,6 +121,8 @@ SIGNATURES = {
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_layers": (ctypes.c_int, [_i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "stylex_timing_kernels": (ctypes.c_int, [ctypes.c_char_p, _i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
+    "stylex_adam_pack_tensor_blocks": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "stylex_adam_pack_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
@@ -317,6 +319,7 @@ def _checksum(w):
 
 def pack_cache_clear():
     _PACK_CACHE.clear()
+    _PARAM_KEYS.clear()
 
 
 def _release_at_exit():
@@ -374,15 +377,18 @@ def _cache_hit(key, w, version=None):
 
 
 _PACK_RECIPES = {}  # key -> (weakref to the parameter, function that packs it again): what `prepack` replays
+_PARAM_KEYS = {}    # id(parameter) -> keys of its cache entries (adam_pack_step rewrites them in place)
 
 
 def _cache_put(key, w_param, wf, wb, version=None, recipe=None):
     if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
         _PACK_CACHE.clear()
+        _PARAM_KEYS.clear()
     ev = torch.cuda.Event()
     ev.record()
     _PACK_CACHE[key] = (weakref.ref(w_param), wf, wb, ev, _stream_id(),
                         _gen(w_param) if version is None else version, _checksum(w_param) if _CACHE_CHECK else None)
+    _PARAM_KEYS.setdefault(id(w_param), set()).add(key)
     if recipe is not None:
         if len(_PACK_RECIPES) >= 4 * _PACK_CACHE_MAX:
             _PACK_RECIPES.clear()
@@ -418,6 +424,150 @@ def prepack(params):
     with torch.cuda.stream(side):
         for w, fn in todo:
             fn(w)
+
+
+# ---- Adam step + refresh of the cached operand copies in ONE launch (csrc/adam_pack.hip) --------------------------------
+_ADAM_DT = None
+_ADAM_PLANS = {}  # id(optimizer) -> plan
+_ADAM_ON = os.environ.get("STYLEX_ADAM_PACK", "1") != "0"
+
+
+def _adam_dtype():
+    global _ADAM_DT
+    if _ADAM_DT is None:
+        import numpy as np
+
+        var = np.dtype([("kind", "<i4"), ("scale", "<f4"), ("a", "<u8"), ("b", "<u8")], align=True)
+        _ADAM_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("step", "<u8"), ("numel", "<i8"),
+                             ("N", "<i4"), ("C", "<i4"), ("T", "<i4"), ("nvar", "<i4"), ("first_block", "<i8"),
+                             ("lr", "<f8"), ("beta1", "<f8"), ("beta2", "<f8"), ("eps", "<f8"), ("var", var, (4,))],
+                            align=True)
+        assert _ADAM_DT.itemsize == 200, _ADAM_DT.itemsize  # sizeof(stylex_adam_tensor)
+    return _ADAM_DT
+
+
+def _adam_copies_of(p):
+    """Cache entries (key, kind, scale, a, b) of parameter `p` that the fused step can rewrite from the updated value:
+    bf16 operand packs (plain and space-to-depth), the bf16 GEMM matrix of a 1x1 weight, the tap sum of squares.  Other
+    derived copies (mirrored-tap packs of the penalty pass, fp32 packs, scaled linear parameters) stay lazy."""
+    out = []
+    ptr, shape = p.data_ptr(), tuple(p.shape)
+    for key in _PARAM_KEYS.get(id(p), ()):
+        hit = _PACK_CACHE.get(key)
+        if hit is None or hit[0]() is not p or len(key) != 4 or key[0] != ptr or key[1] != shape:
+            continue
+        tag, scale = key[2], key[3]
+        if isinstance(scale, str):  # mirrored-tap packs of the penalty pass ("fwd_as_dgrad"): stay lazy
+            continue
+        a, b = hit[1], hit[2]
+        sc = 1.0 if scale is None else float(scale)
+        if tag in (BF16, BF16_ACT) and len(shape) == 4 and all(t is None or t.dtype == torch.bfloat16 for t in (a, b)):
+            out.append((key, 0, sc, a, b))
+        elif tag == "s2d" and len(shape) == 4 and shape[2] == 3 and shape[3] == 3:
+            out.append((key, 1, sc, a, b))
+        elif tag == "bf16mat" and a is not None and a.dtype == torch.bfloat16:
+            out.append((key, 0, sc, a, None))  # [N][C*T] matrix == the forward pack of a T = 1 conv
+        elif tag == "wsq" and a is not None and a.dtype == torch.float32:
+            out.append((key, 2, 1.0, a, None))
+    return out
+
+
+def adam_pack_step(opt):
+    """opt.step() for a torch.optim.Adam(fused=True) in the bf16 speed mode: the Adam update of every parameter that has
+    a gradient AND the refresh of its cached operand copies, one launch (stylex_adam_pack_step).  Operates on the
+    optimiser's own state tensors (exp_avg, exp_avg_sq, step), so state_dict() / checkpoints are unchanged.  Returns
+    False when the optimiser / state is not in the supported form (first step: torch initialises the state; weight
+    decay, amsgrad, maximize, capturable graphs) — the caller then runs opt.step() itself."""
+    import numpy as np
+
+    if not _ADAM_ON:
+        return False
+    todo = []
+    for g in opt.param_groups:
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or not g.get("fused"):
+            return False
+        if g.get("differentiable") or not isinstance(g["lr"], float):
+            return False
+        for p in g["params"]:
+            if p.grad is None:
+                continue
+            st = opt.state.get(p)
+            if not st or "exp_avg" not in st or not torch.is_tensor(st.get("step")) or not st["step"].is_cuda:
+                return False
+            if (p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32
+                    or not p.grad.is_contiguous() or p.grad.is_sparse):
+                return False
+            todo.append((p, st, g))
+    if not todo:
+        return True
+    lib = _ensure_device(todo[0][0])
+    dev = todo[0][0].device
+    dt = _adam_dtype()
+    # ---- plan: everything but the gradient pointers is stable from step to step
+    copies_of = {id(p): sorted(_adam_copies_of(p), key=lambda e: (str(e[0][2]), e[2], e[1])) for p, _, _ in todo}
+    sig = tuple((id(p), p.data_ptr(), tuple((str(k[2]), sc, 0 if a is None else a.data_ptr(), 0 if b is None else b.data_ptr())
+                                            for k, _, sc, a, b in copies_of[id(p)]))
+                for p, _, _ in todo)
+    plan = _ADAM_PLANS.get(id(opt))
+    if plan is None or plan["sig"] != sig:
+        host = np.zeros(len(todo), dtype=dt)
+        entries, block_map, nb = [], [], 0
+        for i, (p, st, g) in enumerate(todo):
+            copies = copies_of[id(p)][:4]
+            shape = tuple(p.shape)
+            if len(shape) == 4 and shape[2] * shape[3] <= 9 and (copies or True):
+                n, c, t = shape[0], shape[1], shape[2] * shape[3]
+            elif copies and len(shape) == 2:
+                n, c, t = shape[0], shape[1], 1
+            else:
+                n, c, t = 0, 0, 0
+                copies = []
+            blocks = lib.stylex_adam_pack_tensor_blocks(p.numel(), n, c, t)
+            if blocks < 0:
+                n = c = t = 0
+                copies = []
+                blocks = lib.stylex_adam_pack_tensor_blocks(p.numel(), 0, 0, 0)
+            r = host[i]
+            r["p"], r["m"], r["v"], r["step"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+            r["numel"], r["N"], r["C"], r["T"], r["nvar"], r["first_block"] = p.numel(), n, c, t, len(copies), nb
+            r["lr"], r["beta1"], r["beta2"], r["eps"] = g["lr"], g["betas"][0], g["betas"][1], g["eps"]
+            for j, (key, kind, sc, a, b) in enumerate(copies):
+                r["var"][j]["kind"], r["var"][j]["scale"] = kind, sc
+                r["var"][j]["a"] = 0 if a is None else a.data_ptr()
+                r["var"][j]["b"] = 0 if b is None else b.data_ptr()
+                entries.append((key, p))
+            block_map.append(np.full(blocks, i, dtype=np.int32))
+            nb += blocks
+        bm = torch.from_numpy(np.concatenate(block_map)).to(dev)
+        pinned = [torch.empty(host.nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        plan = _ADAM_PLANS[id(opt)] = dict(sig=sig, host=host, entries=entries, block_map=bm, n_blocks=nb, pinned=pinned,
+                                           flip=0, dev_descs=torch.empty(host.nbytes, dtype=torch.uint8, device=dev),
+                                           steps=[st["step"] for _, st, _ in todo], opt_ref=weakref.ref(opt))
+        if len(_ADAM_PLANS) > 16:
+            for k in [k for k, v in _ADAM_PLANS.items() if v["opt_ref"]() is None]:
+                del _ADAM_PLANS[k]
+    host = plan["host"]
+    host["g"] = np.fromiter((p.grad.data_ptr() for p, _, _ in todo), dtype=np.uint64, count=len(todo))
+    for i, (_, _, g) in enumerate(todo):  # a scheduler may have changed it
+        host["lr"][i] = g["lr"]
+    pin = plan["pinned"][plan["flip"]]
+    plan["flip"] ^= 1
+    pin.numpy()[:] = host.view(np.uint8).reshape(-1)
+    plan["dev_descs"].copy_(pin, non_blocking=True)
+    torch._foreach_add_(plan["steps"], 1)
+    _check(lib.stylex_adam_pack_step(plan["dev_descs"].data_ptr(), plan["block_map"].data_ptr(), plan["n_blocks"], _stream()),
+           "stylex_adam_pack_step")
+    # the parameters changed (no version bump by a raw kernel): new stamp, and the refreshed copies are valid FOR it
+    mark_updated([p for p, _, _ in todo])
+    if plan["entries"]:
+        ev = torch.cuda.Event()
+        ev.record()
+        sid = _stream_id()
+        for key, p in plan["entries"]:
+            hit = _PACK_CACHE.get(key)
+            if hit is not None and hit[0]() is p:
+                _PACK_CACHE[key] = (hit[0], hit[1], hit[2], ev, sid, _gen(p), _checksum(p) if _CACHE_CHECK else None)
+    return True
 
 
 def prepack_join():

@@ -1288,10 +1288,14 @@ class Trainer:
         prepack = os.environ.get("STYLEX_PREPACK", "0") == "1"
         if prepack:
             hb.prepack_join()  # earlier prepacks have read the parameters
-        opt.step()
-        # the fused Adam does not bump Parameter._version: stamp what it stepped, or every cached operand copy of
-        # these weights (bf16 GEMM layouts, scaled mapping-network weights, ...) would be served stale
-        hb.mark_updated(params)
+        # bf16 speed mode: Adam + the refresh of every cached operand copy of the stepped weights in ONE launch
+        # (hb.adam_pack_step / csrc/adam_pack.hip: it stamps the parameters and re-validates the copies it rewrote);
+        # STYLEX_ADAM_PACK=0, the first step of an optimiser, graphs and the fp32 parity mode take torch's own step
+        if not (ops.get_precision() == "bf16" and not _capturing() and hb.adam_pack_step(opt)):
+            opt.step()
+            # the fused Adam does not bump Parameter._version: stamp what it stepped, or every cached operand copy of
+            # these weights (bf16 GEMM layouts, scaled mapping-network weights, ...) would be served stale
+            hb.mark_updated(params)
         if prepack:
             hb.prepack(params)
 

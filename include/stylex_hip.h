@@ -339,6 +339,39 @@ int stylex_timing_layers(int64_t* meta, double* vals, int64_t cap);
  * rocprofv3 --kernel-trace --stats summary under profiles/. */
 int stylex_timing_kernels(char* names, int64_t* meta, double* vals, int64_t cap);
 
+/* ---- Adam step + operand copies in one launch (bf16 speed mode) -------------------------------------------------
+ * Reference: Adam(lr, betas=(0.5, 0.9)) of StylEx.G_opt / D_opt (stylex_train.py:957-959), stepped at :1357 / :1449.
+ * One launch applies the Adam update (rule of torch._fused_adam_, no weight decay / amsgrad) to a LIST of fp32 tensors
+ * and rewrites, from the updated values, the derived copies the conv kernels read: kind PACK = the bf16 operand layouts
+ * of stylex_pack_weight (a = [N][T][C], b = [C][T][N]; either may be NULL; a 1x1 weight's [N][C] GEMM matrix is the
+ * same layout with T = 1), PACK_S2D = those of stylex_pack_weight_s2d, SUMSQ = stylex_weight_sumsq (a = fp32 [N][C]);
+ * every copy holds scale * w.  `step` points to the tensor's step counter (a device float, ALREADY incremented).
+ * N = 0 marks a flat tensor (numel elements, no copies).  descs / block_map live in device memory: block_map[i] = index
+ * of the tensor that block i works on, blocks of one tensor consecutive from first_block, their number given by
+ * stylex_adam_pack_tensor_blocks() (a host helper; -1 for an unsupported geometry: T > 9 or N*C*T != numel). */
+#define STYLEX_ADAM_COPY_PACK 0
+#define STYLEX_ADAM_COPY_PACK_S2D 1
+#define STYLEX_ADAM_COPY_SUMSQ 2
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    const float* step;
+    int64_t numel;
+    int32_t N, C, T, nvar;
+    int64_t first_block;
+    double lr, beta1, beta2, eps;
+    struct {
+        int32_t kind;
+        float scale;
+        void* a;
+        void* b;
+    } var[4];
+} stylex_adam_tensor;
+int64_t stylex_adam_pack_tensor_blocks(int64_t numel, int32_t N, int32_t C, int32_t T);
+int stylex_adam_pack_step(const stylex_adam_tensor* descs_dev, const int32_t* block_map_dev, int64_t n_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

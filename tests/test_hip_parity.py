@@ -1767,3 +1767,104 @@ def test_gradsync_on_one_rank_rccl_is_bit_identical_to_single_gpu():
     rep = json.loads(line)
     assert rep["identical_to_single"] == {"post": True, "overlap": True}, rep
     assert rep["n_params"] > 100
+
+
+def test_adam_pack_step_matches_torch_fused_adam_and_the_pack_kernels():
+    """csrc/adam_pack.hip (round 4): ONE launch = the Adam update of torch._fused_adam_ on the optimiser's own state
+    tensors + every cached operand copy of the stepped weights rewritten from the updated values.  Against two reference
+    runs from identical state: parameters / moments after 3 steps equal torch's fused Adam to fp32 rounding (same rule;
+    the operation order inside an element differs by at most an ulp or two), and every refreshed cache entry — bf16
+    operand packs [N][T][C] / [C][T][N] (plain and scaled), space-to-depth packs, the bf16 1x1 GEMM matrix, the tap sum
+    of squares — is BIT-identical to what the pack kernels produce from the parameter values the fused step left
+    behind; parameters without a gradient are untouched and keep their copies valid."""
+    torch.manual_seed(5)
+    dev = torch.device(DEV)
+    shapes = [(64, 64, 3, 3), (24, 40, 3, 3), (128, 64, 1, 1), (3, 32, 1, 1), (70, 130, 3, 3), (512,), (17, 33), (8, 3, 3, 3)]
+
+    def make():
+        torch.manual_seed(6)
+        ps = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.1) for s in shapes]
+        frozen = torch.nn.Parameter(torch.randn(32, 32, 3, 3, device=dev) * 0.1)  # never gets a gradient
+        opt = torch.optim.Adam([{"params": ps[:4] + [frozen], "lr": 2e-4}, {"params": ps[4:], "lr": 1e-5}], betas=(0.5, 0.9),
+                               fused=True)
+        return ps, frozen, opt
+
+    def grads(ps, k):
+        g = torch.Generator(device=dev).manual_seed(100 + k)
+        for p in ps:
+            p.grad = torch.randn(p.shape, device=dev, generator=g) * (10.0 ** (k - 1))
+
+    def touch(ps, frozen):  # create the cache entries a training step would have created
+        c = 1 / 2 ** 0.5
+        hb.pack_weight(ps[0], True, True, hb.BF16_ACT)
+        hb.pack_weight(ps[0], False, True, hb.BF16_ACT, scale=c)
+        hb.pack_weight_s2d(ps[0])
+        hb.pack_weight_s2d(ps[0], scale=c)
+        hb.pack_weight(ps[1], True, True, hb.BF16_ACT)
+        hb.weight_sumsq(ps[1])
+        hb._bf16_matrix(ps[2])
+        hb._bf16_matrix(ps[2], c)
+        hb.pack_weight(ps[3], True, True, hb.BF16_ACT)
+        hb.pack_weight(ps[4], True, True, hb.BF16_ACT)
+        hb.weight_sumsq(ps[4])
+        hb.pack_weight(ps[7], True, True, hb.BF16_ACT)
+        hb.pack_weight(frozen, True, True, hb.BF16_ACT)
+
+    hb.pack_cache_clear()
+    ref_p, ref_frozen, ref_opt = make()
+    ps, frozen, opt = make()
+    grads(ref_p, 0), grads(ps, 0)
+    ref_opt.step()
+    assert hb.adam_pack_step(opt) is False, "the first step initialises torch's state: must fall back"
+    opt.step()
+    touch(ps, frozen)
+    frozen_pack = hb.pack_weight(frozen, True, True, hb.BF16_ACT)[0].clone()
+    for k in (1, 2, 3):
+        grads(ref_p, k), grads(ps, k)
+        ref_opt.step()
+        before = {key: (e[1], e[2]) for key, e in hb._PACK_CACHE.items()}
+        assert hb.adam_pack_step(opt) is True
+        for a, b in zip(ps, ref_p):
+            close(b, a, 2e-6, "parameter after step %d" % k)
+            sa, sb = opt.state[a], ref_opt.state[b]
+            close(sb["exp_avg"], sa["exp_avg"], 2e-6, "exp_avg")
+            close(sb["exp_avg_sq"], sa["exp_avg_sq"], 2e-6, "exp_avg_sq")
+            assert float(sa["step"]) == float(sb["step"]) == k + 1
+        # every entry the step claims to have refreshed: served from the cache (no re-pack) and bit-identical to a fresh pack
+        c = 1 / 2 ** 0.5
+        checks = [(lambda: hb.pack_weight(ps[0], True, True, hb.BF16_ACT), ps[0], None, "pack"),
+                  (lambda: hb.pack_weight(ps[0], False, True, hb.BF16_ACT, scale=c), ps[0], c, "pack"),
+                  (lambda: hb.pack_weight_s2d(ps[0]), ps[0], None, "s2d"),
+                  (lambda: hb.pack_weight_s2d(ps[0], scale=c), ps[0], c, "s2d"),
+                  (lambda: hb.pack_weight(ps[1], True, True, hb.BF16_ACT), ps[1], None, "pack"),
+                  (lambda: (hb.weight_sumsq(ps[1]), None), ps[1], None, "wsq"),
+                  (lambda: (hb._bf16_matrix(ps[2]), None), ps[2], None, "mat"),
+                  (lambda: (hb._bf16_matrix(ps[2], c), None), ps[2], c, "mat"),
+                  (lambda: hb.pack_weight(ps[3], True, True, hb.BF16_ACT), ps[3], None, "pack"),
+                  (lambda: hb.pack_weight(ps[4], True, True, hb.BF16_ACT), ps[4], None, "pack"),
+                  (lambda: (hb.weight_sumsq(ps[4]), None), ps[4], None, "wsq"),
+                  (lambda: hb.pack_weight(ps[7], True, True, hb.BF16_ACT), ps[7], None, "pack")]
+        for get, p, sc, kind in checks:
+            got = [t.clone() if t is not None else None for t in get()]
+            ptrs = {t.data_ptr() for pair in before.values() for t in pair if t is not None}
+            assert all(t is None or t.data_ptr() not in () for t in got)
+            served = get()
+            assert any(t is not None and t.data_ptr() in ptrs for t in served), (kind, "not served from the cache")
+            fresh = torch.nn.Parameter(p.detach().clone())  # a new Parameter object: never cached, packs from scratch
+            if kind == "pack":
+                want = hb.pack_weight(fresh, got[0] is not None, got[1] is not None, hb.BF16_ACT, scale=sc)
+            elif kind == "s2d":
+                want = hb.pack_weight_s2d(fresh, scale=sc)
+            elif kind == "wsq":
+                want = (hb.weight_sumsq(fresh), None)
+            else:
+                want = (hb._bf16_matrix(fresh, sc), None)
+            for g_, w_ in zip(got, want):
+                if g_ is None:
+                    continue
+                if kind == "wsq":
+                    close(w_, g_, 1e-6, "tap sum of squares")
+                else:
+                    assert torch.equal(g_.view(-1), w_.view(-1)), (kind, sc, tuple(p.shape), "copy differs from a fresh pack")
+        assert torch.equal(hb.pack_weight(frozen, True, True, hb.BF16_ACT)[0], frozen_pack)
+    hb.pack_cache_clear()
