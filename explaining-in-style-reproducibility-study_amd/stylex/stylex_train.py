@@ -17,6 +17,7 @@ AttFind notebook imports.  New, MI355X-first behaviour:
     to wrap (:1188-1193).
 """
 import atexit
+import threading
 import json
 import math
 import multiprocessing
@@ -96,6 +97,8 @@ def _own_rng_mode(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
+        if fn.__name__ != "train":
+            self._drain_draw_ahead()  # a prefetched draw of the next train() call must not interleave with these draws
         prev, _Staging.DEVICE_RNG = _Staging.DEVICE_RNG, self.device_rng
         try:
             return fn(self, *a, **k)
@@ -163,6 +166,7 @@ class _Staging:
 
     ENV_DEVICE_RNG = os.environ.get("STYLEX_DEVICE_RNG", "0") == "1"
     DEVICE_RNG = ENV_DEVICE_RNG  # set by the Trainer that is drawing (per-instance state, see _own_rng_mode)
+    _tls = threading.local()     # .device_rng: per-thread override (the draw-ahead worker always draws on the CPU)
 
     @classmethod
     def upload(cls, shape, fill, device):
@@ -171,7 +175,7 @@ class _Staging:
         draw and no 8 MB upload per noise plane, but a different random stream than the reference's CPU one (the
         parity default keeps the CPU draw order)."""
         device = _dev(device)
-        if device.type == "cuda" and cls.DEVICE_RNG:
+        if device.type == "cuda" and getattr(cls._tls, "device_rng", cls.DEVICE_RNG):
             return fill(torch.empty(shape, device=device))
         if device.type != "cuda":
             return fill(torch.empty(shape)).to(device)
@@ -710,6 +714,15 @@ class Trainer:
             env = os.environ.get("STYLEX_DEVICE_RNG")
             device_rng = (env == "1") if env is not None else (bool(is_ddp) and torch.cuda.is_available())
         self.device_rng = bool(device_rng)
+        # Draw-ahead (round 4): the CPU-generator draws of a phase (latents, the image-noise planes: ~14 ms of host time
+        # per call at 256 px) run on ONE worker thread while the main thread enqueues the previous phase's kernels —
+        # the draws of a train() call never depend on its compute, and a single worker issues them in exactly the
+        # reference's order (every golden step test runs with it).  1 = within a call (the generator phase's draws
+        # under the discriminator phase), 2 = also the next call's discriminator-phase draws under this call's
+        # generator phase (skipped when this call ends with evaluate / save / FID, which draw from the same
+        # generators), 0 = off.  Off with device RNG, augmentation (AugWrapper draws inside the compute) and graphs.
+        self._draw_mode = int(os.environ.get("STYLEX_DRAW_AHEAD", "2" if self.device.type == "cuda" else "0"))
+        self._draw_worker, self._next_d = None, None
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
         if classifier is not None:
@@ -1137,6 +1150,35 @@ class Trainer:
             total_all.register_hook(raise_if_nan)  # reference :1352, :1432 (opt-in: it synchronises the host)
         total_all.backward()
 
+    # -- draw-ahead worker -------------------------------------------------------------------------------------
+
+    def _draw_submit(self, fn):
+        if self._draw_worker is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            def init(device):
+                if device.type == "cuda":
+                    torch.cuda.set_device(device)
+                _Staging._tls.device_rng = False
+
+            self._draw_worker = ThreadPoolExecutor(1, thread_name_prefix="stylex-draw", initializer=init,
+                                                   initargs=(self.device,))
+        return self._draw_worker.submit(fn)
+
+    def _drain_draw_ahead(self):
+        """Wait for (and keep) a prefetched discriminator-phase draw: called before anything else draws from the loader
+        or the CPU generators (evaluate, generate_truncated, calculate_fid ...)."""
+        nd = getattr(self, "_next_d", None)
+        if nd is not None:
+            nd[0].exception()  # waits; an exception resurfaces when the next train() call takes the result
+
+    def _step_ends_with_draws(self):
+        """Does THIS train() call end with evaluate / save / FID (which consume loader batches and generator draws)?"""
+        s = self.steps
+        if s % self.save_every == 0 or s % self.evaluate_every == 0 or (s % 100 == 0 and s < 2500):
+            return True
+        return exists(self.calculate_fid_every) and s % self.calculate_fid_every == 0 and s != 0
+
     def _new_acc(self):
         acc = {k: torch.zeros((), device=self.device) for k in ("d", "g", "rec", "kl")}
         acc["gp"], acc["pl"] = None, self.pl_mean
@@ -1203,8 +1245,28 @@ class Trainer:
             has_gp = apply_gp
         else:
             acc = self._new_acc()
+            ahead = self._draw_mode if (fuse and not self.device_rng) else 0
+            d_in = g_fut = None
+            if ahead:
+                sig = (gae, self.batch_size, self.world_size, self.alternating_training, self.new_architecture,
+                       m.G.image_size, self.transparent)
+                if self._next_d is not None:  # drawn under the previous call's generator phase
+                    (fut, fsig), self._next_d = self._next_d, None
+                    res = fut.result()
+                    if fsig == sig:
+                        d_in, st = res
+                if d_in is None:
+                    d_in = self._draw_d(groups[0], st, True)
+                st_g = dict(st)
+
+                def draw_g():
+                    if self.alternating_training:
+                        st_g["encoder_input"] = False
+                    return self._draw_g(groups[0], st_g, True, apply_pl)
+
+                g_fut = self._draw_submit(draw_g)  # the generator phase's inputs, under the discriminator phase
             # ---------------- discriminator phase ----------------
-            self._d_phase(groups, None, apply_gp, gae, fuse, acc, st)
+            self._d_phase(groups, [d_in] if ahead else None, apply_gp, gae, fuse, acc, st)
             if self.is_ddp:
                 self._d_sync.all_reduce()
             self._resolve_losses()  # previous step's scalars: its copy finished long ago, the GPU keeps running
@@ -1212,7 +1274,14 @@ class Trainer:
             # ---------------- generator phase ----------------
             if self.alternating_training:
                 st["encoder_input"] = False
-            self._g_phase(groups, None, apply_pl, gae, fuse, acc, st)
+            g_in = None
+            if ahead:
+                g_in = [g_fut.result()]
+                if ahead > 1 and not self._step_ends_with_draws():
+                    st_n = {"encoder_input": False, "latents_fn": None}
+                    grp = list(groups[0])
+                    self._next_d = (self._draw_submit(lambda: (self._draw_d(grp, st_n, True), st_n)), sig)
+            self._g_phase(groups, g_in, apply_pl, gae, fuse, acc, st)
             if self.is_ddp:
                 self._g_sync.all_reduce()
             self._opt_step(m.G_opt)

@@ -488,3 +488,28 @@ def test_resnet_wrapper_vs_reference_golden_cpu(tmp_path):
         close(logits, out, 1e-5)
         got, = torch.autograd.grad((out * coef).sum(), x)
         close(gx, got, 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("tag", ["gae2_alt", "gae2_pl", "gae1_alt"])
+def test_draw_ahead_worker_keeps_the_reference_draw_order(tag, mode, tmp_path, monkeypatch):
+    """Round 4: the CPU-generator draws of a phase run on a worker thread under the previous phase's kernel enqueue
+    (Trainer._draw_mode, the GPU default).  The random streams (loader, Python random(), torch's CPU generator) must be
+    consumed in exactly the reference's order: the step goldens captured from the reference hold with the worker on —
+    within a call (mode 1) and across calls (mode 2: the next call's discriminator-phase draws are prefetched)."""
+    monkeypatch.setenv("STYLEX_DRAW_AHEAD", mode)
+    g = load_golden("steps_" + tag)
+    tr, n = make_trainer(g, tmp_path)
+    assert tr._draw_mode == int(mode)
+    rows = []
+    for k in range(n):
+        rows.append(run_steps(tr, 1)[0])
+        if mode == "2" and k + 1 < n:
+            done = tr.steps - 1  # a call at step 0 (or any step that evaluates / saves) ends with draws: no prefetch there
+            ends_with_draws = done % 100 == 0 and done < 2500
+            assert (tr._next_d is None) == ends_with_draws, "prefetch of the next call's discriminator-phase draws"
+            tr._drain_draw_ahead()
+    gold = g["scalars"]
+    np.testing.assert_allclose(np.array(rows)[0], gold[0], rtol=5e-5, atol=5e-6, equal_nan=True)
+    np.testing.assert_allclose(np.array(rows), gold, rtol=1e-3, atol=1e-3, equal_nan=True)
+    assert tr._draw_worker is not None
