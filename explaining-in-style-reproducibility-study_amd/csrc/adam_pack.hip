@@ -63,6 +63,21 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const stylex_adam_tensor
     }
     if (d.N == 0) {  // flat tensor
         const int64_t e0 = (int64_t)local * SLAB_ELEMS;
+        if (e0 + SLAB_ELEMS <= d.numel && (((uintptr_t)d.p | (uintptr_t)d.g | (uintptr_t)d.m | (uintptr_t)d.v) & 15) == 0) {
+            for (int e = tid * 4; e < SLAB_ELEMS; e += 1024) {
+                const int64_t i = e0 + e;
+                float4 p4 = *reinterpret_cast<const float4*>(d.p + i), g4 = *reinterpret_cast<const float4*>(d.g + i);
+                float4 m4 = *reinterpret_cast<const float4*>(d.m + i), v4 = *reinterpret_cast<const float4*>(d.v + i);
+                p4.x = adam_update(p4.x, g4.x, m4.x, v4.x, k);
+                p4.y = adam_update(p4.y, g4.y, m4.y, v4.y, k);
+                p4.z = adam_update(p4.z, g4.z, m4.z, v4.z, k);
+                p4.w = adam_update(p4.w, g4.w, m4.w, v4.w, k);
+                *reinterpret_cast<float4*>(d.p + i) = p4;
+                *reinterpret_cast<float4*>(d.m + i) = m4;
+                *reinterpret_cast<float4*>(d.v + i) = v4;
+            }
+            return;
+        }
         for (int e = tid; e < SLAB_ELEMS; e += 256) {
             const int64_t i = e0 + e;
             if (i >= d.numel) break;
@@ -78,66 +93,120 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const stylex_adam_tensor
     const int n0 = (local / ncs) * SLAB_N, c0 = (local % ncs) * SLAB_C;
     const int nn = min(SLAB_N, N - n0), cw = min(SLAB_C, C - c0);
     const int row = cw * T;  // contiguous run of one output channel inside the slab
-    for (int e = tid; e < nn * row; e += 256) {
-        const int nl = e / row, r = e - nl * row;
-        const int64_t i = ((int64_t)(n0 + nl) * C + c0) * T + r;
-        float m = d.m[i], v = d.v[i];
-        const float w = adam_update(d.p[i], d.g[i], m, v, k);
-        d.p[i] = w;
-        d.m[i] = m;
-        d.v[i] = v;
-        sw[nl * (SLAB_C * MAX_T) + r] = w;  // r = c_local * T + t
+    if ((row & 3) == 0 && ((C * T) & 3) == 0) {  // 16-byte accesses (every slab of the step's conv weights)
+        const int row4 = row >> 2;
+        for (int e = tid; e < nn * row4; e += 256) {
+            const int nl = e / row4, r = (e - nl * row4) << 2;
+            const int64_t i = ((int64_t)(n0 + nl) * C + c0) * T + r;
+            float4 p4 = *reinterpret_cast<const float4*>(d.p + i), g4 = *reinterpret_cast<const float4*>(d.g + i);
+            float4 m4 = *reinterpret_cast<const float4*>(d.m + i), v4 = *reinterpret_cast<const float4*>(d.v + i);
+            p4.x = adam_update(p4.x, g4.x, m4.x, v4.x, k);
+            p4.y = adam_update(p4.y, g4.y, m4.y, v4.y, k);
+            p4.z = adam_update(p4.z, g4.z, m4.z, v4.z, k);
+            p4.w = adam_update(p4.w, g4.w, m4.w, v4.w, k);
+            *reinterpret_cast<float4*>(d.p + i) = p4;
+            *reinterpret_cast<float4*>(d.m + i) = m4;
+            *reinterpret_cast<float4*>(d.v + i) = v4;
+            *reinterpret_cast<float4*>(sw + nl * (SLAB_C * MAX_T) + r) = p4;
+        }
+    } else {
+        for (int e = tid; e < nn * row; e += 256) {
+            const int nl = e / row, r = e - nl * row;
+            const int64_t i = ((int64_t)(n0 + nl) * C + c0) * T + r;
+            float m = d.m[i], v = d.v[i];
+            const float w = adam_update(d.p[i], d.g[i], m, v, k);
+            d.p[i] = w;
+            d.m[i] = m;
+            d.v[i] = v;
+            sw[nl * (SLAB_C * MAX_T) + r] = w;  // r = c_local * T + t
+        }
     }
     if (d.nvar == 0) return;
     __syncthreads();
+    const bool full_n = nn == SLAB_N && (N & 7) == 0;  // the transposed layouts take 8 output channels = 16 bytes per store
+    const bool even_c = (cw & 1) == 0 && (C & 1) == 0;  // the forward layouts take 2 input channels = 4 bytes per store
+    auto ldw = [&](int nl, int cl, int t) { return sw[nl * (SLAB_C * MAX_T) + cl * T + t]; };
+    auto s2d_val = [&](int nl, int cl, int s, int t2, float sc) {
+        const int sy = s >> 1, sx = s & 1, kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
+        if (kh2 < 2 && kw2 < 2 && (kh2 == 1 || sy == 1) && (kw2 == 1 || sx == 1)) {
+            const int kh = kh2 == 0 ? 0 : 1 + sy, kw = kw2 == 0 ? 0 : 1 + sx;
+            return sc * sw[nl * (SLAB_C * MAX_T) + cl * 9 + kh * 3 + kw];
+        }
+        return 0.f;
+    };
     for (int vi = 0; vi < d.nvar; ++vi) {
         const int kind = d.var[vi].kind;
         const float sc = d.var[vi].scale;
         if (kind == STYLEX_ADAM_COPY_PACK) {  // [N][T][C] and / or [C][T][N], bf16
             unsigned short* wf = (unsigned short*)d.var[vi].a;
             unsigned short* wb = (unsigned short*)d.var[vi].b;
-            if (wf)
+            if (wf && even_c) {
+                const int ch = cw >> 1;
+                for (int e = tid; e < nn * T * ch; e += 256) {
+                    const int cl = (e % ch) << 1, t = (e / ch) % T, nl = e / (ch * T);
+                    const unsigned v = (unsigned)bf16_rne(sc * ldw(nl, cl, t)) | ((unsigned)bf16_rne(sc * ldw(nl, cl + 1, t)) << 16);
+                    *reinterpret_cast<unsigned*>(wf + ((int64_t)(n0 + nl) * T + t) * C + c0 + cl) = v;
+                }
+            } else if (wf) {
                 for (int e = tid; e < nn * T * cw; e += 256) {
                     const int cl = e % cw, t = (e / cw) % T, nl = e / (cw * T);
-                    wf[((int64_t)(n0 + nl) * T + t) * C + c0 + cl] = bf16_rne(sc * sw[nl * (SLAB_C * MAX_T) + cl * T + t]);
+                    wf[((int64_t)(n0 + nl) * T + t) * C + c0 + cl] = bf16_rne(sc * ldw(nl, cl, t));
                 }
-            if (wb)
+            }
+            if (wb && full_n) {
+                for (int e = tid; e < T * cw; e += 256) {
+                    const int t = e % T, cl = e / T;
+                    unsigned q[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        q[h] = (unsigned)bf16_rne(sc * ldw(2 * h, cl, t)) | ((unsigned)bf16_rne(sc * ldw(2 * h + 1, cl, t)) << 16);
+                    *reinterpret_cast<uint4*>(wb + ((int64_t)(c0 + cl) * T + t) * N + n0) = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            } else if (wb) {
                 for (int e = tid; e < nn * T * cw; e += 256) {
                     const int nl = e % nn, t = (e / nn) % T, cl = e / (nn * T);
-                    wb[((int64_t)(c0 + cl) * T + t) * N + n0 + nl] = bf16_rne(sc * sw[nl * (SLAB_C * MAX_T) + cl * T + t]);
+                    wb[((int64_t)(c0 + cl) * T + t) * N + n0 + nl] = bf16_rne(sc * ldw(nl, cl, t));
                 }
+            }
         } else if (kind == STYLEX_ADAM_COPY_PACK_S2D) {  // space-to-depth form of a 3x3 / stride-2 conv (see pack_weight_s2d_kernel)
             unsigned short* wf = (unsigned short*)d.var[vi].a;
             unsigned short* wb = (unsigned short*)d.var[vi].b;
             const int C4 = 4 * C;
-            for (int e = tid; e < nn * 36 * cw; e += 256) {
-                const int cl = e % cw, s = (e / cw) & 3, t2 = (e / (cw * 4)) % 9, nl = e / (cw * 36);
-                const int sy = s >> 1, sx = s & 1, kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
-                float v = 0.f;
-                if (kh2 < 2 && kw2 < 2 && (kh2 == 1 || sy == 1) && (kw2 == 1 || sx == 1)) {
-                    const int kh = kh2 == 0 ? 0 : 1 + sy, kw = kw2 == 0 ? 0 : 1 + sx;
-                    v = sc * sw[nl * (SLAB_C * MAX_T) + cl * 9 + kh * 3 + kw];
+            if (wf && even_c) {
+                const int ch = cw >> 1;
+                for (int e = tid; e < nn * 36 * ch; e += 256) {
+                    const int cl = (e % ch) << 1, s = (e / ch) & 3, t2 = (e / (ch * 4)) % 9, nl = e / (ch * 36);
+                    const unsigned v = (unsigned)bf16_rne(s2d_val(nl, cl, s, t2, sc)) | ((unsigned)bf16_rne(s2d_val(nl, cl + 1, s, t2, sc)) << 16);
+                    *reinterpret_cast<unsigned*>(wf + ((int64_t)(n0 + nl) * 9 + t2) * C4 + s * C + c0 + cl) = v;
                 }
-                if (wf) wf[((int64_t)(n0 + nl) * 9 + t2) * C4 + s * C + c0 + cl] = bf16_rne(v);
+            } else if (wf) {
+                for (int e = tid; e < nn * 36 * cw; e += 256) {
+                    const int cl = e % cw, s = (e / cw) & 3, t2 = (e / (cw * 4)) % 9, nl = e / (cw * 36);
+                    wf[((int64_t)(n0 + nl) * 9 + t2) * C4 + s * C + c0 + cl] = bf16_rne(s2d_val(nl, cl, s, t2, sc));
+                }
             }
-            if (wb)
+            if (wb && full_n) {
+                for (int e = tid; e < 36 * cw; e += 256) {
+                    const int t2 = e % 9, s = (e / 9) & 3, cl = e / 36;
+                    unsigned q[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        q[h] = (unsigned)bf16_rne(s2d_val(2 * h, cl, s, t2, sc)) | ((unsigned)bf16_rne(s2d_val(2 * h + 1, cl, s, t2, sc)) << 16);
+                    *reinterpret_cast<uint4*>(wb + ((int64_t)(s * C + c0 + cl) * 9 + t2) * N + n0) = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            } else if (wb) {
                 for (int e = tid; e < nn * 36 * cw; e += 256) {
                     const int nl = e % nn, t2 = (e / nn) % 9, s = (e / (nn * 9)) & 3, cl = e / (nn * 36);
-                    const int sy = s >> 1, sx = s & 1, kh2 = t2 / 3, kw2 = t2 - kh2 * 3;
-                    float v = 0.f;
-                    if (kh2 < 2 && kw2 < 2 && (kh2 == 1 || sy == 1) && (kw2 == 1 || sx == 1)) {
-                        const int kh = kh2 == 0 ? 0 : 1 + sy, kw = kw2 == 0 ? 0 : 1 + sx;
-                        v = sc * sw[nl * (SLAB_C * MAX_T) + cl * 9 + kh * 3 + kw];
-                    }
-                    wb[((int64_t)(s * C + c0 + cl) * 9 + t2) * N + n0 + nl] = bf16_rne(v);
+                    wb[((int64_t)(s * C + c0 + cl) * 9 + t2) * N + n0 + nl] = bf16_rne(s2d_val(nl, cl, s, t2, sc));
                 }
+            }
         } else if (kind == STYLEX_ADAM_COPY_SUMSQ) {  // wsq[n][c] = sum over the taps of w^2 (fp32)
             float* q = (float*)d.var[vi].a;
             for (int e = tid; e < nn * cw; e += 256) {
                 const int cl = e % cw, nl = e / cw;
                 float acc = 0.f;
                 for (int t = 0; t < T; ++t) {
-                    const float w = sw[nl * (SLAB_C * MAX_T) + cl * T + t];
+                    const float w = ldw(nl, cl, t);
                     acc += w * w;
                 }
                 q[(int64_t)(n0 + nl) * C + c0 + cl] = acc;

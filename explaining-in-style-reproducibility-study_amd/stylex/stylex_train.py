@@ -717,11 +717,13 @@ class Trainer:
         # Draw-ahead (round 4): the CPU-generator draws of a phase (latents, the image-noise planes: ~14 ms of host time
         # per call at 256 px) run on ONE worker thread while the main thread enqueues the previous phase's kernels —
         # the draws of a train() call never depend on its compute, and a single worker issues them in exactly the
-        # reference's order (every golden step test runs with it).  1 = within a call (the generator phase's draws
-        # under the discriminator phase), 2 = also the next call's discriminator-phase draws under this call's
-        # generator phase (skipped when this call ends with evaluate / save / FID, which draw from the same
-        # generators), 0 = off.  Off with device RNG, augmentation (AugWrapper draws inside the compute) and graphs.
-        self._draw_mode = int(os.environ.get("STYLEX_DRAW_AHEAD", "2" if self.device.type == "cuda" else "0"))
+        # reference's order (every golden step test runs with it).  1 (GPU default) = within a call: the generator
+        # phase's draws under the discriminator phase; 2 (opt-in) = also the next call's discriminator-phase draws under
+        # this call's generator phase (skipped when this call ends with evaluate / save / FID) — that changes what a
+        # CALLER's own draws between two train() calls see (the evaluation-surface golden, which calls evaluate()
+        # between steps, fails with it), so it is not a default; 0 = off.  Off with device RNG, augmentation
+        # (AugWrapper draws inside the compute) and graphs.
+        self._draw_mode = int(os.environ.get("STYLEX_DRAW_AHEAD", "1" if self.device.type == "cuda" else "0"))
         self._draw_worker, self._next_d = None, None
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes

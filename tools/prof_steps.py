@@ -17,7 +17,7 @@ with gzip.open(path, "rt") as f:
         names[int(k)] = nm
     rows = sorted(tuple(int(v) for v in line.split(",")) for line in f)
 rows.sort(key=lambda r: r[1])
-adam = [k for k, nm in names.items() if "FusedOptimizerTensorListMetadata" in nm]  # the fused Adam only (other multi-tensor ops exist)
+adam = [k for k, nm in names.items() if ("FusedOptimizerTensorListMetadata" in nm or "adam_pack_kernel" in nm)]  # the fused Adam only (other multi-tensor ops exist)
 ad = [r for r in rows if r[0] in adam]
 # groups of Adam launches separated by > 5 ms: one group per optimiser step (D, G, D, G, ...)
 groups, cur = [], [ad[0]]
