@@ -39,10 +39,14 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
     // torch/ATen fused_adam_utils.cuh (ADAM_MODE::ORIGINAL, no amsgrad / weight decay / maximize):
     //   exp_avg = beta1 * exp_avg + (1 - beta1) * grad;  exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad * grad
     //   denom = sqrt(exp_avg_sq) / sqrt(bias_correction2) + eps;  param -= lr / bias_correction1 * exp_avg / denom
-    m = k.beta1 * m + (1.f - k.beta1) * g;
-    v = k.beta2 * v + (1.f - k.beta2) * g * g;
-    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
-    return p - k.step_size * m / denom;
+    // Explicitly rounded operations: with the compiler free to contract a * b + c into an FMA, the 16-byte and the
+    // scalar code paths of the kernel rounded differently in the last place — and a data-parallel run (gradients are
+    // 4-byte-aligned views of the flat buckets) stopped being bit-identical to a single-GPU run (separately allocated
+    // gradients), which tests/test_hip_parity.py::test_gradsync_on_one_rank_rccl_is_bit_identical_to_single_gpu caught.
+    m = __fmaf_rn(k.beta1, m, __fmul_rn(1.f - k.beta1, g));
+    v = __fmaf_rn(k.beta2, v, __fmul_rn(__fmul_rn(1.f - k.beta2, g), g));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), k.bc2_sqrt), k.eps);
+    return __fsub_rn(p, __fdiv_rn(__fmul_rn(k.step_size, m), denom));
 }
 
 __global__ __launch_bounds__(256) void adam_pack_kernel(const stylex_adam_tensor* __restrict__ descs,
