@@ -155,3 +155,124 @@ def find_significant_styles(style_change_effect, num_indices, class_index, max_i
         images_effect += direction[:, nxt]
         direction[:, nxt] = 0
     return [(x // n_coords, (x % n_coords) + sindex_offset) for x in chosen]
+
+
+# ---- post-processing and visualisation cells of the notebook (cells 11, 12, 14, 17-21) ------------------------------
+
+
+def filter_unstable_images(style_change_effect, effect_threshold=0.3, num_indices_threshold=150):
+    """Cell 11: zero the effects of images on which more than `num_indices_threshold` coordinates move the classifier by
+    more than `effect_threshold` (in place, like the notebook)."""
+    unstable = np.sum(np.abs(style_change_effect) > effect_threshold, axis=(1, 2, 3)) > num_indices_threshold
+    style_change_effect[unstable] = 0
+    return style_change_effect
+
+
+def style_vector_distances(all_style_vectors, style_min, style_max):
+    """Cell 12 (tail): [images, coords, 2] = distance of every style coordinate to the minimum / to the maximum."""
+    d = np.zeros((all_style_vectors.shape[0], all_style_vectors.shape[1], 2))
+    d[:, :, 0] = all_style_vectors - style_min[None]
+    d[:, :, 1] = style_max[None] - all_style_vectors
+    return d
+
+
+def split_by_class(base_probs, style_change_effect, W_values, all_style_vectors_distances, all_style_vectors):
+    """Cell 14: the sweep's arrays split by the class the classifier assigns to the generated image."""
+    labels = np.argmax(base_probs, axis=1)
+    out = {}
+    for c in range(2):
+        idx = np.nonzero(labels == c)[0]
+        out[c] = dict(effect=style_change_effect[idx].astype(np.float64), w=W_values[idx].astype(np.float64),
+                      dist=all_style_vectors_distances[idx], style_vectors=all_style_vectors[idx], index=idx)
+    return out
+
+
+def _block_of(G, sindex):
+    base = 0
+    for k, block in enumerate(G.blocks):
+        if sindex < base + block.num_style_coords:
+            return k, sindex - base
+        base += block.num_style_coords
+    raise IndexError(sindex)
+
+
+@torch.no_grad()
+def change_images(G, classifier, dlatents, sindex, style_direction_index, s_style_min, s_style_max, shift_size, noise,
+                  class_index=0):
+    """Cells 17 + 19 for a BATCH of latents: the generated image of every latent, the image with style coordinate
+    `sindex` moved towards its minimum (direction 0) or maximum (1) by `shift_size` times the distance, and the
+    classifier's probability of `class_index` for both.  The notebook mutates ``to_style{1,2}.bias`` and runs the
+    generator twice per image; here the shift is a per-sample offset on the block's style vector and all latents run
+    as one pass.  Returns (base [n,3,S,S], changed [n,3,S,S], base_prob [n], change_prob [n])."""
+    dev = next(G.parameters()).device
+    w = torch.as_tensor(np.asarray(dlatents), dtype=torch.float32, device=dev)
+    n = w.shape[0]
+    noise = torch.as_tensor(noise).to(dev).expand(n, -1, -1, -1)
+    k, widx = _block_of(G, int(sindex))
+    base_img, coords = G(styles_def_to_tensor([(w, G.num_layers)]), noise, get_style_coords=True)
+    target = float(s_style_min) if style_direction_index == 0 else float(s_style_max)
+    delta = (target - coords[:, int(sindex)]) * shift_size
+    x = G.initial_conv(G.initial_block.expand(n, -1, -1, -1))
+    rgb = None
+    for li, block in enumerate(G.blocks):
+        styles = None
+        if li == k:
+            s1, s2 = block.to_style1(w), block.to_style2(w)
+            if widx < block.input_channels:
+                s1 = s1.clone()
+                s1[:, widx] += delta
+            else:
+                s2 = s2.clone()
+                s2[:, widx - block.input_channels] += delta
+            styles = (s1, s2)
+        x, _ = block.forward_main(x, w, noise, styles=styles)
+        rgb = block.to_rgb(x, rgb, w)
+    changed = rgb.float()
+    base_img = base_img.float()
+    p0 = torch.softmax(classifier.classify_images(base_img), dim=1)[:, class_index]
+    p1 = torch.softmax(classifier.classify_images(changed), dim=1)[:, class_index]
+    return base_img, changed, p0.cpu().numpy(), p1.cpu().numpy()
+
+
+def pair_image(base, changed):
+    """Cells 18 + 19: [S, 2S, 3] uint8, generated image left, changed image right (``draw_on_image``: clip to [0, 1],
+    times 255, truncated to bytes; the probability text the notebook once drew is commented out there)."""
+    def u8(img):
+        return (np.clip(np.transpose(img.detach().cpu().numpy(), (1, 2, 0)), 0, 1) * 255).astype(np.uint8)
+    return np.concatenate((u8(base), u8(changed)), axis=1)
+
+
+def visualize_style(G, classifier, all_dlatents, style_change_effect, style_min, style_max, sindex, style_direction_index,
+                    max_images, shift_size, noise, class_index=0, effect_threshold=0.3, seed=None,
+                    allow_both_directions_change=False):
+    """Cell 20: images on which moving coordinate `sindex` in direction `style_direction_index` changed the
+    classifier's `class_index` output by more than `effect_threshold` in the sweep, shuffled (numpy global generator,
+    seeded like the notebook), up to 10 x `max_images` candidates re-generated, those whose probability moves by at
+    least `effect_threshold` kept, the first `max_images` stacked vertically; an empty array if fewer than three."""
+    eff = style_change_effect[:, style_direction_index, sindex, class_index]
+    idx = (np.abs(eff) > effect_threshold).nonzero()[0] if allow_both_directions_change else (eff > effect_threshold).nonzero()[0]
+    if idx.size == 0:
+        return np.array([])
+    if seed is not None:
+        np.random.seed(seed)
+    np.random.shuffle(idx)
+    idx = idx[:min(max_images * 10, len(idx))]
+    base, changed, p0, p1 = change_images(G, classifier, np.asarray(all_dlatents)[idx], sindex, style_direction_index,
+                                          style_min[sindex], style_max[sindex], shift_size, noise, class_index)
+    rows = [pair_image(base[i], changed[i]) for i in range(len(idx)) if not np.abs(p1[i] - p0[i]) < effect_threshold]
+    rows = rows[:max_images]
+    return np.concatenate(rows, axis=0) if len(rows) >= 3 else np.array([])
+
+
+def visualize_style_by_distance_in_s(G, classifier, all_dlatents, all_style_vectors_distances, style_min, style_max, sindex,
+                                     style_sign_index, max_images, shift_size, noise, class_index=0):
+    """Cell 21: the images whose coordinate `sindex` is farthest from the end it is moved to (largest distance first),
+    base | changed pairs of the first `max_images`; an empty array if fewer than three."""
+    idx = np.argsort(all_style_vectors_distances[:, sindex, style_sign_index])[::-1]
+    if idx.size == 0:
+        return np.array([])
+    idx = idx[:min(max_images * 10, len(idx))]
+    base, changed, _, _ = change_images(G, classifier, np.asarray(all_dlatents)[idx], sindex, style_sign_index,
+                                        style_min[sindex], style_max[sindex], shift_size, noise, class_index)
+    rows = [pair_image(base[i], changed[i]) for i in range(len(idx))]
+    return np.concatenate(rows[:max_images], axis=0) if len(rows) >= 3 else np.array([])

@@ -113,3 +113,74 @@ def test_find_significant_styles_vs_notebook_golden():
         for thr in (0.2, 0.05):
             got = attfind.find_significant_styles(g["out/style_change"], 6, cls, max_image_effect=thr)
             assert np.array_equal(np.array(got, dtype=np.int64), sel["sel/c%d_t%g" % (cls, thr)]), (cls, thr, got)
+
+
+VGOLD = os.path.join(ROOT, "tests", "golden", "attfind_visualize_64.npz")
+
+
+def build_visualize(g, device="cpu"):
+    size, cap, fmax = (int(v) for v in g["config"])
+    torch.manual_seed(int(g["model_seed"]))
+    np.random.seed(int(g["model_seed"]))
+    import random
+
+    random.seed(int(g["model_seed"]))
+    m = st.StylEx(size, network_capacity=cap, fmap_max=fmax, rank=0 if device != "cpu" else None)
+    m.eval()
+    flat, off = torch.from_numpy(g["noise_weights"]), 0
+    for blk in m.G.blocks:
+        for lin in (blk.to_noise1, blk.to_noise2):
+            for t in (lin.weight, lin.bias):
+                t.data = flat[off:off + t.numel()].view_as(t).clone().to(t.device)
+                off += t.numel()
+    clf = TinyClassifier(seed=99, image_size=size)
+    clf.b2 = torch.from_numpy(g["cls_b2"]).clone()
+    clf = clf.to(device)
+    return m, clf, torch.from_numpy(g["input_noise"]).to(device)
+
+
+FLIP_FRACTION = [2e-3]
+
+
+def close_u8(got, want, what):
+    """uint8 images produced by truncating x * 255: a last-place difference of x flips a byte where x * 255 sits on an
+    integer — at most one level, on a handful of pixels."""
+    assert got.shape == want.shape and got.dtype == np.uint8, (what, got.shape, want.shape)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() <= FLIP_FRACTION[0], (what, int(d.max()), float((d > 0).mean()))
+
+
+def check_visualize(m, clf, noise, g, prob_tol):
+    effect, w_values = g["out/style_change"], g["out/latents"]
+    coords, smin, smax = g["out/style_coordinates"], np.squeeze(g["out/minima"]), np.squeeze(g["out/maxima"])
+    dist_s = attfind.style_vector_distances(coords, smin, smax)
+    np.testing.assert_array_equal(dist_s, g["dist"])
+    split = attfind.split_by_class(g["out/base_prob"], effect, w_values, dist_s, coords)
+    for c in (0, 1):
+        np.testing.assert_array_equal(split[c]["effect"], g["class%d/effect" % c])
+        np.testing.assert_array_equal(split[c]["w"], g["class%d/w" % c])
+        np.testing.assert_array_equal(split[c]["dist"], g["class%d/dist" % c])
+    np.testing.assert_array_equal(attfind.filter_unstable_images(effect.copy(), 0.05, 20), g["filtered"])
+    direction, sindex = (int(v) for v in g["pick"])
+    shift = int(g["shift_size"])
+    base, changed, p0, p1 = attfind.change_images(m.G, clf, w_values, sindex, direction, smin[sindex], smax[sindex], shift,
+                                                  noise, class_index=0)
+    np.testing.assert_allclose(np.stack((p0, p1), axis=1), g["probs"], rtol=prob_tol, atol=prob_tol)
+    for i in range(w_values.shape[0]):
+        close_u8(attfind.pair_image(base[i], changed[i]), g["pair_%d" % i], "pair %d" % i)
+    yy = attfind.visualize_style(m.G, clf, w_values, effect, smin, smax, sindex, direction, max_images=3, shift_size=shift,
+                                 noise=noise, class_index=0, effect_threshold=1e-6, seed=int(g["seed"]))
+    close_u8(yy, g["visualize_style"], "visualize_style")
+    zz = attfind.visualize_style_by_distance_in_s(m.G, clf, w_values, dist_s, smin, smax, sindex, direction, max_images=3,
+                                                  shift_size=shift, noise=noise, class_index=0)
+    close_u8(zz, g["visualize_by_distance"], "visualize_style_by_distance_in_s")
+
+
+def test_visualisation_cells_vs_reference_notebook_golden(cpu_double):
+    """N1, the notebook's post-processing and visualisation cells (11, 12, 14, 17-21), batched: against arrays produced
+    by EXECUTING those cells on the reference's StylEx (tests/golden/attfind_visualize_64.npz; 64 px because the
+    notebook's canvas size is hard-wired) — the class split and distances exactly, the probabilities to 1e-4, the
+    base | changed image strips byte for byte up to one level on <= 0.2 % of the pixels."""
+    g = np.load(VGOLD)
+    m, clf, noise = build_visualize(g)
+    check_visualize(m, clf, noise, g, 1e-4)

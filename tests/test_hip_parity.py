@@ -1870,3 +1870,19 @@ def test_adam_pack_step_matches_torch_fused_adam_and_the_pack_kernels():
                     assert torch.equal(g_.view(-1), w_.view(-1)), (kind, sc, tuple(p.shape), "copy differs from a fresh pack")
         assert torch.equal(hb.pack_weight(frozen, True, True, hb.BF16_ACT)[0], frozen_pack)
     hb.pack_cache_clear()
+
+
+def test_attfind_visualisation_cells_on_hip():
+    """N1: the notebook's visualisation cells (batched: attfind.change_images / visualize_style /
+    visualize_style_by_distance_in_s) on the HIP kernels against the arrays the reference notebook's own cells produced
+    (tests/golden/attfind_visualize_64.npz)."""
+    import test_attfind_cpu as ta
+
+    g = np.load(ta.VGOLD)
+    m, clf, noise = ta.build_visualize(g, device=DEV)
+    prev = ta.FLIP_FRACTION[0]
+    ta.FLIP_FRACTION[0] = 1e-2  # fp32 MFMA summation order vs the CPU's: a few more bytes sit on a truncation boundary
+    try:
+        ta.check_visualize(m, clf, noise, g, 1e-3)
+    finally:
+        ta.FLIP_FRACTION[0] = prev
