@@ -1886,3 +1886,87 @@ def test_attfind_visualisation_cells_on_hip():
         ta.check_visualize(m, clf, noise, g, 1e-3)
     finally:
         ta.FLIP_FRACTION[0] = prev
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-5), ("bf16", 4e-2)])
+def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
+    """VERDICT r3 weak point 2 (the full-size bf16 band is HIP-bf16 against HIP-fp32: a bug common to both modes at
+    >= 128 px could only be caught by the adjoint identities): the blocks whose kernels exist ONLY at full resolution —
+    DiscriminatorBlock 0 and 1 of the 256 px model (padded-RGB first layer, pipelined LDS-DMA convs, activation bit
+    masks, blur + space-to-depth stride-2 conv with the residual merge, even-pixel gather / add) and GeneratorBlock 6
+    (64 -> 32 @256^2: bilinear x2, modulated convs with the transposed noise plane, to-RGB) — against the independent
+    CPU oracle modules (oracle/stylex_oracle.py, the restatement pinned to the reference goldens) at batch 2: outputs,
+    input gradients and every parameter gradient, fp32 to 5e-5 of the tensor's scale, bf16 inside the bf16 band."""
+    import networks
+
+    ops.set_precision(prec)
+    hb.pack_cache_clear()
+    torch.manual_seed(11)
+
+    def rel(a, b):
+        b = b.detach().double().cpu()
+        return float((a.detach().double().cpu() - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+    def same_weights(hip_mod, cpu_mod):
+        sd = {k: v.clone() for k, v in cpu_mod.state_dict().items()}
+        missing = hip_mod.load_state_dict(sd, strict=False)
+        assert not [k for k in missing.missing_keys if "blur" not in k and not k.endswith(".f")], missing
+        return hip_mod.to(DEV)
+
+    try:
+        # ---- discriminator blocks 0 (3 -> 64 @256^2) and 1 (64 -> 128 @128^2)
+        for cin, cout, size in ((3, 64, 256), (64, 128, 128)):
+            ref = so.ODiscriminatorBlock(cin, cout, downsample=True)
+            blk = same_weights(networks.DiscriminatorBlock(cin, cout, downsample=True), ref)
+            x = torch.rand(2, cin, size, size) * 2 - 1
+            gy = torch.randn(2, cout, size // 2, size // 2)
+            xr = x.clone().requires_grad_(True)
+            yr = ref(xr)
+            yr.backward(gy)
+            xh = x.to(DEV).requires_grad_(True)
+            ops.set_fast(True)
+            try:
+                yh = blk(xh)
+                yh.float().backward(gy.to(DEV))
+            finally:
+                ops.set_fast(False)
+            errs = {"y": rel(yh, yr), "gx": rel(xh.grad, xr.grad)}
+            ref_grads = dict(ref.named_parameters())
+            for n_, p_ in blk.named_parameters():
+                errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
+            bad = {k: v for k, v in errs.items() if v > tol}
+            assert not bad, ("DiscriminatorBlock %d->%d @%d" % (cin, cout, size), prec, bad)
+        # ---- generator block 6 (64 -> 32, upsample 128 -> 256, last block: no rgb upsample)
+        ref = so.OGeneratorBlock(514, 64, 32, upsample=True, upsample_rgb=False)
+        with torch.no_grad():
+            for lin in (ref.to_noise1, ref.to_noise2):
+                lin.weight.normal_(0, 0.3)
+                lin.bias.normal_(0, 0.1)
+        blk = same_weights(networks.GeneratorBlock(514, 64, 32, upsample=True, upsample_rgb=False), ref)
+        x = torch.randn(2, 64, 128, 128)
+        prev = torch.randn(2, 3, 256, 256) * 0.3
+        w = torch.randn(2, 514) * 0.5
+        nz = torch.rand(2, 256, 256, 1)
+        gx_o, grgb = torch.randn(2, 32, 256, 256), torch.randn(2, 3, 256, 256)
+        ins_r = [t.clone().requires_grad_(True) for t in (x, prev, w)]
+        xo_r, rgb_r, sc_r = ref(ins_r[0], ins_r[1], ins_r[2], nz)
+        ((xo_r * gx_o).sum() + (rgb_r * grgb).sum()).backward()
+        ins_h = [t.to(DEV).requires_grad_(True) for t in (x, prev, w)]
+        ops.set_fast(True)
+        try:
+            xo_h, rgb_h, sc_h = blk(ins_h[0], ins_h[1], ins_h[2], nz.to(DEV))
+            ((xo_h.float() * gx_o.to(DEV)).sum() + (rgb_h.float() * grgb.to(DEV)).sum()).backward()
+        finally:
+            ops.set_fast(False)
+        errs = {"x": rel(xo_h, xo_r), "rgb": rel(rgb_h, rgb_r), "coords": rel(sc_h, sc_r)}
+        for name, a, b in zip(("gx", "gprev", "gw"), ins_h, ins_r):
+            errs[name] = rel(a.grad, b.grad)
+        ref_grads = dict(ref.named_parameters())
+        for n_, p_ in blk.named_parameters():
+            if p_.grad is not None and n_ in ref_grads:
+                errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
+        bad = {k: v for k, v in errs.items() if v > tol}
+        assert not bad, ("GeneratorBlock 64->32 @256", prec, bad)
+    finally:
+        ops.set_precision("fp32")
+        hb.pack_cache_clear()
