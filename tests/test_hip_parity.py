@@ -1888,15 +1888,16 @@ def test_attfind_visualisation_cells_on_hip():
         ta.FLIP_FRACTION[0] = prev
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-5), ("bf16", 4e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 4e-2)])
 def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
     """VERDICT r3 weak point 2 (the full-size bf16 band is HIP-bf16 against HIP-fp32: a bug common to both modes at
     >= 128 px could only be caught by the adjoint identities): the blocks whose kernels exist ONLY at full resolution —
     DiscriminatorBlock 0 and 1 of the 256 px model (padded-RGB first layer, pipelined LDS-DMA convs, activation bit
     masks, blur + space-to-depth stride-2 conv with the residual merge, even-pixel gather / add) and GeneratorBlock 6
     (64 -> 32 @256^2: bilinear x2, modulated convs with the transposed noise plane, to-RGB) — against the independent
-    CPU oracle modules (oracle/stylex_oracle.py, the restatement pinned to the reference goldens) at batch 2: outputs,
-    input gradients and every parameter gradient, fp32 to 5e-5 of the tensor's scale, bf16 inside the bf16 band."""
+    CPU oracle modules (oracle/stylex_oracle.py, the restatement pinned to the reference goldens) run in float64 at
+    batch 2: outputs, input gradients and every parameter gradient, fp32 to 2e-4 of the tensor's scale (a weight
+    gradient is an fp32 sum over 131 072 pixels: measured 1.7e-4), bf16 inside the bf16 band."""
     import networks
 
     ops.set_precision(prec)
@@ -1918,11 +1919,12 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
         for cin, cout, size in ((3, 64, 256), (64, 128, 128)):
             ref = so.ODiscriminatorBlock(cin, cout, downsample=True)
             blk = same_weights(networks.DiscriminatorBlock(cin, cout, downsample=True), ref)
+            ref = ref.double()
             x = torch.rand(2, cin, size, size) * 2 - 1
             gy = torch.randn(2, cout, size // 2, size // 2)
-            xr = x.clone().requires_grad_(True)
+            xr = x.double().requires_grad_(True)
             yr = ref(xr)
-            yr.backward(gy)
+            yr.backward(gy.double())
             xh = x.to(DEV).requires_grad_(True)
             ops.set_fast(True)
             try:
@@ -1943,14 +1945,15 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
                 lin.weight.normal_(0, 0.3)
                 lin.bias.normal_(0, 0.1)
         blk = same_weights(networks.GeneratorBlock(514, 64, 32, upsample=True, upsample_rgb=False), ref)
+        ref = ref.double()
         x = torch.randn(2, 64, 128, 128)
         prev = torch.randn(2, 3, 256, 256) * 0.3
         w = torch.randn(2, 514) * 0.5
         nz = torch.rand(2, 256, 256, 1)
         gx_o, grgb = torch.randn(2, 32, 256, 256), torch.randn(2, 3, 256, 256)
-        ins_r = [t.clone().requires_grad_(True) for t in (x, prev, w)]
-        xo_r, rgb_r, sc_r = ref(ins_r[0], ins_r[1], ins_r[2], nz)
-        ((xo_r * gx_o).sum() + (rgb_r * grgb).sum()).backward()
+        ins_r = [t.double().requires_grad_(True) for t in (x, prev, w)]
+        xo_r, rgb_r, sc_r = ref(ins_r[0], ins_r[1], ins_r[2], nz.double())
+        ((xo_r * gx_o.double()).sum() + (rgb_r * grgb.double()).sum()).backward()
         ins_h = [t.to(DEV).requires_grad_(True) for t in (x, prev, w)]
         ops.set_fast(True)
         try:
