@@ -1939,6 +1939,7 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
             ref_grads = dict(ref.named_parameters())
             for n_, p_ in blk.named_parameters():
                 errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
+            print("DiscriminatorBlock %d->%d @%d %s:" % (cin, cout, size, prec), {k: "%.1e" % v for k, v in errs.items()})
             bad = {k: v for k, v in errs.items() if v > tol}
             assert not bad, ("DiscriminatorBlock %d->%d @%d" % (cin, cout, size), prec, bad)
         # ---- generator block 6 (64 -> 32, upsample 128 -> 256, last block: no rgb upsample)
@@ -1971,6 +1972,7 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
         for n_, p_ in blk.named_parameters():
             if p_.grad is not None and n_ in ref_grads:
                 errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
+        print("GeneratorBlock 64->32 @256 %s:" % prec, {k: "%.1e" % v for k, v in errs.items()})
         bad = {k: v for k, v in errs.items() if v > tol}
         assert not bad, ("GeneratorBlock 64->32 @256", prec, bad)
     finally:
