@@ -1888,8 +1888,8 @@ def test_attfind_visualisation_cells_on_hip():
         ta.FLIP_FRACTION[0] = prev
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 4e-2)])
-def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_resolution_blocks_vs_cpu_oracle(prec):
     """VERDICT r3 weak point 2 (the full-size bf16 band is HIP-bf16 against HIP-fp32: a bug common to both modes at
     >= 128 px could only be caught by the adjoint identities): the blocks whose kernels exist ONLY at full resolution —
     DiscriminatorBlock 0 and 1 of the 256 px model (padded-RGB first layer, pipelined LDS-DMA convs, activation bit
@@ -1897,7 +1897,13 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
     (64 -> 32 @256^2: bilinear x2, modulated convs with the transposed noise plane, to-RGB) — against the independent
     CPU oracle modules (oracle/stylex_oracle.py, the restatement pinned to the reference goldens) run in float64 at
     batch 2: outputs, input gradients and every parameter gradient (90th percentile of the error over the tensor's RMS,
-    see `rel`), fp32 to 1e-4, bf16 inside the bf16 band."""
+    see `rel`).  Bounds: fp32 1e-4 (measured 1e-7 ... 1.5e-6), except the gradients that reach the generator block's
+    FIRST style vector, 3e-3: that quantity is ill-conditioned — the reference's own fp32 arithmetic (the CPU oracle in
+    float32) is 2.7e-4 away from float64 there, and 3.4e-4 on conv1.weight where the HIP path is at 1.3e-6; HIP fp32
+    measured 5.7e-4 ... 8.9e-4.  bf16: outputs 2e-2, gradients 1e-1 — behind a LeakyReLU whose pre-activation carries
+    a bf16-sized error, ~0.4 % of the gates sit on the other side of zero than in float64, which alone is a 5 %
+    perturbation of a first-layer weight gradient (measured 7.6e-2 on D0.conv1, 4e-2 on D0.conv2); a wrong index rule,
+    tap order, scale or layout gives O(1)."""
     import networks
 
     ops.set_precision(prec)
@@ -1914,6 +1920,11 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
         err = (a.detach().double().cpu().reshape(-1) - b).abs()
         k = max(1, int(0.9 * err.numel()))
         return float(err.kthvalue(k).values / max(1e-12, float(b.pow(2).mean().sqrt())))
+
+    def bound(name):
+        if prec == "fp32":
+            return 3e-3 if name in ("gw", "g:to_style1.weight", "g:to_style1.bias") else 1e-4
+        return 2e-2 if name in ("y", "x", "rgb", "coords") else 1e-1
 
     def same_weights(hip_mod, cpu_mod):
         sd = {k: v.clone() for k, v in cpu_mod.state_dict().items()}
@@ -1944,7 +1955,7 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
             for n_, p_ in blk.named_parameters():
                 errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
             print("DiscriminatorBlock %d->%d @%d %s:" % (cin, cout, size, prec), {k: "%.1e" % v for k, v in errs.items()})
-            bad = {k: v for k, v in errs.items() if v > tol}
+            bad = {k: v for k, v in errs.items() if v > bound(k)}
             assert not bad, ("DiscriminatorBlock %d->%d @%d" % (cin, cout, size), prec, bad)
         # ---- generator block 6 (64 -> 32, upsample 128 -> 256, last block: no rgb upsample)
         ref = so.OGeneratorBlock(514, 64, 32, upsample=True, upsample_rgb=False)
@@ -1977,7 +1988,7 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec, tol):
             if p_.grad is not None and n_ in ref_grads:
                 errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
         print("GeneratorBlock 64->32 @256 %s:" % prec, {k: "%.1e" % v for k, v in errs.items()})
-        bad = {k: v for k, v in errs.items() if v > tol}
+        bad = {k: v for k, v in errs.items() if v > bound(k)}
         assert not bad, ("GeneratorBlock 64->32 @256", prec, bad)
     finally:
         ops.set_precision("fp32")
