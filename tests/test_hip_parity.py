@@ -1900,10 +1900,10 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec):
     see `rel`).  Bounds: fp32 1e-4 (measured 1e-7 ... 1.5e-6), except the gradients that reach the generator block's
     FIRST style vector, 3e-3: that quantity is ill-conditioned — the reference's own fp32 arithmetic (the CPU oracle in
     float32) is 2.7e-4 away from float64 there, and 3.4e-4 on conv1.weight where the HIP path is at 1.3e-6; HIP fp32
-    measured 5.7e-4 ... 8.9e-4.  bf16: outputs 2e-2, gradients 1e-1 — behind a LeakyReLU whose pre-activation carries
-    a bf16-sized error, ~0.4 % of the gates sit on the other side of zero than in float64, which alone is a 5 %
-    perturbation of a first-layer weight gradient (measured 7.6e-2 on D0.conv1, 4e-2 on D0.conv2); a wrong index rule,
-    tap order, scale or layout gives O(1)."""
+    measured 5.7e-4 ... 8.9e-4.  bf16: outputs 2e-2 (measured 5e-3 ... 7.5e-3), gradients 1.5e-1 — behind a LeakyReLU
+    whose pre-activation carries a bf16-sized error, ~0.4 % of the gates sit on the other side of zero than in float64,
+    which alone is a 5 % perturbation of the gradients below it (measured 3e-3 ... 1e-2 for the gradients that do not
+    pass a gate, 4e-2 ... 9.8e-2 for those that do); a wrong index rule, tap order, scale or layout gives O(1)."""
     import networks
 
     ops.set_precision(prec)
@@ -1924,7 +1924,7 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec):
     def bound(name):
         if prec == "fp32":
             return 3e-3 if name in ("gw", "g:to_style1.weight", "g:to_style1.bias") else 1e-4
-        return 2e-2 if name in ("y", "x", "rgb", "coords") else 1e-1
+        return 2e-2 if name in ("y", "x", "rgb", "coords") else 1.5e-1
 
     def same_weights(hip_mod, cpu_mod):
         sd = {k: v.clone() for k, v in cpu_mod.state_dict().items()}
