@@ -1247,6 +1247,9 @@ class Trainer:
             has_gp = apply_gp
         else:
             acc = self._new_acc()
+            stale, self._g_fut = getattr(self, "_g_fut", None), None
+            if stale is not None:  # a call that raised (NaN restart) left its generator-phase draw running: let it finish
+                stale.exception()  # before anything else touches the loader / the generators
             ahead = self._draw_mode if (fuse and not self.device_rng) else 0
             d_in = g_fut = None
             if ahead:
@@ -1266,7 +1269,7 @@ class Trainer:
                         st_g["encoder_input"] = False
                     return self._draw_g(groups[0], st_g, True, apply_pl)
 
-                g_fut = self._draw_submit(draw_g)  # the generator phase's inputs, under the discriminator phase
+                g_fut = self._g_fut = self._draw_submit(draw_g)  # the generator phase's inputs, under the discriminator phase
             # ---------------- discriminator phase ----------------
             self._d_phase(groups, [d_in] if ahead else None, apply_gp, gae, fuse, acc, st)
             if self.is_ddp:
@@ -1279,6 +1282,7 @@ class Trainer:
             g_in = None
             if ahead:
                 g_in = [g_fut.result()]
+                self._g_fut = None
                 if ahead > 1 and not self._step_ends_with_draws():
                     st_n = {"encoder_input": False, "latents_fn": None}
                     grp = list(groups[0])
