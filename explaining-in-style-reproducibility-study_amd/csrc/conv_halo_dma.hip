@@ -175,6 +175,26 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         const int piece = wave + 4 * it;
         if (piece >= PIECES) return;
         if (S2D && piece >= HALO_PIECES + 4 * TNJ) return;  // at most 4 tap slots are ever staged
+        if (S2D && c0 >= C) {
+            // second K segment (forward only): 16 channels of the residual operand x2 [B][H][W][c2], centre tap, weights
+            // w2 [N][c2].  Addresses are recomputed here (a handful of chunks per tile) instead of held in registers.
+            const unsigned short* x2 = reinterpret_cast<const unsigned short*>(p.x2);
+            const unsigned short* w2 = reinterpret_cast<const unsigned short*>(p.w2);
+            const int cx = c0 - C + slot * 8;
+            const unsigned short* src = zero;
+            if (piece < HALO_PIECES) {
+                const int hp = piece * 32 + lr;
+                const int hh = hp / HWD, ww = hp - hh * HWD;
+                const int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                if (hp < NP && y >= 0 && y < H && x >= 0 && x < W && cx < p.c2) src = x2 + ((long)(b * H + y) * W + x) * p.c2 + cx;
+            } else {
+                const int r = (piece - HALO_PIECES) * 32 + lr;
+                const int nl = r % BN;
+                if (r < BN && n0 + nl < N && cx < p.c2) src = w2 + (long)(n0 + nl) * p.c2 + cx;
+            }
+            __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
+            return;
+        }
         long off = src_off[it] + c0;
         bool ok = src_ok[it] && cok;
         if (S2D && !p.flip_taps && piece >= HALO_PIECES) {
@@ -213,7 +233,8 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
     // weight rows tap*BN + j*32 + li: the tap / j terms are multiples of 16 rows, so bit3(row) = bit3(li)
     const int b_lane = HALO_BYTES + li * ROW + ((((li >> 3) ^ lk) & 1) << 4);  // + (tap*128 + j*32)*ROW
 
-    const int nchunks = (C + 15) / 16;
+    const int chunks2 = (S2D && !p.flip_taps && p.x2) ? (p.c2 + 15) / 16 : 0;  // second K segment (residual 1x1 conv)
+    const int nchunks = (C + 15) / 16 + chunks2;
     issue(0, 0);
     int buf = 0;
     if (S2D) {
@@ -241,6 +262,7 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
             run(std::integral_constant<unsigned, S2D_FWD_MASK[1]>{}, cpq, 2 * cpq);
             run(std::integral_constant<unsigned, S2D_FWD_MASK[2]>{}, 2 * cpq, 3 * cpq);
             run(std::integral_constant<unsigned, S2D_FWD_MASK[3]>{}, 3 * cpq, 4 * cpq);
+            if (chunks2) run(std::integral_constant<unsigned, S2D_FWD_MASK[0]>{}, 4 * cpq, 4 * cpq + chunks2);  // centre tap
         }
     } else
     for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
@@ -294,6 +316,7 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         // block merge of DiscriminatorBlock (:743) on the space-to-depth forward: (conv + bias + residual) * res_scale in fp32
         const unsigned short* res = (S2D && (p.flags & STYLEX_EPI_RESIDUAL)) ? reinterpret_cast<const unsigned short*>(p.residual) : nullptr;
         const float rsc = p.res_scale;
+        const bool merged = S2D && !p.flip_taps && p.x2 != nullptr;  // the residual conv sits in the accumulators already
         // D[row = channel][col = pixel]: lane (lj = pixel, lh) holds channels j*32 + 8g + 4lh + (0..3), g = r >> 2
         float4 b4[TNJ][4];
 #pragma unroll
@@ -324,6 +347,11 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
                         v1 = (v1 + __uint_as_float(rv.x & 0xffff0000u)) * rsc;
                         v2 = (v2 + __uint_as_float(rv.y << 16)) * rsc;
                         v3 = (v3 + __uint_as_float(rv.y & 0xffff0000u)) * rsc;
+                    } else if (merged) {
+                        v0 *= rsc;
+                        v1 *= rsc;
+                        v2 *= rsc;
+                        v3 *= rsc;
                     }
                     if (act) {
                         v0 = v0 > 0.f ? v0 : slope * v0;
@@ -403,6 +431,10 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
                     (p.s2d_c ? STYLEX_EPI_RESIDUAL : (STYLEX_EPI_GATE | STYLEX_EPI_GATE_MASK | STYLEX_EPI_MASK_OUT))))
         return STYLEX_NOT_APPLICABLE;
     if (p.s2d_c && (p.mask || p.gate_mask)) return STYLEX_NOT_APPLICABLE;
+    if (p.x2) {  // second K segment: forward of the space-to-depth conv only
+        if (!p.s2d_c || p.flip_taps || !p.w2 || p.c2 < 8 || p.c2 % 8 != 0 || (p.flags & STYLEX_EPI_RESIDUAL)) return STYLEX_NOT_APPLICABLE;
+        if ((reinterpret_cast<uintptr_t>(p.x2) & 15) || (reinterpret_cast<uintptr_t>(p.w2) & 15)) return STYLEX_NOT_APPLICABLE;
+    }
     if ((p.flags & STYLEX_EPI_GATE) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15))) return STYLEX_NOT_APPLICABLE;
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||

@@ -324,6 +324,49 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
     return stylex_launch_igemm(p, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+static int s2d_res_params(ConvKParams& p, const int64_t* sh, int64_t s2d_c, int64_t res_c) {
+    if (!conv_shape_ok(sh)) return STYLEX_EINVAL;
+    fwd_params(p, sh);
+    p.s2d_c = (int)s2d_c;
+    p.c2 = (int)res_c;
+    if (s2d_c <= 0 || s2d_c % 64 || p.Ck != 4 * p.s2d_c || p.KH != 3 || p.stride != 1 || p.pad != 1) return STYLEX_EINVAL;
+    if (res_c < 8 || res_c % 8) return STYLEX_EINVAL;
+    p.act_bf16 = 1;
+    p.flags = STYLEX_EPI_BIAS;
+    return 0;
+}
+
+int stylex_conv2d_s2d_res_supported(const int64_t* sh, int64_t s2d_c, int64_t res_c) {
+    static const uintptr_t fake = 4096;
+    ConvKParams p;
+    if (s2d_res_params(p, sh, s2d_c, res_c)) return 0;
+    p.a = (const float*)fake;
+    p.w = (const void*)fake;
+    p.y = (float*)fake;
+    p.bias = (const float*)fake;
+    p.x2 = p.w2 = (const void*)fake;
+    p.dry = 1;
+    return stylex_launch_halo_dma(p, nullptr) == 0 ? 1 : 0;
+}
+
+int stylex_conv2d_s2d_res_fwd(const void* x_s2d, const void* w_fwd_s2d, const void* x_res, const void* w_res, const float* bias,
+                              void* y, const int64_t* sh, int64_t s2d_c, int64_t res_c, float scale, void* stream) {
+    if (!x_s2d || !w_fwd_s2d || !x_res || !w_res || !bias || !y) return STYLEX_EINVAL;
+    ConvKParams p;
+    if (int rc = s2d_res_params(p, sh, s2d_c, res_c)) return rc;
+    p.a = (const float*)x_s2d;
+    p.w = w_fwd_s2d;
+    p.y = (float*)y;
+    p.bias = bias;
+    p.x2 = x_res;
+    p.w2 = w_res;
+    p.res_scale = scale;
+    const double flops = 2.0 * p.M * (double)p.N * (p.Ck * 9 / 4.0 + p.c2);
+    ScopedTimer tm(0, flops, conv_bytes(sh, STYLEX_BF16_ACT, false) + 2.0 * p.M * p.c2, (hipStream_t)stream, sh, p.s2d_c);
+    const int rc = stylex_launch_halo_dma(p, (hipStream_t)stream);
+    return rc == STYLEX_NOT_APPLICABLE ? STYLEX_EINVAL : rc;
+}
+
 int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const int64_t* sh, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                            void* stream) {

@@ -40,6 +40,11 @@ struct ConvKParams {
     const unsigned char* gate_mask; // STYLEX_EPI_GATE_MASK: the activation gate of a data gradient as such a mask
     int dry;                        // launchers: run the applicability checks only, launch nothing (mask-support query)
     float* bias_partial;            // wgrad: [splits][N] per-split sums of dy over the pixels (bias gradient), or null
+    // space-to-depth FORWARD only (conv_halo_dma.hip): a second K segment — the 1x1 residual conv of a DiscriminatorBlock,
+    // y += x2[b, oh, ow, :] . w2[n, :] — accumulated behind the four sub-position phases of the 3x3 / stride-2 conv
+    const void* x2;                 // [B][Ho][Wo][c2] bf16 (the block input at the even pixels), or null
+    const void* w2;                 // [N][c2] bf16
+    int c2;
 };
 
 int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s);

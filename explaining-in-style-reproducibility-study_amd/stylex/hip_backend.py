@@ -121,6 +121,9 @@ SIGNATURES = {
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_layers": (ctypes.c_int, [_i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "stylex_timing_kernels": (ctypes.c_int, [ctypes.c_char_p, _i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
+    "stylex_conv2d_s2d_res_supported": (ctypes.c_int, [_i64p, ctypes.c_int64, ctypes.c_int64]),
+    "stylex_conv2d_s2d_res_fwd": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float,
+                                                  ctypes.c_void_p]),
     "stylex_adam_pack_tensor_blocks": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "stylex_adam_pack_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
@@ -596,22 +599,42 @@ def scaled_linear_params(w, b, lr_mul):
     return ws, bs
 
 
-def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
+def pad_in_channels(w, extra):
+    """OIHW parameter with `extra` zero input channels appended (the first conv of D / the encoder reads the RGB image
+    padded to one 16-byte channel slot), cached per Parameter version: the block used to rebuild it with two launches
+    (zeros + cat) in every forward and every backward."""
+    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32 and w.is_cuda
+    key = None
+    if cacheable:
+        key = (w.data_ptr(), tuple(w.shape), "padc", int(extra))
+        hit = _cache_hit(key, w)
+        if hit is not None and hit[0] is not None:
+            return hit[0]
+    wp = torch.cat([w.detach(), w.new_zeros(w.shape[0], extra, w.shape[2], w.shape[3])], dim=1)
+    if key is not None:
+        _cache_put(key, w, wp, None)
+    return wp
+
+
+def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None, owner=None):
     """OIHW fp32 parameter -> K-contiguous operand layouts, fp32 or bf16 according to `precision`.
     Packs of nn.Parameters are cached until the parameter is modified in place (optimizer step):
     D runs three forwards per step on the same weights.  `scale`: pack scale * w (a constant folded into the operand,
-    e.g. the 1/sqrt(2) of the residual merge for the backward of a DiscriminatorBlock)."""
+    e.g. the 1/sqrt(2) of the residual merge for the backward of a DiscriminatorBlock).  `owner`: the Parameter a DERIVED
+    tensor `w` was computed from (pad_in_channels): the pack is cached under the owner's modification stamp."""
     lib = _ensure_device(w)
-    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+    own = w if owner is None else owner
+    cacheable = isinstance(own, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
     key = None
     if cacheable:
-        key = (w.data_ptr(), tuple(w.shape), precision, scale)
-        hit = _cache_hit(key, w)
+        key = (own.data_ptr(), tuple(w.shape), precision, scale) if owner is None else \
+            (own.data_ptr(), tuple(w.shape), precision, scale, "derived")
+        hit = _cache_hit(key, own)
         if hit is not None and (hit[0] is not None or not want_fwd) and (hit[1] is not None or not want_bwd):
             return hit
         if scale is None:
             want_fwd = want_bwd = True  # both operand layouts in one launch; a scaled pack is only ever used one way
-    w_param = w
+    w_param = own
     w = w.contiguous()
     if w.dtype != torch.float32:
         w = w.float()
@@ -624,7 +647,8 @@ def pack_weight(w, want_fwd=True, want_bwd=False, precision=F32, scale=None):
     _check(lib.stylex_pack_weight(_ptr(w), _ptr(wf), _ptr(wb), _shape(n, c, kh, kw), precision, _stream()),
            "stylex_pack_weight")
     if key is not None:
-        _cache_put(key, w_param, wf, wb, recipe=lambda p: pack_weight(p, want_fwd, want_bwd, precision, scale))
+        _cache_put(key, w_param, wf, wb,
+                   recipe=(lambda p: pack_weight(p, want_fwd, want_bwd, precision, scale)) if owner is None else None)
     return wf, wb
 
 
@@ -702,6 +726,34 @@ def conv_mask_supported(sh, which, flags, precision):
     if hit is None:
         hit = _MASK_OK[key] = bool(load_library().stylex_conv_mask_supported(_shape(*sh), which, flags, precision))
     return hit
+
+
+_S2D_RES_OK = {}
+
+
+def s2d_res_supported(xb_shape, n, s2d_c, res_c):
+    """Can the tail of a DiscriminatorBlock — stride-2 conv over the space-to-depth blur output + 1x1 residual conv +
+    merge — run as ONE launch (stylex_conv2d_s2d_res_fwd)?  Cached per shape."""
+    key = (tuple(xb_shape), n, s2d_c, res_c)
+    hit = _S2D_RES_OK.get(key)
+    if hit is None:
+        sh = conv_shape(xb_shape, (n, xb_shape[1], 3, 3), 1, 1)
+        hit = _S2D_RES_OK[key] = bool(load_library().stylex_conv2d_s2d_res_supported(_shape(*sh), s2d_c, res_c))
+    return hit
+
+
+def conv2d_s2d_res_fwd(xb, wf2, xs, w_res_mat, bias, n, s2d_c, scale):
+    """(conv3x3_s2(blur) [xb: space-to-depth, wf2: its packed weights] + conv1x1(xs) [w_res_mat: [N, C_res] bf16] + bias)
+    * scale, one launch: the residual conv is one more tap phase of the same accumulators."""
+    lib = _ensure_device(xb)
+    assert is_cl(xb) and is_cl(xs) and xb.dtype == torch.bfloat16 and xs.dtype == torch.bfloat16
+    assert xs.shape[0] == xb.shape[0] and xs.shape[2:] == xb.shape[2:] and w_res_mat.shape == (n, xs.shape[1])
+    sh = conv_shape(xb.shape, (n, xb.shape[1], 3, 3), 1, 1)
+    y = empty_cl((sh[0], n, sh[9], sh[10]), xb, torch.bfloat16)
+    bias = _f32(bias)
+    _check(lib.stylex_conv2d_s2d_res_fwd(_ptr(xb), _ptr(wf2), _ptr(xs), _ptr(w_res_mat), _ptr(bias), _ptr(y), _shape(*sh),
+                                         int(s2d_c), int(xs.shape[1]), float(scale), _stream()), "stylex_conv2d_s2d_res_fwd")
+    return y
 
 
 def conv2d_fwd(x, w, stride, pad, precision, bias=None, lrelu=False, in_scale=None, out_scale=None, noise=None,
@@ -890,23 +942,26 @@ def lpips_tap_bwd(f0, f1, lin, r0, r1, gout, want0, want1):
     return g0, g1
 
 
-def _bf16_matrix(w, scale=None):
-    """[N, C] bf16 copy of a 1x1 conv weight (x scale), cached per Parameter version like the packed operands."""
-    cacheable = isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
+def _bf16_matrix(w, scale=None, owner=None):
+    """[N, C] bf16 copy of a 1x1 conv weight (x scale), cached per Parameter version like the packed operands
+    (`owner`: as in pack_weight)."""
+    own = w if owner is None else owner
+    cacheable = isinstance(own, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32
     key = None
     if cacheable:
-        key = (w.data_ptr(), tuple(w.shape), "bf16mat", scale)
-        hit = _cache_hit(key, w)
+        key = (own.data_ptr(), tuple(w.shape), "bf16mat", scale) if owner is None else \
+            (own.data_ptr(), tuple(w.shape), "bf16mat", scale, "derived")
+        hit = _cache_hit(key, own)
         if hit is not None and hit[0] is not None:
             return hit[0]
     m = w.detach().reshape(w.shape[0], -1)
     m = (m * scale if scale is not None else m).to(torch.bfloat16).contiguous()
     if key is not None:
-        _cache_put(key, w, m, None, recipe=lambda p: _bf16_matrix(p, scale))
+        _cache_put(key, own, m, None, recipe=(lambda p: _bf16_matrix(p, scale)) if owner is None else None)
     return m
 
 
-def conv1x1_gemm_fwd(x, w, bias):
+def conv1x1_gemm_fwd(x, w, bias, owner=None):
     """1x1 / stride-1 conv of a channels_last bf16 tensor as the plain GEMM it is — [B*H*W, C] x [C, N] (+ bias) on
     hipBLASLt (torch.addmm): the residual path of a DiscriminatorBlock after the even-pixel gather.  Measured against
     the generic implicit-GEMM kernel at B = 128 (tools/probes/gemm1x1_probe.py): 64->128 @64^2 .161 -> .049 ms,
@@ -914,17 +969,17 @@ def conv1x1_gemm_fwd(x, w, bias):
     rounding of the result)."""
     assert is_cl(x) and x.dtype == torch.bfloat16
     b, c, h, wd = x.shape
-    wm = _bf16_matrix(w)
+    wm = _bf16_matrix(w, owner=owner)
     x2 = x.permute(0, 2, 3, 1).reshape(b * h * wd, c)
     y2 = torch.mm(x2, wm.t()) if bias is None else torch.addmm(bias.detach().to(torch.bfloat16), x2, wm.t())
     return y2.view(b, h, wd, wm.shape[0]).permute(0, 3, 1, 2)
 
 
-def conv1x1_gemm_bwd_data(dy, w, scale=None):
+def conv1x1_gemm_bwd_data(dy, w, scale=None, owner=None):
     """Data gradient of the same conv: [B*H*W, N] x [N, C] (the weight optionally pre-multiplied by `scale`)."""
     assert is_cl(dy) and dy.dtype == torch.bfloat16
     b, n, h, wd = dy.shape
-    wm = _bf16_matrix(w, scale)
+    wm = _bf16_matrix(w, scale, owner=owner)
     dx2 = torch.mm(dy.permute(0, 2, 3, 1).reshape(b * h * wd, n), wm)
     return dx2.view(b, h, wd, wm.shape[1]).permute(0, 3, 1, 2)
 

@@ -636,8 +636,9 @@ class _DBlockFast(torch.autograd.Function):
                 and os.environ.get("STYLEX_PAD_RGB", "1") != "0"):
             # RGB input, bf16 mode: cast + channels_last + zero-pad to one 16-byte channel slot in ONE pass
             x = hb.pad_rgb8(x.detach())
-            w1p = torch.cat([w1, w1.new_zeros(w1.shape[0], 5, 3, 3)], dim=1)
-            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], 5, 1, 1)], dim=1)
+            # padded weights and their operand packs: cached per parameter version (they used to be rebuilt — zeros,
+            # cat, pack, cast — in every forward and backward of block 0: ~50 launches per train() call)
+            w1p, wrp = hb.pad_in_channels(w1, 5), hb.pad_in_channels(w_res, 5)
         elif cin == 3:  # RGB input: pad to one 16-byte channel slot (see _pad_rgb); gradients are sliced back
             x = _cl(_act(x))
             x, w1p, _ = _pad_rgb(x, w1)
@@ -651,9 +652,21 @@ class _DBlockFast(torch.autograd.Function):
         side = _fork_side(x)
         # the 1x1 conv of the residual path is a plain GEMM: hipBLASLt in the bf16 mode (2-3x the generic kernel)
         res_gemm = _PRECISION == hb.BF16_ACT and os.environ.get("STYLEX_RES_GEMM", "1") != "0"
-        conv_res = (lambda t: hb.conv1x1_gemm_fwd(t, wrp if cin == 3 else w_res, b_res)) if res_gemm else (
+        conv_res = (lambda t: hb.conv1x1_gemm_fwd(t, wrp if cin == 3 else w_res, b_res,
+                                                  owner=w_res if cin == 3 else None)) if res_gemm else (
             lambda t: hb.conv2d_fwd(t, wrp, 1, 0, _PRECISION, bias=b_res))
-        if side is None:
+        # Blocks whose stride-2 conv runs on the LDS-DMA space-to-depth kernel take the residual conv as a second K segment
+        # of that launch (hb.conv2d_s2d_res_fwd): no GEMM, no bf16 `res` tensor written and read back (round 4;
+        # STYLEX_RES_FOLD=0 = the separate GEMM)
+        n2_, h2_, w2_ = w2.shape[0], x.shape[2], x.shape[3]
+        fold_res = (bool(downsample) and _PRECISION == hb.BF16_ACT and res_gemm and h2_ % 2 == 0 and w2_ % 2 == 0
+                    and n2_ % 64 == 0 and x.shape[1] % 8 == 0 and os.environ.get("STYLEX_RES_FOLD", "1") != "0"
+                    and hb.s2d_res_supported((x.shape[0], 4 * n2_, h2_ // 2, w2_ // 2), w_res.shape[0], n2_, x.shape[1]))
+        res = None
+        if fold_res:
+            xs = hb.subsample2_fwd(x)
+            side = None
+        elif side is None:
             xs = hb.subsample2_fwd(x) if downsample else x
             res = conv_res(xs)
         else:
@@ -675,8 +688,10 @@ class _DBlockFast(torch.autograd.Function):
         # at 64^2 and below the saving no longer covers that, so the masks are used from 128^2 up)
         use_m = (_PRECISION == hb.BF16_ACT and os.environ.get("STYLEX_GATE_MASK", "1") != "0"
                  and h2 * wd2 >= int(os.environ.get("STYLEX_GATE_MASK_MIN_PIXELS", 128 * 128)))
-        y1, m1 = hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True, want_mask=True) if use_m else (
-            hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True), None)
+        pk1 = dict(packed=hb.pack_weight(w1p, True, False, _PRECISION, owner=w1)[0], w_shape=tuple(w1p.shape)) \
+            if (cin == 3 and w1p is not w1 and isinstance(w1, torch.nn.Parameter)) else {}
+        y1, m1 = hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True, want_mask=True, **pk1) if use_m else (
+            hb.conv2d_fwd(x, w1p, 1, 1, _PRECISION, bias=b1, lrelu=True, **pk1), None)
         want_m2 = use_m and s2d_next and hb.blur_mask_ok((x.shape[0], n2, h2, wd2), x.dtype)
         y2, m2 = hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True, want_mask=True) if want_m2 else (
             hb.conv2d_fwd(y1, w2, 1, 1, _PRECISION, bias=b2, lrelu=True), None)
@@ -694,8 +709,12 @@ class _DBlockFast(torch.autograd.Function):
                 xb = hb.blur3x3_s2d_fwd(y2)
                 join()
                 wf2, _ = hb.pack_weight_s2d(w3)
-                out = hb.conv2d_fwd(xb, None, 1, 1, _PRECISION, bias=b3, residual=res, res_scale=c, packed=wf2,
-                                    w_shape=(w3.shape[0], 4 * n, 3, 3), s2d_c=n)
+                if fold_res:
+                    wm = hb._bf16_matrix(wrp if cin == 3 else w_res, owner=w_res if cin == 3 else None)
+                    out = hb.conv2d_s2d_res_fwd(xb, wf2, xs, wm, b3.detach().float() + b_res.detach().float(), w3.shape[0], n, c)
+                else:
+                    out = hb.conv2d_fwd(xb, None, 1, 1, _PRECISION, bias=b3, residual=res, res_scale=c, packed=wf2,
+                                        w_shape=(w3.shape[0], 4 * n, 3, 3), s2d_c=n)
             else:
                 xb = hb.blur3x3_fwd(y2)
                 join()
@@ -739,8 +758,7 @@ class _DBlockFast(torch.autograd.Function):
         gb_res = gsum3  # the per-channel sum is the bias gradient of BOTH conv_res and the down conv
         if cin == 3:  # x was saved padded; only the weights need padding again
             extra = x.shape[1] - 3
-            w1p = torch.cat([w1, w1.new_zeros(w1.shape[0], extra, 3, 3)], dim=1)
-            wrp = torch.cat([w_res, w_res.new_zeros(w_res.shape[0], extra, 1, 1)], dim=1)
+            w1p, wrp = hb.pad_in_channels(w1, extra), hb.pad_in_channels(w_res, extra)
         else:
             w1p, wrp = w1, w_res
         # residual path (1x1 weight gradient + data gradient on the quarter-size tensor): companion stream, joined
@@ -750,7 +768,8 @@ class _DBlockFast(torch.autograd.Function):
 
         def res_dgrad():
             if res_gemm:  # [M, N] x [N, C] on hipBLASLt, the 1/sqrt(2) folded into the bf16 weight copy as below
-                return hb.conv1x1_gemm_bwd_data(gz3, wrp if cin == 3 else w_res, scale=c if alg else None)
+                return hb.conv1x1_gemm_bwd_data(gz3, wrp if cin == 3 else w_res, scale=c if alg else None,
+                                                owner=w_res if cin == 3 else None)
             wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
             return hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
 
@@ -804,7 +823,9 @@ class _DBlockFast(torch.autograd.Function):
         if want_b and gb1 is None:
             gb1 = _channel_sum(gz1)
         if want_x:
-            gx = hb.conv2d_bwd_data(gz1, w1p, tuple(x.shape), 1, 1, prec)
+            pk1 = dict(packed=hb.pack_weight(w1p, False, True, prec, owner=w1)[1], w_shape=tuple(w1p.shape)) \
+                if (cin == 3 and isinstance(w1, torch.nn.Parameter)) else {}
+            gx = hb.conv2d_bwd_data(gz1, w1p, tuple(x.shape), 1, 1, prec, **pk1)
         if side_bwd is not None:  # join: the residual-path gradients were issued on the companion stream above
             gw_res, gxs = side_out
             main.wait_stream(side_bwd)

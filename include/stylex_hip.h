@@ -119,6 +119,19 @@ int stylex_conv2d_fwd(const void* x, const void* w_fwd, void* y, const int64_t* 
                       const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                       void* stream);
 
+/* Tail of a DiscriminatorBlock in one launch (reference stylex_train.py:724, :733-743, bf16 activations):
+ *   y = ( conv3x3_s2(blur(x))  [space-to-depth form: x_s2d {B,Ho,Wo,4C}, w_fwd_s2d from stylex_pack_weight_s2d, s2d_c = C]
+ *       + conv1x1_s2(block input) [x_res {B,Ho,Wo,res_c} = the block input at the even pixels (stylex_subsample2_fwd),
+ *                                  w_res {N,res_c} bf16, res_c % 8 == 0]
+ *       + bias [N: the sum of the two convs' biases] ) * scale
+ * The residual conv is a second K segment of the same accumulators (one more tap phase over x_res) instead of a GEMM
+ * whose bf16 result the conv's epilogue reads back.  shape = the 11-entry conv shape of the 3x3 part
+ * {B,Ho,Wo,4C,N,3,3,1,1,Ho,Wo}.  stylex_conv2d_s2d_res_supported() = 1 when a kernel takes the launch (16-byte aligned
+ * tensors); stylex_conv2d_s2d_res_fwd returns STYLEX_EINVAL otherwise. */
+int stylex_conv2d_s2d_res_supported(const int64_t* shape, int64_t s2d_c, int64_t res_c);
+int stylex_conv2d_s2d_res_fwd(const void* x_s2d, const void* w_fwd_s2d, const void* x_res, const void* w_res, const float* bias,
+                              void* y, const int64_t* shape, int64_t s2d_c, int64_t res_c, float scale, void* stream);
+
 /* dx[b,hi,wi,c] = sum_{kh,kw,n} dy[b,(hi+p-kh)/s,(wi+p-kw)/s,n] * w_bwd[c][t][n]   (exact division only)
  * Replaces the input-gradient half of aten::convolution_backward issued by
  * autograd for the call sites above (and, through create_graph=True, the
