@@ -52,7 +52,8 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
 __global__ __launch_bounds__(256) void adam_pack_kernel(const stylex_adam_tensor* __restrict__ descs,
                                                         const int32_t* __restrict__ block_map) {
     __shared__ float sw[SLAB_ELEMS];
-    const stylex_adam_tensor d = descs[block_map[blockIdx.x]];
+    // by reference: a by-value copy of the 200-byte descriptor, indexed by the variant loop, lived in scratch memory
+    const stylex_adam_tensor& d = descs[block_map[blockIdx.x]];
     const int local = (int)((int64_t)blockIdx.x - d.first_block);
     const int tid = threadIdx.x;
     AdamConsts k;

@@ -175,26 +175,6 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
         const int piece = wave + 4 * it;
         if (piece >= PIECES) return;
         if (S2D && piece >= HALO_PIECES + 4 * TNJ) return;  // at most 4 tap slots are ever staged
-        if (S2D && c0 >= C) {
-            // second K segment (forward only): 16 channels of the residual operand x2 [B][H][W][c2], centre tap, weights
-            // w2 [N][c2].  Addresses are recomputed here (a handful of chunks per tile) instead of held in registers.
-            const unsigned short* x2 = reinterpret_cast<const unsigned short*>(p.x2);
-            const unsigned short* w2 = reinterpret_cast<const unsigned short*>(p.w2);
-            const int cx = c0 - C + slot * 8;
-            const unsigned short* src = zero;
-            if (piece < HALO_PIECES) {
-                const int hp = piece * 32 + lr;
-                const int hh = hp / HWD, ww = hp - hh * HWD;
-                const int y = y0 - 1 + hh, x = x0 - 1 + ww;
-                if (hp < NP && y >= 0 && y < H && x >= 0 && x < W && cx < p.c2) src = x2 + ((long)(b * H + y) * W + x) * p.c2 + cx;
-            } else {
-                const int r = (piece - HALO_PIECES) * 32 + lr;
-                const int nl = r % BN;
-                if (r < BN && n0 + nl < N && cx < p.c2) src = w2 + (long)(n0 + nl) * p.c2 + cx;
-            }
-            __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
-            return;
-        }
         long off = src_off[it] + c0;
         bool ok = src_ok[it] && cok;
         if (S2D && !p.flip_taps && piece >= HALO_PIECES) {
@@ -209,6 +189,29 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
     auto issue = [&](int c0, int buf) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) issue_piece(c0, buf, it);
+    };
+    // Second K segment of the space-to-depth FORWARD (its chunks come FIRST and share the centre-tap loop of sub-position
+    // 0): 16 channels [cx0, cx0 + 16) of the residual operand x2 [B][H][W][c2], weights w2 [N][c2].  Kept out of
+    // issue_piece — inside it the extra code stopped the per-piece arrays from living in registers (640 bytes of scratch,
+    // the step 27 % slower) — and recomputed per piece: a handful of chunks per tile.
+    auto issue_extra = [&](int cx0, int buf) {
+        char* base = smem + buf * BUF;
+        const unsigned short* x2 = reinterpret_cast<const unsigned short*>(p.x2);
+        const unsigned short* w2 = reinterpret_cast<const unsigned short*>(p.w2);
+        const int cx = cx0 + slot * 8;
+        for (int piece = wave; piece < HALO_PIECES + TNJ; piece += 4) {  // halo pieces + ONE tap slot of weights (BN rows)
+            const unsigned short* src = zero;
+            if (piece < HALO_PIECES) {
+                const int hp = piece * 32 + lr;
+                const int hh = hp / HWD, ww = hp - hh * HWD;
+                const int y = y0 - 1 + hh, x = x0 - 1 + ww;
+                if (hp < NP && y >= 0 && y < H && x >= 0 && x < W && cx < p.c2) src = x2 + ((long)(b * H + y) * W + x) * p.c2 + cx;
+            } else {
+                const int nl = (piece - HALO_PIECES) * 32 + lr;
+                if (n0 + nl < N && cx < p.c2) src = w2 + (long)(n0 + nl) * p.c2 + cx;
+            }
+            __builtin_amdgcn_global_load_lds((gl_void_ptr)src, (lds_void_ptr)(base + piece * 1024), 16, 0, 0);
+        }
     };
 
     f32x16 acc[4][TNJ];
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
 
     const int chunks2 = (S2D && !p.flip_taps && p.x2) ? (p.c2 + 15) / 16 : 0;  // second K segment (residual 1x1 conv)
     const int nchunks = (C + 15) / 16 + chunks2;
-    issue(0, 0);
+    if (chunks2) issue_extra(0, 0);
+    else issue(0, 0);
     int buf = 0;
     if (S2D) {
         // the tap set is uniform per block (output sub-position of its channel tile): one copy of the whole chunk loop
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
             for (int ch = ch_begin; ch < ch_end; ++ch, buf ^= 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (ch + 1 < nchunks) issue((ch + 1) * 16, buf ^ 1);
+                if (ch + 1 < chunks2) issue_extra((ch + 1) * 16, buf ^ 1);
+                else if (ch + 1 < nchunks) issue((ch + 1 - chunks2) * 16, buf ^ 1);
                 dma_chunk_masked<TNJ, MASK>(smem + buf * BUF, a_off, b_lane, acc);
             }
         };
@@ -257,12 +262,11 @@ __global__ __launch_bounds__(256, TNJ == 4 ? 1 : 2) void conv3x3_halo_dma_kernel
                 default: run(std::integral_constant<unsigned, S2D_DGRAD_MASK[3]>{}, 0, nchunks); break;
             }
         } else {  // forward: the four input sub-positions one after the other, each with its own tap set
-            const int cpq = p.s2d_c / 16;
-            run(std::integral_constant<unsigned, S2D_FWD_MASK[0]>{}, 0, cpq);
-            run(std::integral_constant<unsigned, S2D_FWD_MASK[1]>{}, cpq, 2 * cpq);
-            run(std::integral_constant<unsigned, S2D_FWD_MASK[2]>{}, 2 * cpq, 3 * cpq);
-            run(std::integral_constant<unsigned, S2D_FWD_MASK[3]>{}, 3 * cpq, 4 * cpq);
-            if (chunks2) run(std::integral_constant<unsigned, S2D_FWD_MASK[0]>{}, 4 * cpq, 4 * cpq + chunks2);  // centre tap
+            const int cpq = p.s2d_c / 16, c2 = chunks2;  // the residual segment's chunks lead: centre tap, like sub-position 0
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[0]>{}, 0, c2 + cpq);
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[1]>{}, c2 + cpq, c2 + 2 * cpq);
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[2]>{}, c2 + 2 * cpq, c2 + 3 * cpq);
+            run(std::integral_constant<unsigned, S2D_FWD_MASK[3]>{}, c2 + 3 * cpq, c2 + 4 * cpq);
         }
     } else
     for (int ch = 0; ch < nchunks; ++ch, buf ^= 1) {
