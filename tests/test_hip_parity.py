@@ -978,6 +978,11 @@ def test_gradient_penalty_tangent_pass_matches_double_backward(prec, size):
 
     res = {}
     os.environ["STYLEX_GP_TANGENT"] = "2"  # the tangent path in any precision
+    # same primal arithmetic on both sides: the fused block's residual conv as a second K segment of the stride-2 conv
+    # (round 4) skips one bf16 rounding that the composable double-backward path has — a 0.4 % difference of block 0's
+    # output that flips gates further down and moves the gradient of a 2x2 px layer by 10 %: noise between two bf16
+    # evaluation orders, not what this test compares
+    os.environ["STYLEX_RES_FOLD"] = "0"
     try:
         for mode in ("double", "tangent"):
             D.zero_grad()
@@ -996,6 +1001,7 @@ def test_gradient_penalty_tangent_pass_matches_double_backward(prec, size):
     finally:
         ops.set_fast(False)
         os.environ.pop("STYLEX_GP_TANGENT", None)
+        os.environ.pop("STYLEX_RES_FOLD", None)
         ops.set_precision("fp32")
     tol = 2e-4 if prec == "fp32" else 4e-2
     close(res["double"][0], res["tangent"][0], 2e-5 if prec == "fp32" else 2e-2, "D(real)")
