@@ -126,6 +126,17 @@ SIGNATURES = {
                                                   ctypes.c_void_p]),
     "stylex_adam_pack_tensor_blocks": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "stylex_adam_pack_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_hinge_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_hinge_bwd": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "stylex_pl_lengths_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_pl_lengths_bwd": (ctypes.c_int, [_c_f] * 4 + [_i64p, ctypes.c_void_p]),
+    "stylex_kl_logits_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_kl_logits_bwd": (ctypes.c_int, [_c_f] * 5 + [_i64p, ctypes.c_void_p]),
+    "stylex_l1_mean_chunks": (ctypes.c_int64, [ctypes.c_int64]),
+    "stylex_l1_mean_fwd": (ctypes.c_int, [_c_f] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _i64p,
+                                            ctypes.c_void_p]),
+    "stylex_l1_mean_bwd": (ctypes.c_int, [_c_f] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _i64p, _i64p, _i64p,
+                                            ctypes.c_void_p]),
     "stylex_timing_report": (ctypes.c_int, [ctypes.c_int, _i64p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
@@ -170,7 +181,7 @@ class _SyncTraced:
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         if not name.startswith("stylex_") or name.endswith("_bytes") or name in (
-                "stylex_reduce_chunks", "stylex_conv_mask_supported", "stylex_version"):
+                "stylex_reduce_chunks", "stylex_l1_mean_chunks", "stylex_conv_mask_supported", "stylex_version"):
             return fn
         import sys
 
@@ -1208,6 +1219,107 @@ def rowwise_sumsq(x2d):
     _check(lib.stylex_rowwise_sumsq(_ptr(x2d), _ptr(out), _shape(x2d.shape[0], x2d.shape[1]), _stream()),
            "stylex_rowwise_sumsq")
     return out
+
+
+# ---- K10: scalar loss reductions (csrc/losses.hip).  fp32 vectors; results are 0-dim DEVICE tensors ---------------
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def hinge_fwd(real, fake, mode=0):
+    lib = _ensure_device(fake)
+    out = _empty((), dtype=torch.float32, device=fake.device)
+    _check(lib.stylex_hinge_fwd(_ptr(real), _ptr(fake), _ptr(out), fake.numel(), mode, _stream()), "stylex_hinge_fwd")
+    return out
+
+
+def hinge_bwd(real, fake, gout, want_real, want_fake, mode=0):
+    lib = _ensure_device(fake)
+    greal = torch.empty_like(real) if (want_real and real is not None) else None
+    gfake = torch.empty_like(fake) if want_fake else None
+    _check(lib.stylex_hinge_bwd(_ptr(real), _ptr(fake), _ptr(gout), _ptr(greal), _ptr(gfake), fake.numel(), mode, _stream()),
+           "stylex_hinge_bwd")
+    return greal, gfake
+
+
+def pl_lengths_fwd(g):
+    lib = _ensure_device(g)
+    out = _empty(g.shape[0], dtype=torch.float32, device=g.device)
+    _check(lib.stylex_pl_lengths_fwd(_ptr(g), _ptr(out), _shape(*g.shape), _stream()), "stylex_pl_lengths_fwd")
+    return out
+
+
+def pl_lengths_bwd(g, lengths, glen):
+    lib = _ensure_device(g)
+    gg = torch.empty_like(g)
+    _check(lib.stylex_pl_lengths_bwd(_ptr(g), _ptr(lengths), _ptr(glen), _ptr(gg), _shape(*g.shape), _stream()), "stylex_pl_lengths_bwd")
+    return gg
+
+
+def kl_logits_fwd(real, fake):
+    lib = _ensure_device(fake)
+    out = _empty((), dtype=torch.float32, device=fake.device)
+    _check(lib.stylex_kl_logits_fwd(_ptr(real), _ptr(fake), _ptr(out), _shape(*fake.shape), _stream()), "stylex_kl_logits_fwd")
+    return out
+
+
+def kl_logits_bwd(real, fake, gout, want_real, want_fake):
+    lib = _ensure_device(fake)
+    greal = torch.empty_like(real) if want_real else None
+    gfake = torch.empty_like(fake) if want_fake else None
+    _check(lib.stylex_kl_logits_bwd(_ptr(real), _ptr(fake), _ptr(gout), _ptr(greal), _ptr(gfake), _shape(*fake.shape), _stream()),
+           "stylex_kl_logits_bwd")
+    return greal, gfake
+
+
+def l1_walk(a, b):
+    """How the L1 kernels can walk the pair: None (not expressible: the caller keeps the torch composition), or
+    (shape4, a_strides4, b_strides4) ctypes arrays — all None when a and b share one dense element order; otherwise the
+    dims are ordered by b's strides, and an operand that is not dense in that order is addressed through its strides
+    (<= 4 dims, < 2^32 elements, no broadcast strides)."""
+    if a.shape != b.shape or a.numel() == 0:
+        return None
+    order = sorted(range(b.dim()), key=lambda d: (-b.stride(d), d))
+    ap, bp = a.permute(order), b.permute(order)
+    a_lin, b_lin = ap.is_contiguous(), bp.is_contiguous()
+    if a_lin and b_lin:
+        return (None, None, None)
+    if a.dim() > 4 or a.numel() >= 2 ** 32:
+        return None
+    for t in (ap, bp):
+        if any(st <= 0 and sz > 1 for st, sz in zip(t.stride(), t.shape)):
+            return None
+    pad = 4 - a.dim()
+    strides = lambda t: _shape(*([0] * pad + list(t.stride())))
+    return (_shape(*([1] * pad + list(ap.shape))), None if a_lin else strides(ap), None if b_lin else strides(bp))
+
+
+def _like_strided(t):
+    g = torch.empty_like(t)
+    return g if g.stride() == t.stride() else torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
+def l1_mean_fwd(a, b, walk):
+    """mean |a - b| (fp32 or bf16 each); `walk` from l1_walk(a, b)."""
+    lib = _ensure_device(a)
+    n = a.numel()
+    partial = _empty(int(lib.stylex_l1_mean_chunks(n)), dtype=torch.float32, device=a.device)
+    out = _empty((), dtype=torch.float32, device=a.device)
+    _check(lib.stylex_l1_mean_fwd(_ptr(a), _ptr(b), _ptr(partial), _ptr(out), n, int(a.dtype == torch.bfloat16),
+                                  int(b.dtype == torch.bfloat16), walk[0], walk[1], walk[2], _stream()), "stylex_l1_mean_fwd")
+    return out
+
+
+def l1_mean_bwd(a, b, gout, want_a, want_b, walk):
+    """Gradients with the strides of their operands (storage a non-dense operand does not address is left unwritten: no
+    view of the gradient reaches it)."""
+    lib = _ensure_device(a)
+    ga = _like_strided(a) if want_a else None
+    gb = _like_strided(b) if want_b else None
+    _check(lib.stylex_l1_mean_bwd(_ptr(a), _ptr(b), _ptr(gout), _ptr(ga), _ptr(gb), a.numel(), int(a.dtype == torch.bfloat16),
+                                  int(b.dtype == torch.bfloat16), walk[0], walk[1], walk[2], _stream()), "stylex_l1_mean_bwd")
+    return ga, gb
 
 
 def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True, per_sample=False):

@@ -310,6 +310,123 @@ class _RowSumSq(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------
+# K10: the scalar losses of the step as one forward + one backward launch each (csrc/losses.hip).  First-order nodes:
+# none of these losses is differentiated twice (the gradient penalty and the path-length term differentiate D / G
+# twice, not the reduction on top — the backward of `pl_lengths` only FEEDS the double-backward graph of G).
+# STYLEX_FUSED_LOSSES=0 keeps the torch compositions (A/B, bisecting).
+# ------------------------------------------------------------------------------------------
+
+_FUSED_LOSSES = os.environ.get("STYLEX_FUSED_LOSSES", "1") != "0"
+
+
+def _loss_fusable(*ts):
+    return (_FUSED_LOSSES and _IMPL is HipOps and
+            all(t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.numel() > 0 for t in ts))
+
+
+class _Hinge(torch.autograd.Function):
+    """mode 0: mean(relu(1 + real) + relu(1 - fake)) (reference hinge_loss :386-387); mode 1: fake.mean() (:382-383)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, mode):
+        real = hb._f32c(real) if real is not None else None
+        fake = hb._f32c(fake)
+        ctx.save_for_backward(real, fake)
+        ctx.mode = mode
+        return hb.hinge_fwd(real, fake, mode)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        real, fake = ctx.saved_tensors
+        greal, gfake = hb.hinge_bwd(real, fake, hb._f32c(g), ctx.mode == 0 and ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    ctx.mode)
+        return greal, gfake, None
+
+
+class _PLLengths(torch.autograd.Function):
+    """sqrt(mean_l(sum_d g^2)) per sample (reference calc_pl_lengths :316)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = hb._f32c(g)
+        lengths = hb.pl_lengths_fwd(g)
+        ctx.save_for_backward(g, lengths)
+        return lengths
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, glen):
+        g, lengths = ctx.saved_tensors
+        return hb.pl_lengths_bwd(g, lengths, hb._f32c(glen))
+
+
+class _KLLogits(torch.autograd.Function):
+    """KLDivLoss(batchmean, log_target=True)(log_softmax(fake), log_softmax(real)) (reference :421-438)."""
+
+    @staticmethod
+    def forward(ctx, real, fake):
+        real, fake = hb._f32c(real), hb._f32c(fake)
+        ctx.save_for_backward(real, fake)
+        return hb.kl_logits_fwd(real, fake)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        real, fake = ctx.saved_tensors
+        return hb.kl_logits_bwd(real, fake, hb._f32c(g), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+class _L1Mean(torch.autograd.Function):
+    """nn.L1Loss() (reference :404-405): mean |a - b|."""
+
+    @staticmethod
+    def forward(ctx, a, b, walk):
+        ctx.save_for_backward(a, b)
+        ctx.walk = walk
+        return hb.l1_mean_fwd(a, b, walk)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga, gb = hb.l1_mean_bwd(a, b, hb._f32c(g), ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.walk)
+        return ga, gb, None
+
+
+def hinge_loss(real, fake):
+    if _loss_fusable(real, fake) and real.shape == fake.shape:
+        return _Hinge.apply(real, fake, 0)
+    return (F.relu(1 + real) + F.relu(1 - fake)).mean()
+
+
+def gen_hinge_loss(fake):
+    if _loss_fusable(fake):
+        return _Hinge.apply(None, fake, 1)
+    return fake.mean()
+
+
+def pl_lengths(pl_grads):
+    if _loss_fusable(pl_grads) and pl_grads.dim() == 3:
+        return _PLLengths.apply(pl_grads)
+    return (pl_grads ** 2).sum(dim=2).mean(dim=1).sqrt()
+
+
+def kl_logits(real_logits, fake_logits):
+    if _loss_fusable(real_logits, fake_logits) and real_logits.dim() == 2 and real_logits.shape == fake_logits.shape:
+        return _KLLogits.apply(real_logits, fake_logits)
+    return F.kl_div(F.log_softmax(fake_logits, dim=1), F.log_softmax(real_logits, dim=1), reduction="batchmean", log_target=True)
+
+
+def l1_mean(a, b):
+    if _loss_fusable(a, b):
+        walk = hb.l1_walk(a, b)
+        if walk is not None:
+            return _L1Mean.apply(a, b, walk)
+    return F.l1_loss(a, b)
+
+
+# ------------------------------------------------------------------------------------------
 # fused fast path: ONE forward kernel per conv (scales, bias, noise, residual merge, LeakyReLU in the
 # epilogue) and fused backward bookkeeping.  Backward is NOT differentiable again, so it is used
 # only when no double backward can be requested: under no_grad, or when the Trainer has declared

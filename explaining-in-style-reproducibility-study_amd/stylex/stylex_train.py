@@ -318,15 +318,17 @@ def calc_pl_lengths(styles, images, pl_noise=None):
     with ops.inputs_only():
         (pl_grads,) = torch.autograd.grad(outputs=outputs, inputs=styles, grad_outputs=torch.ones_like(outputs),
                                           create_graph=True, retain_graph=True, only_inputs=True)
-    return (pl_grads ** 2).sum(dim=2).mean(dim=1).sqrt()
+    return ops.pl_lengths(pl_grads)  # (pl_grads ** 2).sum(dim=2).mean(dim=1).sqrt()
 
 
+# The scalar reductions below are one forward and one backward launch each on the GPU (csrc/losses.hip,
+# ops._Hinge / _KLLogits / _L1Mean / _PLLengths); on other devices the reference's torch composition.
 def gen_hinge_loss(fake, real):
-    return fake.mean()
+    return ops.gen_hinge_loss(fake)  # fake.mean()
 
 
 def hinge_loss(real, fake):
-    return (F.relu(1 + real) + F.relu(1 - fake)).mean()
+    return ops.hinge_loss(real, fake)  # (F.relu(1 + real) + F.relu(1 - fake)).mean()
 
 
 def lpips_normalize(images):
@@ -378,14 +380,12 @@ def reconstruction_loss(encoder_batch, generated_images, generated_images_w, enc
     (the Trainer runs it on a side stream)."""
     if perceptual is None:
         perceptual = perceptual_loss(encoder_batch, generated_images, lpips_fn)
-    return 0.1 * perceptual + 0.1 * F.l1_loss(encoder_w, generated_images_w) + 1 * F.l1_loss(encoder_batch,
-                                                                                             generated_images)
+    return 0.1 * perceptual + 0.1 * ops.l1_mean(encoder_w, generated_images_w) + 1 * ops.l1_mean(encoder_batch,
+                                                                                               generated_images)
 
 
 def classifier_kl_loss(real_classifier_logits, fake_classifier_logits):
-    real_lp = F.log_softmax(real_classifier_logits, dim=1)
-    fake_lp = F.log_softmax(fake_classifier_logits, dim=1)
-    return F.kl_div(fake_lp, real_lp, reduction="batchmean", log_target=True)
+    return ops.kl_logits(real_classifier_logits, fake_classifier_logits)
 
 
 # ------------------------------------------------------------------------------------------

@@ -385,6 +385,34 @@ typedef struct {
 int64_t stylex_adam_pack_tensor_blocks(int64_t numel, int32_t N, int32_t C, int32_t T);
 int stylex_adam_pack_step(const stylex_adam_tensor* descs_dev, const int32_t* block_map_dev, int64_t n_blocks, void* stream);
 
+/* K10 — the scalar loss reductions of the train step, one forward and one backward launch each (fp32; deterministic:
+ * fixed reduction trees, no atomics).  Results and incoming gradients are DEVICE scalars: no host synchronisation.
+ *   hinge       mode 0: out = mean(relu(1 + real) + relu(1 - fake))   (hinge_loss, stylex_train.py:386-387)
+ *               mode 1: out = mean(fake)                               (gen_hinge_loss, :382-383; real ignored)
+ *   pl_lengths  len[b] = sqrt(mean_l(sum_d g[b][l][d]^2)), shape = {B, L, D}   (calc_pl_lengths :316)
+ *   kl_logits   out = sum_b sum_k p_real (log p_real - log p_fake) / B over log-softmaxed logit rows, shape = {B, K}
+ *               (classifier_kl_loss :421-438 with KLDivLoss(reduction='batchmean', log_target=True) :406)
+ *   l1_mean     out = mean(|a - b|) over n elements (nn.L1Loss :404-405, used at :415-418).  shape4 = NULL: both
+ *               operands in one linear element order.  Otherwise the logical tensor is the 4-D index space {shape4}
+ *               (n = its product < 2^32) walked with the last index fastest; an operand with a NULL stride array is
+ *               linear in that order, the other is addressed through its element strides.  Operand dtypes 0 = fp32 /
+ *               1 = bf16; `partial` = stylex_l1_mean_chunks(n) floats of workspace; a gradient takes the dtype and the
+ *               addressing of its operand
+ * bwd: gradient pointers may be NULL where a gradient is not wanted (at least one must be given). */
+int stylex_hinge_fwd(const float* real, const float* fake, float* out, int64_t n, int mode, void* stream);
+int stylex_hinge_bwd(const float* real, const float* fake, const float* gout, float* greal, float* gfake, int64_t n, int mode,
+                     void* stream);
+int stylex_pl_lengths_fwd(const float* g, float* len, const int64_t* shape, void* stream);
+int stylex_pl_lengths_bwd(const float* g, const float* len, const float* glen, float* gg, const int64_t* shape, void* stream);
+int stylex_kl_logits_fwd(const float* real, const float* fake, float* out, const int64_t* shape, void* stream);
+int stylex_kl_logits_bwd(const float* real, const float* fake, const float* gout, float* greal, float* gfake, const int64_t* shape,
+                         void* stream);
+int64_t stylex_l1_mean_chunks(int64_t n);
+int stylex_l1_mean_fwd(const void* a, const void* b, float* partial, float* out, int64_t n, int a_dtype, int b_dtype,
+                       const int64_t* shape4, const int64_t* a_strides4, const int64_t* b_strides4, void* stream);
+int stylex_l1_mean_bwd(const void* a, const void* b, const float* gout, void* ga, void* gb, int64_t n, int a_dtype, int b_dtype,
+                       const int64_t* shape4, const int64_t* a_strides4, const int64_t* b_strides4, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,40 @@ lib.stylex_pack_weight_s2d(ptr(buf(n * c * 9 * 4)), ptr(buf(n * c * 36 * 2)), pt
 lib.stylex_fold_weight_grad_s2d(ptr(buf(n * c * 36 * 4)), ptr(buf(n * c * 9 * 4)), shape(n, c, 3, 3), None)
 lib.stylex_weight_sumsq(ptr(buf(n * c * 9 * 4)), ptr(buf(n * c * 4)), i64(n), i64(c), i64(9), None)
 
+# K10 loss reductions: argument validation + walk geometry
+f32 = lambda n: ptr(buf(4 * n))
+for n in (1, 5, 32, 1000):
+    for mode in (0, 1):
+        lib.stylex_hinge_fwd(f32(n), f32(n), f32(1), i64(n), mode, None)
+        lib.stylex_hinge_bwd(f32(n), f32(n), f32(1), f32(n), f32(n), i64(n), mode, None)
+        calls += 2
+assert lib.stylex_hinge_fwd(None, f32(4), f32(1), i64(4), 0, None) != 0 and lib.stylex_hinge_fwd(f32(4), f32(4), f32(1), i64(0), 0, None) != 0
+assert lib.stylex_hinge_bwd(f32(4), f32(4), f32(1), None, None, i64(4), 0, None) != 0 and lib.stylex_hinge_fwd(f32(4), f32(4), f32(1), i64(4), 2, None) != 0
+for b, l, d in ((1, 1, 1), (5, 7, 514)):
+    lib.stylex_pl_lengths_fwd(f32(b * l * d), f32(b), shape(b, l, d), None)
+    lib.stylex_pl_lengths_bwd(f32(b * l * d), f32(b), f32(b), f32(b * l * d), shape(b, l, d), None)
+    lib.stylex_kl_logits_fwd(f32(b * l), f32(b * l), f32(1), shape(b, l), None)
+    lib.stylex_kl_logits_bwd(f32(b * l), f32(b * l), f32(1), f32(b * l), None, shape(b, l), None)
+    calls += 4
+assert lib.stylex_pl_lengths_fwd(f32(4), f32(1), shape(0, 2, 2), None) != 0 and lib.stylex_kl_logits_fwd(f32(4), f32(4), f32(1), shape(2, 0), None) != 0
+assert lib.stylex_kl_logits_bwd(f32(4), f32(4), f32(1), None, None, shape(2, 2), None) != 0
+lib.stylex_l1_mean_chunks.restype = i64
+for n in (1, 777, 3 * 3 * 20 * 12, 1 << 22):
+    nch = lib.stylex_l1_mean_chunks(i64(n))
+    assert 1 <= nch <= 1024
+    lib.stylex_l1_mean_fwd(f32(n), f32(n), f32(nch), f32(1), i64(n), 0, 1, None, None, None, None)
+    lib.stylex_l1_mean_bwd(f32(n), f32(n), f32(1), f32(n), None, i64(n), 0, 0, None, None, None, None)
+    calls += 2
+n = 3 * 3 * 20 * 12
+sh4, st_a, st_b = shape(3, 20, 12, 3), shape(720, 12, 1, 240), shape(960, 48, 4, 1)
+lib.stylex_l1_mean_fwd(f32(n), f32(n * 2), f32(8), f32(1), i64(n), 0, 0, sh4, st_a, st_b, None)
+lib.stylex_l1_mean_bwd(f32(n), f32(n * 2), f32(1), f32(n), f32(n * 2), i64(n), 0, 0, sh4, st_a, None, None)
+assert lib.stylex_l1_mean_fwd(f32(n), f32(n), f32(8), f32(1), i64(n), 0, 0, None, st_a, None, None) != 0  # strides without a shape
+assert lib.stylex_l1_mean_fwd(f32(n), f32(n), f32(8), f32(1), i64(n + 1), 0, 0, sh4, st_a, None, None) != 0  # product != n
+assert lib.stylex_l1_mean_fwd(f32(n), f32(n), f32(8), f32(1), i64(n), 0, 2, None, None, None, None) != 0  # dtype
+assert lib.stylex_l1_mean_bwd(f32(n), f32(n), f32(1), None, None, i64(n), 0, 0, None, None, None, None) != 0
+calls += 6
+
 # timing bookkeeping (events cannot be created without a device: the report paths must still be sound)
 lau, ms, fl, by = i64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
 for cls in (0, 1, 2, 7):

@@ -181,7 +181,7 @@ def test_fast_fused_path_matches_differentiable_path(prec):
         close(a, b_, tol * 5, "fast grad " + nm)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 128, 64, 64), (1, 128, 64, 48, 80), (2, 64, 64, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 64, 64), (1, 128, 64, 48, 80), (2, 64, 64, 32, 32), (1, 128, 256, 64, 96)])
 def test_s2d_downsample_path_matches_strided_conv(shape):
     """blur -> space-to-depth -> 3x3/s1 halo conv with skipped zero taps == blur -> 3x3/s2 conv (+bias+res)*c,
     outputs and all gradients (bf16 mode: this path only exists on the bf16 kernels).  The first two shapes send the
@@ -1999,3 +1999,91 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec):
     finally:
         ops.set_precision("fp32")
         hb.pack_cache_clear()
+
+
+def test_fused_loss_kernels_match_the_torch_compositions():
+    """SURVEY K10 (csrc/losses.hip): hinge / generator hinge (reference :382-387), path lengths (:316), the classifier KL
+    (:421-438 with KLDivLoss(batchmean, log_target) :406) and nn.L1Loss (:404-405) as one forward + one backward launch each,
+    against the reference's torch composition in float64 on the CPU — values and every input gradient, fp32 tolerance
+    2e-6 relative; ragged sizes, both operand layouts of the reconstruction L1 (NCHW real batch against the sliced
+    channels-last generated batch), a bf16 operand, and STYLEX_FUSED_LOSSES semantics (the fused node is what ran)."""
+    g = torch.Generator().manual_seed(31)
+    tol = 2e-6
+
+    def check(fused_fn, ref_fn, inputs, grads_for, what, tol=tol):
+        xs = [t.clone().to(DEV).requires_grad_(i in grads_for) for i, t in enumerate(inputs)]
+        out = fused_fn(*xs)
+        assert type(out.grad_fn).__name__.endswith("Backward") and "_" in type(out.grad_fn).__name__, (what, out.grad_fn)
+        w = torch.randn(out.shape, generator=g).to(DEV)
+        (out * w).sum().backward()
+        rs = [t.clone().double().requires_grad_(i in grads_for) for i, t in enumerate(inputs)]
+        ref = ref_fn(*rs)
+        (ref * w.double().cpu()).sum().backward()
+        close(ref, out, tol, what + " value")
+        for i in grads_for:
+            assert xs[i].grad.shape == xs[i].shape and xs[i].grad.dtype == xs[i].dtype
+            close(rs[i].grad, xs[i].grad, tol if xs[i].dtype == torch.float32 else 1e-2, "%s grad %d" % (what, i))
+
+    for n in (1, 5, 32, 1000):
+        real, fake = torch.randn(n, generator=g) * 2, torch.randn(n, generator=g) * 2
+        real[0], fake[0] = -1.0, 1.0  # the kink: relu'(0) = 0
+        check(ops.hinge_loss, lambda r, f: (F.relu(1 + r) + F.relu(1 - f)).mean(), (real, fake), (0, 1), "hinge n=%d" % n)
+        check(ops.gen_hinge_loss, lambda f: f.mean(), (fake,), (0,), "gen hinge n=%d" % n)
+    for b, l, d in ((1, 1, 1), (5, 7, 514), (32, 6, 514)):
+        pg = torch.randn(b, l, d, generator=g) * 0.1
+        check(ops.pl_lengths, lambda t: (t ** 2).sum(dim=2).mean(dim=1).sqrt(), (pg,), (0,), "pl_lengths %s" % ((b, l, d),))
+    for b, k in ((1, 2), (32, 2), (33, 5), (300, 17)):
+        r, f = torch.randn(b, k, generator=g) * 3, torch.randn(b, k, generator=g) * 3
+        check(ops.kl_logits, lambda a, c: F.kl_div(F.log_softmax(c, dim=1), F.log_softmax(a, dim=1), reduction="batchmean",
+                                                   log_target=True), (r, f), (0, 1), "kl %s" % ((b, k),), tol=5e-6)
+    # L1: same layout, both gradients
+    a, b_ = torch.randn(7, 512, generator=g), torch.randn(7, 512, generator=g)
+    b_[0, :4] = a[0, :4]  # sign(0) = 0
+    check(ops.l1_mean, lambda x, y: (x - y).abs().mean(), (a, b_), (0, 1), "l1 2-d")
+    # the reconstruction term: NCHW real batch (no gradient) against the [:, :3] slice of a 4-channel channels-last batch
+    real = torch.rand(3, 3, 20, 12, generator=g)
+    gen4 = torch.randn(3, 4, 20, 12, generator=g)
+    xr = real.to(DEV)
+    x4 = gen4.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gen = x4[:, :3]  # the generator's fp32-mode output: a view with a 4-element pixel stride
+    assert not gen.is_contiguous() and not gen.permute(0, 2, 3, 1).is_contiguous()
+    out = ops.l1_mean(xr, gen)
+    assert type(out.grad_fn).__name__ == "_L1MeanBackward"
+    out.backward()
+    r4 = gen4.clone().double().requires_grad_()
+    ref = (real.double() - r4[:, :3]).abs().mean()
+    ref.backward()
+    close(ref, out, tol, "l1 strided value")
+    close(r4.grad, x4.grad, tol, "l1 strided grad")
+    # the bf16 mode's output: a dense channels-last copy of that slice
+    x4b = gen4.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    genb = x4b[:, :3].contiguous(memory_format=torch.channels_last)
+    assert genb.permute(0, 2, 3, 1).is_contiguous() and not genb.is_contiguous()
+    out = ops.l1_mean(xr, genb)
+    assert type(out.grad_fn).__name__ == "_L1MeanBackward"
+    out.backward()
+    rb = gen4.clone().double().requires_grad_()
+    refb = (real.double() - rb[:, :3]).abs().mean()
+    refb.backward()
+    close(refb, out, tol, "l1 channels-last value")
+    close(rb.grad, x4b.grad, tol, "l1 channels-last grad")
+    # gradient INTO the strided operand, and a bf16 operand
+    ar = real.to(DEV).requires_grad_()
+    out = ops.l1_mean(ar, gen.detach().contiguous(memory_format=torch.channels_last))
+    out.backward()
+    rr = real.clone().double().requires_grad_()
+    (rr - gen4[:, :3].double()).abs().mean().backward()
+    assert ar.grad.stride() == ar.stride()
+    close(rr.grad, ar.grad, tol, "l1 grad of the strided operand")
+    hb16 = torch.randn(4, 8, 6, 6, generator=g).bfloat16()
+    check(ops.l1_mean, lambda x, y: (x - y).abs().mean(), (torch.randn(4, 8, 6, 6, generator=g), hb16.float()), (0, 1), "l1 f32")
+    xb = hb16.to(DEV).requires_grad_()
+    xa = torch.randn(4, 8, 6, 6, generator=g)
+    out = ops.l1_mean(xa.to(DEV), xb)
+    out.backward()
+    close((xa.double() - hb16.double()).abs().mean(), out, tol, "l1 bf16 value")
+    assert xb.grad.dtype == torch.bfloat16
+    close(-torch.sign(xa.double() - hb16.double()) / xa.numel(), xb.grad, 1e-2, "l1 bf16 grad")
+    # not expressible as a walk (broadcast operand): the torch composition answers
+    out = ops.l1_mean(torch.zeros(1, 8, 1, 1, device=DEV).expand(4, 8, 6, 6), xb.detach().float())
+    close(hb16.double().abs().mean(), out, 1e-6, "l1 broadcast fallback")

@@ -60,7 +60,7 @@ def main():
     tot = [0.0, 0.0, 0.0]
     totf = 0.0
     for (name, c, n, res, k, s, p) in layers(a.size):
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         cp = c
         if c == 3:  # the product pads RGB to one 16-byte slot (ops._pad_rgb)
