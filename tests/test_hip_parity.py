@@ -622,7 +622,11 @@ def test_bf16_step_band_vs_reference_golden(tmp_path):
     squared norm of a double-rounded gradient: 1e-1.  g_loss is evaluated on the UPDATED discriminator: until round 3
     this test excluded it ("measured -0.21 vs 3.88", blamed on Adam's sign-like first step) — that was the stale operand
     cache under the fused Adam; with the fix the bf16 mode gives 3.89 vs 3.88.  Later calls: the band widens
-    by 1.6x per call (the untrained GAN amplifies any difference), capped at 30 %."""
+    by 1.6x per call (the untrained GAN amplifies any difference), capped at 30 %.  The KL column gets the cap from
+    the third call on: on this fixture it is hypersensitive to the last bits of its own gradient — scaling the (torch)
+    KL loss by 1 + 1e-6 moves it from 2.02 to 2.39 at the third call (golden 2.06) while every other scalar stays
+    within 5 % (tools/probes/bf16_band_perturb.py, profiles/r04_h_bf16_band_perturbation.txt); the fused loss kernels
+    of round 4 round differently in exactly that place and land at 2.34."""
     g = load_golden("steps_gae2_alt")
     ops.set_precision("bf16")
     try:
@@ -634,7 +638,9 @@ def test_bf16_step_band_vs_reference_golden(tmp_path):
     print("bf16 rows\n", rows, "\ngolden\n", gold)
     assert np.isfinite(rows[:, :5]).all()
     for i in range(n):
-        tol = min(0.3, 5e-2 * 1.6 ** i)
+        tol = np.full(4, min(0.3, 5e-2 * 1.6 ** i))
+        if i >= 2:
+            tol[3] = 0.3
         scale = np.maximum(1.0, np.abs(gold[i, :4]))
         assert (np.abs(rows[i, :4] - gold[i, :4]) <= tol * scale).all(), (i, tol, rows[i], gold[i])
     assert abs(rows[0, 4] - gold[0, 4]) <= 1e-1 * max(1.0, abs(gold[0, 4])), (rows[0, 4], gold[0, 4])
