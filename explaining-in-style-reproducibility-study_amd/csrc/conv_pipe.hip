@@ -307,56 +307,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
         const unsigned t_off = __builtin_amdgcn_readfirstlane((unsigned)((((long)(b * H + y0) * W + x0) * N + n0) * 2));
         // operand-side addressing (gates, bit masks): pixel li, pieces (j, q, lh) — the layout before the transpose
         const unsigned g_off = x0 + li < W ? (unsigned)(((4 * rg) * W + li) * N + nh * 64 + 8 * lh) * 2u : OOB;
-        // GATE OPERANDS ARE LOADED AHEAD OF THE STORES THAT PRECEDE THEIR USE.  vmcnt counts loads and stores in one
-        // in-order queue: a gate load issued after the previous row's four stores cannot be waited for without waiting
-        // for those stores (and for every DMA piece of the next tile issued before them) — the first version did that
-        // once per row, and the gated launches ran 1.4-1.5x the ungated ones.  Bit masks (EPI 2): all 16 bytes of the
-        // tile up front, one wait.  Gate tensors (EPI 1): row i+1's four 16-byte loads are issued before row i's stores.
-        unsigned gm_all[4][2][2];
-        u32x4 gv_next[2][2];
-        auto load_gates = [&](int i, u32x4 (&dst)[2][2]) {
-            const unsigned voff = (y0 + 4 * rg + i < H) ? g_off : OOB;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    dst[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rgate, voff + (j * 64 + q * 32), t_off + i * rowb, 0);
-        };
-        if (EPI == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned voff = (y0 + 4 * rg + i < H) ? g_off : OOB;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        gm_all[i][j][q] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (voff >> 4) + (j * 4 + q * 2), (t_off + i * rowb) >> 4, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (EPI == 1) load_gates(0, gv_next);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool row_ok = y0 + 4 * rg + i < H;
             const unsigned soff = t_off + i * rowb;
             u32x4 R[4];  // R[2j + q]
-            u32x4 gv_cur[2][2];
-            if (EPI == 1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) gv_cur[j][q] = gv_next[j][q];
-                if (i + 1 < 4) load_gates(i + 1, gv_next);
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 u32x4 gv[2];
                 unsigned gm[2];
+                if (EPI != 0) {
+                    const unsigned voff = row_ok ? g_off : OOB;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (EPI == 1) gv[q] = gv_cur[j][q];
-                    if (EPI == 2) gm[q] = gm_all[i][j][q];
+                    for (int q = 0; q < 2; ++q) {
+                        if (EPI == 1) gv[q] = __builtin_amdgcn_raw_buffer_load_b128(rgate, voff + (j * 64 + q * 32), soff, 0);
+                        if (EPI == 2) gm[q] = __builtin_amdgcn_raw_buffer_load_b8(rmask, (voff >> 4) + (j * 4 + q * 2), soff >> 4, 0);
+                    }
                 }
                 float4 b4[4];
 #pragma unroll

@@ -30,7 +30,7 @@ def timeit(fn, iters=20):
 
 mk = lambda *sh: torch.randn(*sh, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
 print("%-34s %9s %9s" % ("launch (B=64)", "tensor ms", "mask ms"))
-for C, N, S in ((64, 64, 256), (128, 128, 128), (256, 256, 64), (8, 64, 256)):
+for C, N, S in ((64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512, 32), (8, 64, 256)):
     B = 64
     x = mk(B, C, S, S)
     w = torch.randn(N, C, 3, 3, device=dev) / (9 * C) ** 0.5
