@@ -456,7 +456,9 @@ int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return STYLEX_NOT_APPLICABLE;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return STYLEX_NOT_APPLICABLE;
     {
-        int rc = stylex_launch_pipe(p, s);
+        int rc = stylex_launch_line64(p, s);  // 64 -> 64 channels at >= 128^2: whole-line DMA, weights resident in LDS
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+        rc = stylex_launch_pipe(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
         rc = stylex_launch_halo_dma(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;

@@ -86,6 +86,7 @@ int stylex_launch_rgb(const ConvKParams& p, hipStream_t s);
 
 // persistent, software-pipelined LDS-DMA kernel for the unmodulated 3x3/s1 layers (conv_pipe.hip)
 int stylex_launch_pipe(const ConvKParams& p, hipStream_t s);
+int stylex_launch_line64(const ConvKParams& p, hipStream_t s);
 
 // LDS-DMA implicit GEMM for the <= 8x8 px layers (conv_gather.hip): writes fp32 partials and fills p.ksplit / p.partial
 // for the split-K epilogue kernel

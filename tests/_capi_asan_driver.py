@@ -75,7 +75,7 @@ for b, h, c, n in ((2, 32, 64, 64), (64, 128, 64, 64), (64, 64, 128, 128), (64, 
 # real calls on host buffers (small shapes): every launcher's applicability logic + the launch attempt itself
 for (b, h, c, n, k, stride, pad), prec, flagset in itertools.product(
         ((1, 8, 16, 24, 3, 1, 1), (2, 16, 64, 64, 3, 1, 1), (1, 32, 64, 64, 3, 1, 1), (2, 16, 8, 64, 3, 1, 1), (1, 8, 64, 64, 3, 2, 1),
-         (2, 8, 32, 8, 1, 1, 0), (1, 4, 512, 512, 3, 1, 1), (1, 16, 16, 16, 1, 2, 0), (1, 32, 128, 128, 3, 1, 1)),
+         (2, 8, 32, 8, 1, 1, 0), (1, 4, 512, 512, 3, 1, 1), (1, 16, 16, 16, 1, 2, 0), (1, 32, 128, 128, 3, 1, 1), (1, 128, 64, 64, 3, 1, 1)),
         (0, 1, 2), (0, EPI["BIAS"] | EPI["LRELU"], EPI["BIAS"] | EPI["OSCALE"] | EPI["NOISE"] | EPI["LRELU"])):
     sh, ho, wo = conv_shape(b, h, h, c, n, k, stride, pad)
     es = 2 if prec == 2 else 4

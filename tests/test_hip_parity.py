@@ -1433,17 +1433,83 @@ def test_pipelined_conv_kernel_matches_per_tile_kernel(case):
             assert torch.equal(outs[-1], outs[2]), "mask-gated data gradient differs from the tensor-gated one"
         return outs
 
+    os.environ["STYLEX_CONV_LINE64"] = "0"  # the 64 -> 64 kernel of round 4 would take the large 64-channel cases from both arms
     os.environ["STYLEX_CONV_PIPE"] = "0"
     try:
         ref = run()
+        os.environ.pop("STYLEX_CONV_PIPE", None)
+        got = run()
     finally:
         os.environ.pop("STYLEX_CONV_PIPE", None)
-    got = run()
+        os.environ.pop("STYLEX_CONV_LINE64", None)
     assert len(ref) == len(got) and len(got) >= 3
     for k, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), "output %d: max diff %g" % (k, float((a.float() - b.float()).abs().max()))
     yr = F.leaky_relu(F.conv2d(x.float(), w.to(torch.bfloat16).float(), bias, 1, 1), 0.2)
     close(yr, got[0].float(), 1e-2, "pipe fwd vs fp32 definition")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [(2, 128, 128), (1, 256, 256), (5, 128, 160), (3, 256, 128), (67, 128, 128)])
+def test_line64_conv_kernel_matches_pipelined_kernel_and_definition(case):
+    """conv_line64.hip (round 4: 64 -> 64 channels at >= 128^2, whole-pixel K stage, weights resident in LDS) against the
+    pipelined kernel on the same inputs (STYLEX_CONV_LINE64=0) and against the fp32 definition: forward with bias +
+    LeakyReLU + activation bit mask, plain data gradient, data gradient gated by a bit mask.  The two kernels add the
+    same products in a different order (tap-major over whole pixels against 16-channel chunks), so results agree to the
+    bf16 rounding of the output (<= 1 ulp on a small fraction of elements), not bit for bit; the mask must be the sign
+    of the kernel's OWN output; a second run is bit-identical (fixed order, no atomics).  Cases: fewer tiles than CUs,
+    several tiles per block (67 x 64 = 4288 tiles), non-square images."""
+    import os
+
+    B, H, W = case
+    C = N = 64
+    ops.set_precision("bf16")
+    P = hb.BF16_ACT
+    g = torch.Generator(device=DEV).manual_seed(35)
+    mk = lambda *sh: torch.randn(*sh, device=DEV, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, dy, gate = mk(B, C, H, W), mk(B, N, H, W), mk(B, C, H, W)
+    w = torch.randn(N, C, 3, 3, device=DEV, generator=g) / (9 * C) ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    bits = (gate.permute(0, 2, 3, 1).float() > 0).reshape(B, H, W, C // 8, 8).to(torch.int32)
+    gmask = (bits * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous()
+
+    def run():
+        hb.timing_enable(True)
+        y, m = hb.conv2d_fwd(x, w, 1, 1, P, bias=bias, lrelu=True, want_mask=True)
+        outs = [y, m, hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P), hb.conv2d_bwd_data(dy, w, (B, C, H, W), 1, 1, P, gate_mask=gmask)]
+        torch.cuda.synchronize()
+        names = [k["kernel"] for k in hb.timing_kernels()]
+        hb.timing_enable(False)
+        return outs, names
+
+    os.environ["STYLEX_CONV_LINE64"] = "0"
+    try:
+        ref, ref_names = run()
+    finally:
+        os.environ.pop("STYLEX_CONV_LINE64", None)
+    got, names = run()
+    again, _ = run()
+    assert any("line64" in n for n in names) and not any("line64" in n for n in ref_names), (names, ref_names)
+    for k in (0, 2, 3):
+        a, b = ref[k].float(), got[k].float()
+        # one bf16 step at the magnitude of the element; near zero the two summation orders differ by the fp32 rounding of
+        # sums of O(1) terms (~1e-6) whatever the size of the result
+        # (the gated data gradient rounds twice — the sum, then its gate-scaled value — so a one-step difference of the
+        # first rounding can become two steps of the result)
+        ulp = (a.abs() * (2.0 ** -6 if k == 3 else 2.0 ** -7)).clamp_min(2e-5)
+        d = (a - b).abs()
+        assert bool((d <= ulp).all()), "output %d: max diff %g" % (k, float(d.max()))
+        assert float((d > 0).float().mean()) < 0.05, "output %d: %g of the elements differ" % (k, float((d > 0).float().mean()))
+        assert torch.equal(got[k], again[k]), "output %d is not reproducible" % k
+    ybits = (got[0].permute(0, 2, 3, 1).float() > 0).reshape(B, H, W, N // 8, 8).to(torch.int32)
+    want_mask = (ybits * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8)
+    assert torch.equal(got[1].reshape(-1), want_mask.reshape(-1)), "mask is not the sign of the stored output"
+    if B <= 5:
+        wb = w.to(torch.bfloat16).float()
+        close(F.leaky_relu(F.conv2d(x.float(), wb, bias, 1, 1), 0.2), got[0].float(), 1e-2, "line64 fwd vs fp32 definition")
+        dxr = F.conv_transpose2d(dy.float(), wb, None, 1, 1)
+        close(dxr, got[2].float(), 1e-2, "line64 dgrad vs fp32 definition")
+        close(torch.where(gate.float() > 0, dxr, 0.2 * dxr), got[3].float(), 1e-2, "line64 gated dgrad vs fp32 definition")
     torch.cuda.synchronize()
 
 

@@ -19,6 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     ("conv_halo_dma.hip", ["conv3x3_halo_dma_kernelILi2ELb1", "conv3x3_halo_dma_kernelILi2ELb0", "conv3x3_halo_dma_kernelILi1ELb0"]),
     ("conv_pipe.hip", ["conv3x3_pipe_kernelILi128ELi0", "conv3x3_pipe_kernelILi64ELi0", "conv3x3_pipe_kernelILi128ELi2"]),
     ("adam_pack.hip", ["adam_pack_kernel"]),
+    ("conv_line64.hip", ["conv3x3_line64_kernelILi0", "conv3x3_line64_kernelILi2"]),
 ])
 def test_hot_kernels_use_no_scratch(tmp_path, source, kernels):
     out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
