@@ -63,7 +63,11 @@ class ResNet:
         classifier signal to be the default)."""
         if not x.is_cuda:
             return self.model
-        if os.environ.get("STYLEX_FROZEN_HIP", "0") != "1":
+        mode = os.environ.get("STYLEX_FROZEN_HIP", "0")
+        # "nograd" (opt-in, round 4): the HIP kernels only where no gradient is asked of the classifier — the logits of
+        # REAL images (conditioning + KL target: 2 of its 3 forward passes per encoder micro-step); the pass on generated
+        # images, whose input gradient trains G, stays on the library's fp32 convolutions
+        if not (mode == "1" or (mode == "nograd" and not x.requires_grad)):
             # default: the library's fp32 convolutions, everything between them (eval BatchNorm, ReLU, residual add,
             # max-pool) on the fused fp32 kernels of csrc/frozen_ew.hip; STYLEX_FROZEN_FUSE=0 = the plain nn.Module
             if os.environ.get("STYLEX_FROZEN_FUSE", "1") == "0":
