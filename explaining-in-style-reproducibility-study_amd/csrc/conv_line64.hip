@@ -295,7 +295,8 @@ int launch_line(const ConvKParams& p, hipStream_t s) {
 int stylex_launch_line64(const ConvKParams& p, hipStream_t s) {
     const char* env = getenv("STYLEX_CONV_LINE64");
     if (env && env[0] == '0') return STYLEX_NOT_APPLICABLE;
-    if (!p.act_bf16 || p.a_scale || p.s2d_c || p.Ck != 64 || p.N != 64) return STYLEX_NOT_APPLICABLE;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return STYLEX_NOT_APPLICABLE;
+    if (!p.act_bf16 || p.a_scale || p.out_scale || p.noise || p.s2d_c || p.Ck != 64 || p.N != 64) return STYLEX_NOT_APPLICABLE;
     if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | STYLEX_EPI_GATE_MASK | STYLEX_EPI_MASK_OUT)) return STYLEX_NOT_APPLICABLE;
     if ((p.flags & STYLEX_EPI_GATE_MASK) && (p.flags & (STYLEX_EPI_BIAS | STYLEX_EPI_LRELU | STYLEX_EPI_RELU | STYLEX_EPI_MASK_OUT)))
         return STYLEX_NOT_APPLICABLE;
