@@ -1150,6 +1150,22 @@ __global__ void bias_partial_reduce_kernel(const float* __restrict__ part, float
 
 int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s, float* db, int* db_done) {
     if (db_done) *db_done = 0;
+    if (precision == STYLEX_BF16 && stylex_wgrad_pipe_applicable(p)) {
+        int slices = 0, tps, blocks, bias_done = 0;
+        stylex_wgrad_pipe_plan(p, &slices, &tps, &blocks);
+        if (db) p.bias_partial = partial + (long)slices * p.N * 9 * p.Ck;  // behind the weight-gradient partials
+        int rc = stylex_launch_wgrad_pipe(p, partial, s, &slices, &bias_done);
+        if (rc != STYLEX_NOT_APPLICABLE) {
+            if (rc) return rc;
+            launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, slices, s);
+            if (db && bias_done) {
+                hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3((p.N + 255) / 256), dim3(256), 0, s, p.bias_partial, db, p.N, slices);
+                if (db_done) *db_done = 1;
+            }
+            return (int)hipGetLastError();
+        }
+        p.bias_partial = nullptr;
+    }
     if (precision == STYLEX_BF16 && stylex_wgrad_halo_applicable(p)) {
         int hs = 0, bias_done = 0;
         if (db) {  // the bias partials live behind the weight-gradient partials of this plan

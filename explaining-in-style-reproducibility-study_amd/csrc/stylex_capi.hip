@@ -458,6 +458,20 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
                 if (hs > splits) splits = hs;
             }
     }
+    {  // pipelined LDS-DMA plan (bf16 activations; with / without a per-sample x scale)
+        static const float dummy_scale[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sc = 0; sc < 2; ++sc) {
+            ConvKParams q = p;
+            q.act_bf16 = 1;
+            q.a = q.a2 = nullptr;
+            q.a_scale = sc ? dummy_scale : nullptr;
+            if (stylex_wgrad_pipe_applicable(q)) {
+                int sl, tps, blocks;
+                stylex_wgrad_pipe_plan(q, &sl, &tps, &blocks);
+                if (sl > splits) splits = sl;
+            }
+        }
+    }
     if (p.Ck % 8 == 0 && p.N % 8 == 0) {  // bf16-activation tr kernel plan
         int mode, ts;
         long tl;

@@ -98,6 +98,11 @@ bool stylex_wgrad_halo_applicable(const ConvKParams& p);
 void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);
 int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out, int* bias_done = nullptr);
 
+// round 5: pipelined LDS-DMA weight gradient of the 3x3/s1/p1 bf16 layers with whole 64-channel tiles (conv_wgrad_pipe.hip)
+bool stylex_wgrad_pipe_applicable(const ConvKParams& p);
+void stylex_wgrad_pipe_plan(const ConvKParams& p, int* slices, int* tiles_per_split, int* blocks);
+int stylex_launch_wgrad_pipe(ConvKParams p, float* partial, hipStream_t s, int* slices_out, int* bias_done = nullptr);
+
 // general bf16 weight gradient with LDS transpose reads (conv_wgrad_tr.hip)
 bool stylex_wgrad_tr_applicable(const ConvKParams& p);
 void stylex_wgrad_tr_plan(const ConvKParams& p, int* mode, int* splits, long* split_len);

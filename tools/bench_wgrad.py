@@ -1,0 +1,136 @@
+"""Weight-gradient kernels A/B: the round-5 pipelined LDS-DMA kernel (conv_wgrad_pipe.hip) against the kernels it
+replaces (STYLEX_WGRAD_PIPE=0), per layer shape of the 256 px StylEx networks — results compared with each other and,
+on small batches, with an fp64 torch reference; times by hipEvents.
+Usage (GPU box): python tools/bench_wgrad.py [--batch 64] [--iters 20] [--check-only]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd")
+sys.path[:0] = [os.path.join(PKG, "stylex"), PKG]
+import torch  # noqa: E402
+
+import hip_backend as hb  # noqa: E402
+
+# (name, C, N, res) — the 3x3 / stride-1 layers of G, D and the encoder at 256 px with >= 64 channels on both sides
+SHAPES = [
+    ("64->64@256", 64, 64, 256),
+    ("64->128@128", 64, 128, 128),
+    ("128->128@128", 128, 128, 128),
+    ("128->64@128", 128, 64, 128),
+    ("64->64@128", 64, 64, 128),
+    ("128->256@64", 128, 256, 64),
+    ("256->256@64", 256, 256, 64),
+    ("256->128@64", 256, 128, 64),
+    ("128->128@64", 128, 128, 64),
+    ("256->512@32", 256, 512, 32),
+    ("512->512@32", 512, 512, 32),
+    ("512->256@32", 512, 256, 32),
+    ("256->256@32", 256, 256, 32),
+    ("512->512@16", 512, 512, 16),
+]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def ref_wgrad(x, dy, scale=None):
+    """fp64 definition: dW[n][c][kh][kw] = sum dy[b,n,y,x] * (x*scale)[b,c,y+kh-1,x+kw-1]"""
+    xd = x.double()
+    if scale is not None:
+        xd = xd * scale.double()[:, :, None, None]
+    dyd = dy.double()
+    xp = torch.nn.functional.pad(xd, (1, 1, 1, 1))
+    b, c, h, w = xd.shape
+    n = dyd.shape[1]
+    out = torch.empty(n, c, 3, 3, dtype=torch.float64, device=x.device)
+    for kh in range(3):
+        for kw in range(3):
+            out[:, :, kh, kw] = torch.einsum("bnyx,bcyx->nc", dyd, xp[:, :, kh:kh + h, kw:kw + w])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--new-only", action="store_true", help="time the new kernel only (PMC runs)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    prec = hb.BF16_ACT
+    dev = "cuda:0"
+    torch.manual_seed(0)
+
+    # ---- correctness first: small batches against the fp64 definition, with / without bias sums and an x scale
+    worst = 0.0
+    for (name, c, n, res) in ([] if a.no_check else SHAPES):
+        if a.only and a.only not in name:
+            continue
+        for (b, with_scale, with_bias) in ((2, False, True), (3, True, False)):
+            x = torch.randn(b, c, res, res, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(b, n, res, res, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            sc = (torch.rand(b, c, device=dev) + 0.5) if with_scale else None
+            ref = ref_wgrad(x.float(), dy.float(), sc)
+            outs = {}
+            for mode in ("1", "0"):
+                os.environ["STYLEX_WGRAD_PIPE"] = mode
+                r = hb.conv2d_bwd_weight(x, dy, (n, c, 3, 3), 1, 1, prec, x_scale=sc, want_bias_sum=with_bias)
+                dw, db = r if with_bias else (r, None)
+                torch.cuda.synchronize()
+                err = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
+                outs[mode] = err
+                if with_bias and db is not None:
+                    dbr = dy.double().sum((0, 2, 3))
+                    eb = ((db.double() - dbr).abs().max() / dbr.abs().max()).item()
+                    outs[mode + "b"] = eb
+            worst = max(worst, outs["1"], outs.get("1b", 0.0))
+            print("%-14s B=%d scale=%d bias=%d | rel err new %.2e old %.2e%s" % (
+                name, b, with_scale, with_bias, outs["1"], outs["0"],
+                (" | bias new %.2e old %s" % (outs["1b"], ("%.2e" % outs["0b"]) if "0b" in outs else "n/a")) if "1b" in outs else ""))
+    if not a.no_check:
+        print("worst relative error of the new kernel: %.3e" % worst)
+    assert worst < 2e-5, worst  # same bf16 operands, fp32 accumulation: only the summation order differs
+    if a.check_only:
+        return
+
+    # ---- times
+    print("%-14s %5s | %9s %9s | %7s %7s | speed-up" % ("layer", "B", "new ms", "old ms", "new TF", "old TF"))
+    tot = [0.0, 0.0]
+    for (name, c, n, res) in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        for b in ((a.batch, 2 * a.batch) if res >= 64 else (a.batch,)):
+            if b * res * res * max(c, n) * 2 >= 1.4 * 2 ** 30:
+                continue
+            x = torch.randn(b, c, res, res, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(b, n, res, res, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            t = {}
+            for mode in (("1",) if a.new_only else ("1", "0", "1", "0")):
+                os.environ["STYLEX_WGRAD_PIPE"] = mode
+                fn = lambda: hb.conv2d_bwd_weight(x, dy, (n, c, 3, 3), 1, 1, prec, want_bias_sum=True)
+                t[mode] = min(t.get(mode, 1e9), timeit(fn, a.iters))
+            fl = 2.0 * b * res * res * n * c * 9
+            t.setdefault("0", float("nan"))
+            print("%-14s %5d | %9.3f %9.3f | %7.1f %7.1f | %.2fx" % (name, b, t["1"], t["0"], fl / t["1"] / 1e9, fl / t["0"] / 1e9,
+                                                                    t["0"] / t["1"]))
+            if b == a.batch:
+                tot[0] += t["1"]
+                tot[1] += t["0"]
+            del x, dy
+    print("TOTAL at B=%d: new %.3f ms, old %.3f ms (%.2fx)" % (a.batch, tot[0], tot[1], tot[1] / tot[0]))
+
+
+if __name__ == "__main__":
+    main()
