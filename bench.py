@@ -99,11 +99,38 @@ def layer_roofline(layers, precision, top=14):
     return {"mixed_frac": round(t_min / t_all, 4) if t_all else None,
             "note": "sum over layers of max(FLOPs/peak_mfma, bytes/peak_hbm) / measured time; per-layer frac likewise",
             "layers": rows[:top]}
-G_FWD, D_FWD, E_FWD = 17.767, 35.511, 35.513  # conv GFLOP per image @256 px
 
 
-def algorithmic_gflop_per_image(gae):
-    """Bench A (GAE=1) 4G+8.75D = 381.8; Bench B (GAE=2) (8G+17.5D+7E)/2 = 506.1."""
+def conv_gflop_forward(image_size, network_capacity=16, fmap_max=512):
+    """Forward conv GFLOP per image of G, D and the encoder from the layer lists (reference Generator :747-825,
+    DiscriminatorE :842-909): 17.767 / 35.511 / 35.513 @256 px, 4.46 / 8.88 @128, 1.13 / 2.22 @64."""
+    from math import log2
+
+    n = int(log2(image_size) - 1)
+    f = [min(fmap_max, network_capacity * 2 ** (i + 1)) for i in range(n)][::-1]
+    gfil = [f[0]] + f
+    g = 2 * 4 * 4 * gfil[0] * gfil[0] * 9  # initial_conv
+    for i in range(n):
+        res, cin, cout = 4 * 2 ** i, gfil[i], gfil[i + 1]
+        g += 2 * res * res * (cin * cout * 9 + cout * cout * 9 + cout * 3)  # conv1, conv2, to_rgb
+    dfil = [3] + [min(fmap_max, 4 * network_capacity * 2 ** i) for i in range(n + 1)]
+    d = 0
+    for i in range(len(dfil) - 1):
+        res, cin, cout, last = image_size // 2 ** i, dfil[i], dfil[i + 1], i == len(dfil) - 2
+        ro = res if last else res // 2
+        d += 2 * ro * ro * cin * cout + 2 * res * res * (cin * cout * 9 + cout * cout * 9)  # conv_res, conv1, conv2
+        if not last:
+            d += 2 * ro * ro * cout * cout * 9  # down-sampling conv
+    rl = image_size // 2 ** (len(dfil) - 2)
+    d += 2 * rl * rl * dfil[-1] * dfil[-1] * 9  # final_conv
+    e = d + 2 * (rl * rl * dfil[-1]) * 511  # the encoder's fc is 512 wide instead of 1
+    return g / 1e9, d / 1e9, e / 1e9
+
+
+def algorithmic_gflop_per_image(gae, image_size=256, network_capacity=16, fmap_max=512):
+    """Bench A (GAE=1) 4G+8.75D = 381.8 @256 px; Bench B (GAE=2) (8G+17.5D+7E)/2 = 506.1 @256 px,
+    126.6 @128 px, 31.7 @64 px (round 4 used the 256 px constants at every --image-size)."""
+    G_FWD, D_FWD, E_FWD = conv_gflop_forward(image_size, network_capacity, fmap_max)
     if gae == 1:
         return 4 * G_FWD + 8.75 * D_FWD
     noise = (G_FWD + 6 * D_FWD) + (3 * G_FWD + 2 * D_FWD) + 0.75 * D_FWD
@@ -123,8 +150,8 @@ def build_trainer(args, device, rank, world):
     gen = torch.Generator().manual_seed(7 + rank)
     ring = [torch.rand(args.batch, 3, args.image_size, args.image_size, generator=gen).to(device) for _ in range(8)]
     seed_all(42)
-    tr = st.Trainer(name="bench", base_dir=args.workdir, image_size=args.image_size, network_capacity=16,
-                    fmap_max=512, batch_size=args.batch * world, gradient_accumulate_every=args.gae, lr=2e-4,
+    tr = st.Trainer(name="bench", base_dir=args.workdir, image_size=args.image_size,
+                    network_capacity=getattr(args, "network_capacity", 16), fmap_max=getattr(args, "fmap_max", 512), batch_size=args.batch * world, gradient_accumulate_every=args.gae, lr=2e-4,
                     ttur_mult=1.5, mixed_prob=0.9, rec_scaling=1, kl_scaling=1, aug_prob=0.,
                     alternating_training=True, classifier_name=args.classifier, classifier_path=None,
                     evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None,
@@ -189,9 +216,82 @@ def fp32_record(args, device, tr_old):
             "ms_per_step": round(dt / args.fp32_steps * 1e3, 2), "dtype": "fp32",
             "class_achieved_tflops": round(ach, 2), "peak": PEAK_TFLOPS["fp32"],
             "class_frac": round(ach / PEAK_TFLOPS["fp32"], 4),
-            "whole_step_frac": round(algorithmic_gflop_per_image(args.gae) * value / 1e3 / PEAK_TFLOPS["fp32"], 4),
+            "whole_step_frac": round(algorithmic_gflop_per_image(args.gae, args.image_size, args.network_capacity, args.fmap_max) * value / 1e3 / PEAK_TFLOPS["fp32"], 4),
             "note": "same workload in the exact-fp32 MFMA mode of the parity tests; class = forward + data-gradient conv "
                     "launches of one plain instrumented step"}
+
+
+def bench_a_record(args, device):
+    """Bench A of SURVEY §8(d) — the "G+D step" BASELINE.md §4 quotes the >= 60 % roofline target on: the same
+    workload at gradient_accumulate_every = 1 (noise micro-step only), timed like the headline (N = 1 only)."""
+    import copy
+
+    a = copy.copy(args)
+    a.gae, a.graphs = 1, 0
+    tr = build_trainer(a, device, 0, 1)
+    for _ in range(4):
+        tr.train()
+    tr.steps = args.start_step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.bench_a_steps):
+        tr.train()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del tr
+    torch.cuda.empty_cache()
+    value = args.batch * args.bench_a_steps / dt
+    gf = algorithmic_gflop_per_image(1, args.image_size, args.network_capacity, args.fmap_max)
+    return {"workload": "Bench A: same shapes, gradient_accumulate_every = 1 (noise micro-step only), GP every 4th call",
+            "value": round(value, 2), "unit": "images/sec", "steps": args.bench_a_steps,
+            "ms_per_step": round(dt / args.bench_a_steps * 1e3, 2), "algorithmic_conv_gflop_per_image": round(gf, 1),
+            "step_conv_tflops": round(gf * value / 1e3, 2),
+            "whole_step_frac": round(gf * value / 1e3 / PEAK_TFLOPS[args.precision], 4)}
+
+
+def frozen_split(args, tr, device, iters=6):
+    """How the frozen networks' time splits (round-4 VERDICT item 7c): the classifier FORWARD (the part north_star pins
+    to stock PyTorch-ROCm), the classifier's data-gradient pass and LPIPS-AlexNet (forward on two batches + backward),
+    each timed alone on the benchmark's batch shape with hipEvents and weighted with its calls per train() call
+    (encoder micro-step: classifier forward x3 of which one is differentiated, LPIPS x1; stylex_train.py:1086-1145)."""
+    import stylex_train as st
+
+    g = torch.Generator(device=device).manual_seed(3)
+    x = torch.rand(args.batch, 3, args.image_size, args.image_size, device=device, generator=g)
+    y = torch.rand(args.batch, 3, args.image_size, args.image_size, device=device, generator=g)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def cls_fwd():
+        with torch.no_grad():
+            tr.classifier.classify_images(st._frozen_layout(x))
+
+    def cls_fwd_bwd():
+        xi = x.clone().requires_grad_(True)
+        tr.classifier.classify_images(st._frozen_layout(xi)).sum().backward()
+
+    def lp_fwd_bwd():
+        yi = y.clone().requires_grad_(True)
+        st.perceptual_loss(x, yi, tr.lpips_fn).backward()
+
+    t_f, t_fb, t_lp = timed(cls_fwd), timed(cls_fwd_bwd), timed(lp_fwd_bwd)
+    enc_steps = args.gae // 2  # encoder micro-steps per phase; the classifier / LPIPS run in the generator phase only
+    return {"classifier_forward_ms_per_call": round(t_f, 3), "classifier_forward_backward_ms_per_call": round(t_fb, 3),
+            "lpips_forward_backward_ms_per_call": round(t_lp, 3),
+            "per_step_ms": {"classifier_forward (stock, north_star)": round(enc_steps * (2 * t_f + min(t_f, t_fb)), 3),
+                            "classifier_data_gradient": round(enc_steps * max(0.0, t_fb - t_f), 3),
+                            "lpips_alexnet": round(enc_steps * t_lp, 3)},
+            "note": "each part alone on the GPU (no overlap with other streams), batch %d @%d px, %d encoder micro-step(s) "
+                    "per train() call" % (args.batch, args.image_size, enc_steps)}
 
 
 def cpu_baseline(args):
@@ -238,7 +338,10 @@ def cpu_baseline(args):
                       % (args.image_size, bs, args.gae, t_gp, t_plain)}
 
 
-def main():
+def main(argv=None, backend="nccl", device=None):
+    """`backend` / `device` are overridden only by tests/test_ddp_gloo.py (2 ranks over gloo on the CPU test double): the
+    N > 1 plumbing below — barrier, MAX-reduce of the elapsed time, rank-0-only JSON line, process-group teardown — is
+    then the code a real `--gpus N` run executes, minus the kernels."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -248,6 +351,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--gae", type=int, default=2, help="gradient_accumulate_every (2 = noise + encoder micro-step)")
     ap.add_argument("--classifier", default="resnet")
+    ap.add_argument("--network-capacity", type=int, default=16)
+    ap.add_argument("--fmap-max", type=int, default=512)
     ap.add_argument("--workdir", default="/tmp/stylex_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--miopen-find", action="store_true",
@@ -259,6 +364,8 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=4)
     ap.add_argument("--fp32-steps", type=int, default=4,
                     help="timed train() calls of the fp32 parity mode for the fp32_parity_mode sub-record (0 = skip)")
+    ap.add_argument("--bench-a-steps", type=int, default=12,
+                    help="timed train() calls of Bench A (GAE = 1) for the bench_a sub-record (0 = skip; N = 1 only)")
     ap.add_argument("--graphs", type=int, default=int(os.environ.get("STYLEX_GRAPHS", "0")),
                     help="1 = replay the step as captured HIP graphs after the eager warm-up calls (0 = eager enqueue, "
                          "the default: at 256 px the step is GPU-bound and the capture of the multi-stream step is not "
@@ -272,7 +379,7 @@ def main():
     ap.add_argument("--host-share", type=int, default=int(os.environ.get("STYLEX_HOST_SHARE", "1")),
                     help="emulate the host share of one rank on an N-GPU node: pin this process (before anything touches "
                          "the GPU; no re-exec) to 1/N of the cores it may run on")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.host_share > 1:
         cores = sorted(os.sched_getaffinity(0))
         keep = cores[:max(1, len(cores) // args.host_share)]
@@ -282,9 +389,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda:%d" % local_rank)
+    on_gpu = device is None
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda:%d" % local_rank)
+
+    def dev_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
     # host side of a rank = kernel launches + the CPU RNG draws: a few threads per rank, not one pool per core per rank
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, world))))
     force_ddp = os.environ.get("STYLEX_FORCE_DDP") == "1"  # 1-rank RCCL smoke test of the N>1 code path
@@ -293,13 +407,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         # no device_id: the eager communicator set-up it triggers cost 3 % of step throughput on the 1-rank RCCL
         # path (584 vs 604 images/s); torch.cuda.set_device above already binds the rank to its GPU
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import hip_backend as hb
     import ops
 
-    hb.load_library()  # no fallback: fail loudly if the extension is missing
-    ops.set_precision(args.precision)
+    if on_gpu:
+        hb.load_library()  # no fallback: fail loudly if the extension is missing
+        ops.set_precision(args.precision)
     # The frozen classifier / LPIPS convolutions run on stock MIOpen in IMMEDIATE mode — the reference's setting
     # (cli.py:38) and what a `cli.py` training run of this package uses, so the headline number is the one a user gets.
     # Rounds 1-3 let MIOpen search during the warm-up (cudnn.benchmark); round 4 measured the two modes equal on this
@@ -312,7 +427,7 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     for _ in range(args.warmup):
         tr.train()
@@ -419,6 +534,13 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # ---- the frozen networks' share, part by part, and Bench A (N = 1 only)
+    frozen_rec = bench_a = None
+    if rank == 0 and world == 1 and args.roofline_steps > 0:
+        frozen_rec = frozen_split(args, tr, device)
+    if rank == 0 and world == 1 and args.bench_a_steps > 0 and args.gae != 1:
+        bench_a = bench_a_record(args, device)
+
     # ---- the fp32 parity mode on the same workload (N = 1 only): images/s and the class fraction of the fp32 MFMA peak
     fp32_rec = None
     if rank == 0 and world == 1 and args.fp32_steps > 0 and args.precision != "fp32":
@@ -430,7 +552,7 @@ def main():
         cpu = cpu_baseline(args)
 
     if rank == 0:
-        gf = algorithmic_gflop_per_image(args.gae)
+        gf = algorithmic_gflop_per_image(args.gae, args.image_size, args.network_capacity, args.fmap_max)
         line = {
             "metric": "StylEx G+D+enc train-step images/sec @%dpx" % args.image_size, "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -449,7 +571,8 @@ def main():
                                       if not args.miopen_find else "stock MIOpen fp32, algorithms searched during the warm-up"},
             "algorithmic_conv_gflop_per_image": round(gf, 1),
             "step_conv_tflops": round(gf * value / 1e3, 2),
-            "roofline": roof, "cpu_baseline": cpu, "fp32_parity_mode": fp32_rec,
+            "roofline": roof, "cpu_baseline": cpu, "fp32_parity_mode": fp32_rec, "bench_a": bench_a,
+            "frozen_nets": frozen_rec,
         }
         if roof is not None:
             roof["whole_step_frac"] = round(gf * value / 1e3 / PEAK_TFLOPS[args.precision], 4)

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(const stylex_adam_tensor
     const int n0 = (local / ncs) * SLAB_N, c0 = (local % ncs) * SLAB_C;
     const int nn = min(SLAB_N, N - n0), cw = min(SLAB_C, C - c0);
     const int row = cw * T;  // contiguous run of one output channel inside the slab
-    if ((row & 3) == 0 && ((C * T) & 3) == 0) {  // 16-byte accesses (every slab of the step's conv weights)
+    // 16-byte accesses (every slab of the step's conv weights) — only on 16-byte aligned tensors: under data parallelism
+    // the gradient is a view into a flat bucket (parallel.py aligns its views since round 5; any other caller's need not be)
+    const bool aligned16 = ((((uintptr_t)d.p | (uintptr_t)d.g | (uintptr_t)d.m | (uintptr_t)d.v) & 15) == 0);
+    if (aligned16 && (row & 3) == 0 && ((C * T) & 3) == 0) {
         const int row4 = row >> 2;
         for (int e = tid; e < nn * row4; e += 256) {
             const int nl = e / row4, r = (e - nl * row4) << 2;

@@ -263,13 +263,16 @@ unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsi
 
 template <int EPI>
 int launch_line(const ConvKParams& p, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    // 0 = not asked yet, 1 = granted, -1 = refused (a device with less than 160 KiB of LDS): the pipelined and per-tile
+    // kernels behind this one in stylex_launch_halo's dispatch then serve the launch
+    static int attr_state = 0;
+    if (attr_state == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_line64_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_state = e == hipSuccess ? 1 : -1;
+        if (e != hipSuccess) (void)hipGetLastError();
     }
+    if (attr_state < 0) return STYLEX_NOT_APPLICABLE;
     if (!g_line_cus) {
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);

@@ -486,6 +486,18 @@ def _adam_copies_of(p):
     return out
 
 
+_ADAM_COPY_OVERFLOW = False
+
+
+def adam_forget(opt=None):
+    """Drop the cached launch plan of `opt` (all plans when None): called by Trainer.load() after load_state_dict —
+    the signature check below would notice the new state tensors as well, this just does not rely on it."""
+    if opt is None:
+        _ADAM_PLANS.clear()
+    else:
+        _ADAM_PLANS.pop(id(opt), None)
+
+
 def adam_pack_step(opt):
     """opt.step() for a torch.optim.Adam(fused=True) in the bf16 speed mode: the Adam update of every parameter that has
     a gradient AND the refresh of its cached operand copies, one launch (stylex_adam_pack_step).  Operates on the
@@ -519,17 +531,31 @@ def adam_pack_step(opt):
     dt = _adam_dtype()
     # ---- plan: everything but the gradient pointers is stable from step to step
     copies_of = {id(p): sorted(_adam_copies_of(p), key=lambda e: (str(e[0][2]), e[2], e[1])) for p, _, _ in todo}
-    sig = tuple((id(p), p.data_ptr(), tuple((str(k[2]), sc, 0 if a is None else a.data_ptr(), 0 if b is None else b.data_ptr())
-                                            for k, _, sc, a, b in copies_of[id(p)]))
-                for p, _, _ in todo)
+    # the signature covers everything the device descriptors hold a raw pointer / constant of: the parameter, its
+    # moment and step tensors (load_state_dict installs NEW ones while the parameter keeps its address), the
+    # hyper-parameters baked into the descriptor, and the registered copies
+    sig = tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                 float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                 tuple((str(k[2]), sc, 0 if a is None else a.data_ptr(), 0 if b is None else b.data_ptr())
+                       for k, _, sc, a, b in copies_of[id(p)]))
+                for p, st, g in todo)
     plan = _ADAM_PLANS.get(id(opt))
-    if plan is None or plan["sig"] != sig:
+    if plan is None or plan["sig"] != sig or plan["opt_ref"]() is not opt:  # (a recycled id(opt) must not inherit a plan)
         host = np.zeros(len(todo), dtype=dt)
         entries, block_map, nb = [], [], 0
         for i, (p, st, g) in enumerate(todo):
-            copies = copies_of[id(p)][:4]
+            copies = copies_of[id(p)]
+            if len(copies) > 4:  # the descriptor has four slots: the rest stay on the lazy re-pack path
+                global _ADAM_COPY_OVERFLOW
+                if not _ADAM_COPY_OVERFLOW:
+                    _ADAM_COPY_OVERFLOW = True
+                    import warnings
+
+                    warnings.warn("adam_pack_step: a parameter has %d cached operand copies, the fused step refreshes 4 "
+                                  "(the others are re-packed lazily)" % len(copies))
+                copies = copies[:4]
             shape = tuple(p.shape)
-            if len(shape) == 4 and shape[2] * shape[3] <= 9 and (copies or True):
+            if len(shape) == 4 and shape[2] * shape[3] <= 9:
                 n, c, t = shape[0], shape[1], shape[2] * shape[3]
             elif copies and len(shape) == 2:
                 n, c, t = shape[0], shape[1], 1

@@ -5,11 +5,12 @@ The reference's multi-GPU path is vestigial (DDP wrappers around S/G/D only, the
 wrapped — stylex/stylex_train.py:1188-1193, README.md:81).  Here gradient exchange is explicit
 (class GradSync): the gradients of a phase live in persistent flat fp32 buckets (every .grad is a
 view after the bucket's pack) that are all-reduced in place, averaged by the collective itself
-(ReduceOp.AVG on RCCL).  DEFAULT: 128 MB buckets issued AFTER the last backward of the phase.
-Opt-in (``STYLEX_DDP_OVERLAP=1`` / ``GradSync(overlap=True)``): 32 MB buckets launched from
-autograd hooks inside that backward, strictly in index order on every rank — covered by the gloo
-tests and a 1-rank RCCL run, not yet by a >= 2-GPU RCCL run, hence not the default.  Non-final
-micro-steps never communicate (== ``no_sync``, :274-285).
+(ReduceOp.AVG on RCCL).  DEFAULT since round 5 (the design SURVEY §8(e) specifies): 32 MB buckets
+launched from autograd hooks INSIDE the last backward of the phase, strictly in index order on
+every rank — the path the gloo tests (2 and 4 ranks), the 1-rank RCCL identity test and the
+2-rank gloo run of bench.py exercise, so that what ships is what is tested the day a multi-GPU box
+appears.  ``STYLEX_DDP_OVERLAP=0`` / ``GradSync(overlap=False)``: 128 MB buckets issued AFTER the
+backward.  Non-final micro-steps never communicate (== ``no_sync``, :274-285).
 """
 import torch
 import torch.distributed as dist
@@ -53,12 +54,13 @@ class GradSync:
     reference stylex_train.py:274-285)."""
 
     def __init__(self, params, bucket_bytes=None, overlap=None):
-        # Default: few large (128 MB) collectives issued after the backward.  The in-backward launch (32 MB buckets from
-        # autograd hooks, STYLEX_DDP_OVERLAP=1) is covered by the gloo tests and a 1-rank RCCL run only — it stays
-        # opt-in until a >= 2-GPU RCCL run has shown both the rank-averaged gradients and a scaling gain on hardware.
+        # Default (round 5): the in-backward launch — 32 MB buckets from autograd hooks.  Rounds 3-4 kept it opt-in for
+        # want of a >= 2-GPU RCCL run; no such box exists in this environment, and a default nobody tests is worse than a
+        # default the gloo tests, the 1-rank RCCL identity test and bench.py's 2-rank gloo run all go through.
+        # STYLEX_DDP_OVERLAP=0: few large (128 MB) collectives issued after the backward.
         import os
 
-        self.overlap = (os.environ.get("STYLEX_DDP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
+        self.overlap = (os.environ.get("STYLEX_DDP_OVERLAP", "1") == "1") if overlap is None else bool(overlap)
         if bucket_bytes is None:
             bucket_bytes = (32 if self.overlap else 128) * 1024 * 1024
         seen, self.params = set(), []
@@ -78,11 +80,13 @@ class GradSync:
         self._bucket_of = {id(p): bi for bi, bucket in enumerate(self.buckets) for p in bucket}
         self.flats, self._views = [], {}
         for bucket in self.buckets:
-            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+            # every view starts on a 16-byte boundary: the fused Adam + pack kernel reads gradients with float4 loads
+            # (csrc/adam_pack.hip), and a view behind an odd-sized bias would otherwise be 4-byte aligned only
+            flat = torch.zeros(sum((p.numel() + 3) & ~3 for p in bucket), dtype=torch.float32, device=bucket[0].device)
             off = 0
             for p in bucket:
                 self._views[id(p)] = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+                off += (p.numel() + 3) & ~3
             self.flats.append(flat)
         self._armed = False
         self._reset()

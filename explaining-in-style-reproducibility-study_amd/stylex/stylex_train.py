@@ -1250,7 +1250,9 @@ class Trainer:
             stale, self._g_fut = getattr(self, "_g_fut", None), None
             if stale is not None:  # a call that raised (NaN restart) left its generator-phase draw running: let it finish
                 stale.exception()  # before anything else touches the loader / the generators
-            ahead = self._draw_mode if (fuse and not self.device_rng) else 0
+            # draw-ahead is an eager-path feature: with graphs enabled a draw prefetched here would be neither consumed
+            # nor drained by a following _train_graphed call (which draws on its own), reordering the RNG / loader streams
+            ahead = self._draw_mode if (fuse and not self.device_rng and not self._graphs_enabled()) else 0
             d_in = g_fut = None
             if ahead:
                 sig = (gae, self.batch_size, self.world_size, self.alternating_training, self.new_architecture,
@@ -1666,6 +1668,7 @@ class Trainer:
         import hip_backend as hb
 
         hb.mark_updated(self.StylEx.parameters())  # belt and braces: no operand pack of the pre-load weights survives
+        hb.adam_forget()  # load_state_dict installed new moment / step tensors: no fused-Adam plan keeps the old pointers
 
 
 def grid_to_pil(images, nrow=8, padding=2):

@@ -304,3 +304,33 @@ def test_nan_restart_is_collective(tmp_path, on_save_step):
     # detected while enqueueing the call after the NaN one / inside the NaN call itself on a checkpoint step
     assert ev0 == ev1 == ["ok", "ok", "nan", "ok"], (ev0, ev1)
     assert loads0 == loads1 and len(loads0) == 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_two_ranks_over_gloo(tmp_path):
+    """bench.py's own N > 1 path, launched the way the driver launches it (`python -m torch.distributed.run
+    --nproc-per-node 2 ... bench.py --gpus 2 --steps K --warmup W`), on the CPU test double over gloo: process-group
+    set-up, rank-split batches, the in-backward bucket all-reduce (the default), barrier + MAX-reduce of the elapsed
+    time, exactly ONE JSON line (rank 0, last thing on stdout), process-group teardown.  The first real `--gpus 8` run
+    must not die in this plumbing."""
+    import json
+    import subprocess
+
+    launcher = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bench_gloo_double.py")
+    env = dict(os.environ, OMP_NUM_THREADS="2", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    env.pop("STYLEX_DDP_OVERLAP", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), launcher, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--image-size", "64", "--network-capacity", "2", "--fmap-max", "16", "--roofline-steps", "0", "--fp32-steps", "0",
+           "--bench-a-steps", "0", "--no-cpu-baseline", "--workdir", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    assert out.stdout.rstrip().endswith(lines[0]), "the JSON line must be the last thing on stdout"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 4
+    assert j["value"] > 0 and abs(j["value"] - 2 * 2 * 2 * 2 / (j["ms_per_step"] * 2 / 1e3)) / j["value"] < 0.02
+    assert j["algorithmic_conv_gflop_per_image"] < 10  # size-aware: this 64 px / capacity-2 model, not the 256 px constants
+    assert j["roofline"] is None and j["cpu_baseline"] is None

@@ -1950,6 +1950,57 @@ def test_adam_pack_step_matches_torch_fused_adam_and_the_pack_kernels():
     hb.pack_cache_clear()
 
 
+def test_adam_pack_step_follows_load_state_dict():
+    """the fused Adam + pack launch caches raw pointers to exp_avg / exp_avg_sq / step.
+    Optimizer.load_state_dict installs NEW state tensors while the parameters keep their addresses (Trainer.load with
+    save_training_state, or the NaN-restart path) — the cached plan must notice, or the kernel keeps updating freed
+    buffers and the reloaded moments are never used.  step, save, step, load, step: parameters and moments equal a
+    torch fused-Adam run through the same sequence."""
+    import copy
+
+    dev = torch.device(DEV)
+    shapes = [(64, 64, 3, 3), (40,), (17, 33)]
+
+    def make():
+        torch.manual_seed(6)
+        ps = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.1) for s in shapes]
+        return ps, torch.optim.Adam(ps, lr=2e-4, betas=(0.5, 0.9), fused=True)
+
+    def grads(ps, k):
+        g = torch.Generator(device=dev).manual_seed(200 + k)
+        for p in ps:
+            p.grad = torch.randn(p.shape, device=dev, generator=g)
+
+    hb.pack_cache_clear()
+    ref_p, ref_opt = make()
+    ps, opt = make()
+    for k in range(2):  # the first step initialises torch's state (fallback), the second runs the fused launch
+        grads(ref_p, k), grads(ps, k)
+        ref_opt.step()
+        if not hb.adam_pack_step(opt):
+            opt.step()
+    saved, ref_saved = copy.deepcopy(opt.state_dict()), copy.deepcopy(ref_opt.state_dict())
+    for k in (2, 3):  # move on: the state to be overwritten by the load differs from the saved one
+        grads(ref_p, k), grads(ps, k)
+        ref_opt.step()
+        assert hb.adam_pack_step(opt) is True
+    old_ptrs = {opt.state[p]["exp_avg"].data_ptr() for p in ps}
+    opt.load_state_dict(saved)
+    ref_opt.load_state_dict(ref_saved)
+    assert {opt.state[p]["exp_avg"].data_ptr() for p in ps} != old_ptrs, "load_state_dict is expected to install new tensors"
+    for k in (4, 5):
+        grads(ref_p, k), grads(ps, k)
+        ref_opt.step()
+        assert hb.adam_pack_step(opt) is True
+        for a, b in zip(ps, ref_p):
+            close(b, a, 2e-6, "parameter after load + step")
+            sa, sb = opt.state[a], ref_opt.state[b]
+            close(sb["exp_avg"], sa["exp_avg"], 2e-6, "exp_avg after load")
+            close(sb["exp_avg_sq"], sa["exp_avg_sq"], 2e-6, "exp_avg_sq after load")
+            assert float(sa["step"]) == float(sb["step"]) == 2 + (k - 3)
+    hb.pack_cache_clear()
+
+
 def test_attfind_visualisation_cells_on_hip():
     """N1: the notebook's visualisation cells (batched: attfind.change_images / visualize_style /
     visualize_style_by_distance_in_s) on the HIP kernels against the arrays the reference notebook's own cells produced

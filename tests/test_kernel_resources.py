@@ -20,6 +20,9 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     ("conv_pipe.hip", ["conv3x3_pipe_kernelILi128ELi0", "conv3x3_pipe_kernelILi64ELi0", "conv3x3_pipe_kernelILi128ELi2"]),
     ("adam_pack.hip", ["adam_pack_kernel"]),
     ("conv_line64.hip", ["conv3x3_line64_kernelILi0", "conv3x3_line64_kernelILi2"]),
+    ("conv_wgrad_pipe.hip", ["conv3x3_wgrad_pipe_kernelILi2ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi32ELb0",
+                             "conv3x3_wgrad_pipe_kernelILi1ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi16ELb1",
+                             "conv3x3_wgrad_pipe_kernelILi1ELi16ELb0"]),
 ])
 def test_hot_kernels_use_no_scratch(tmp_path, source, kernels):
     out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",

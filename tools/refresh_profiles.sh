@@ -12,7 +12,7 @@ python tools/bench_conv.py --batch 64 > $O/${TAG}_conv_layers_bf16_b64.txt 2>&1
 python tools/bench_elementwise.py > $O/${TAG}_elementwise_bf16_b64.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o r01 -- python3 $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --fp32-steps 0 > /tmp/b_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o r01 -- python3 $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --fp32-steps 0 --bench-a-steps 0 > /tmp/b_$TAG.log 2>&1
 python3 $R/tools/prof_summary.py $(find /tmp/prof_$TAG -name "*kernel_stats.csv") 12 > $O/${TAG}_kernel_stats_bench_bf16.csv
 grep -a ms_per_step /tmp/b_$TAG.log > $O/${TAG}_kernel_stats_bench_line.txt
 python3 $R/tools/trace_pack.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv") $O/trace_$TAG.csv.gz
