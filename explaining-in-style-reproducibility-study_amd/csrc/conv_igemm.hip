@@ -684,14 +684,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
     }
 }
 
+// Bias gradient riding the weight-gradient reduce launch (round 5; its own launch was 22 us of serial dependent loads,
+// 27 times per step): the blocks behind the `main_blocks` reduce blocks sum the per-split pixel sums of dy the
+// weight-gradient kernel left in bias_part[split][n].  One wave per channel, lane l takes splits l, l + 64, ..., then a
+// fixed shuffle tree: deterministic.
+__device__ __forceinline__ void bias_reduce_block(const float* __restrict__ part, float* __restrict__ db, int N, int splits,
+                                                  int blk) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int n = blk * 4 + w;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int s = l; s < splits; s += 64) v += part[(long)s * N + n];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (l == 0) db[n] = v;
+}
+
 // dw_oihw[n][c][t] = sum_split partial[split][n][t][c]   (fixed order => deterministic)
 // One thread owns one (n, c): for each tap it reads the slices with lanes running along c (coalesced
 // 256-byte rows), four slices in flight per tap.  The T results of a thread are consecutive in OIHW, so a block's
 // 256 pairs form one contiguous span of 256*T floats: it is transposed through LDS and written with coalesced
 // rows (the direct form wrote 4 bytes at a 36-byte lane stride).  Fixed summation order -> deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int N, int C, int T, int splits) {
+                                                           int N, int C, int T, int splits, int main_blocks,
+                                                           const float* __restrict__ bias_part, float* __restrict__ db) {
     __shared__ float tile[256 * 9];
+    if ((int)blockIdx.x >= main_blocks) {
+        bias_reduce_block(bias_part, db, N, splits, blockIdx.x - main_blocks);
+        return;
+    }
     const long total = (long)N * C * T;
     const long pairs = (long)N * C;
     const long i0 = (long)blockIdx.x * 256;
@@ -750,9 +771,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // fixed order (deterministic), T outputs per pair.
 template <int PP, int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                 int N, int C, int T, int splits) {
+                                                                 int N, int C, int T, int splits, int main_blocks,
+                                                                 const float* __restrict__ bias_part, float* __restrict__ db) {
     static_assert(PP * G == 256, "one thread per (pair, slice group)");
     __shared__ float red[G][PP][9];
+    if ((int)blockIdx.x >= main_blocks) {
+        bias_reduce_block(bias_part, db, N, splits, blockIdx.x - main_blocks);
+        return;
+    }
     const long total = (long)N * C * T;
     const long pairs = (long)N * C;
     const int p = threadIdx.x % PP, g = threadIdx.x / PP;
@@ -800,17 +826,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
     }
 }
 
-static void launch_wgrad_reduce(const float* partial, float* dw, int N, int C, int T, int splits, hipStream_t s) {
+// bias_part / db != null: the same launch also reduces the per-split bias sums (bias_reduce_block)
+static void launch_wgrad_reduce(const float* partial, float* dw, int N, int C, int T, int splits, hipStream_t s,
+                                const float* bias_part = nullptr, float* db = nullptr) {
     const long pairs = (long)N * C;
+    const unsigned extra = (bias_part && db) ? (unsigned)((N + 3) / 4) : 0u;
     if (T <= 9 && splits >= 32 && (pairs <= 2048 || (pairs <= 8192 && splits >= 256))) {
-        hipLaunchKernelGGL((wgrad_reduce_small_kernel<8, 32>), dim3((unsigned)((pairs + 7) / 8)), dim3(256), 0, s, partial, dw,
-                           N, C, T, splits);
+        const unsigned mb = (unsigned)((pairs + 7) / 8);
+        hipLaunchKernelGGL((wgrad_reduce_small_kernel<8, 32>), dim3(mb + extra), dim3(256), 0, s, partial, dw, N, C, T, splits,
+                           (int)mb, bias_part, db);
     } else if (T <= 9 && splits >= 16 && pairs <= 16384) {
-        hipLaunchKernelGGL((wgrad_reduce_small_kernel<32, 8>), dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, partial,
-                           dw, N, C, T, splits);
+        const unsigned mb = (unsigned)((pairs + 31) / 32);
+        hipLaunchKernelGGL((wgrad_reduce_small_kernel<32, 8>), dim3(mb + extra), dim3(256), 0, s, partial, dw, N, C, T, splits,
+                           (int)mb, bias_part, db);
     } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, partial, dw, N, C, T,
-                           splits);
+        const unsigned mb = (unsigned)((pairs + 255) / 256);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mb + extra), dim3(256), 0, s, partial, dw, N, C, T, splits, (int)mb,
+                           bias_part, db);
     }
 }
 
@@ -1139,15 +1171,6 @@ void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long
     *split_len = len;
 }
 
-// db[n] = sum over the splits (fixed order) of the per-split pixel sums of dy the LDS-DMA weight-gradient kernel left
-__global__ void bias_partial_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int splits) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += part[(long)s * N + n];
-    db[n] = v;
-}
-
 int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s, float* db, int* db_done) {
     if (db_done) *db_done = 0;
     if (precision == STYLEX_BF16 && stylex_wgrad_pipe_applicable(p)) {
@@ -1157,11 +1180,9 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         int rc = stylex_launch_wgrad_pipe(p, partial, s, &slices, &bias_done);
         if (rc != STYLEX_NOT_APPLICABLE) {
             if (rc) return rc;
-            launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, slices, s);
-            if (db && bias_done) {
-                hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3((p.N + 255) / 256), dim3(256), 0, s, p.bias_partial, db, p.N, slices);
-                if (db_done) *db_done = 1;
-            }
+            const bool with_db = db && bias_done;
+            launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, slices, s, with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
+            if (with_db && db_done) *db_done = 1;
             return (int)hipGetLastError();
         }
         p.bias_partial = nullptr;
@@ -1175,11 +1196,9 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         }
         int rc = stylex_launch_wgrad_halo(p, partial, s, &hs, &bias_done);
         if (rc) return rc;
-        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s);
-        if (db && bias_done) {
-            hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3((p.N + 255) / 256), dim3(256), 0, s, p.bias_partial, db, p.N, hs);
-            if (db_done) *db_done = 1;
-        }
+        const bool with_db = db && bias_done;
+        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s, with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
+        if (with_db && db_done) *db_done = 1;
         return (int)hipGetLastError();
     }
     if (precision == STYLEX_BF16 && stylex_wgrad_tr_applicable(p)) {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
         const int piece = wave + 8 * k;
         const int q = piece * 8 + dpx;
         const int row = q / HWD, col = q - row * HWD;
-        const bool ok = piece < X_PIECES && q < XPX;
+        const bool ok = piece < X_PIECES && q < XPX && c0 + (int)lslot * 8 < C;  // C == 32: half of the 64-channel row
         const unsigned edge = (row == 0 ? 1u : 0u) | (row == TR + 1 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col == TW + 1 ? 8u : 0u);
         vxc[k] = ok ? (((unsigned)(row * W + col) * (unsigned)C + (unsigned)c0 + lslot * 8u) * 2u) | edge : WG_OOB;
         xdst[k] = piece < X_PIECES ? piece * 1024 : -1;
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
         const int piece = wave + 8 * k;  // panel = piece >> 4
         const int q = (piece & 15) * 8 + dpx;
         const int r = q / TW, col = q - r * TW;
-        vdy[k] = ((unsigned)(r * W + col) * (unsigned)N + (unsigned)(n0 + (piece >> 4) * 64) + lslot * 8u) * 2u;
+        const int nch = n0 + (piece >> 4) * 64 + (int)lslot * 8;
+        vdy[k] = nch < N ? ((unsigned)(r * W + col) * (unsigned)N + (unsigned)nch) * 2u : WG_OOB;  // N == 32: half rows
     }
     // (the lane-constant code above leaves W in a VGPR behind a divergent branch: scalar copies for everything below)
     const int Hs = __builtin_amdgcn_readfirstlane(p.Ho), Ws = __builtin_amdgcn_readfirstlane(p.Wo);
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
     const int lj = lane & 31, lh = lane >> 5;
     float* out = p.y + (long)split * N * 9 * C;
     const int c = c0 + cblk * 32 + lj;
+    if (nbase >= N || c0 + cblk * 32 >= C) return;  // N == 32 / C == 32: this wave multiplied the zero half of a row
     if (do_bias && lj == 0) {  // every column of accb holds the same sums: column 0 writes them
 #pragma unroll
         for (int r = 0; r < 16; ++r) p.bias_partial[(long)split * N + nbase + (r & 3) + 8 * (r >> 2) + 4 * lh] = accb[r];
@@ -485,14 +487,32 @@ int g_wg_cus = 0;
 
 }  // namespace
 
-// bf16 activations, 3x3 / s1 / p1, whole 64-channel tiles on both sides, image = whole tiles, no dy scale, tensors
-// below 1 GiB (32-bit buffer offsets with the halo bias)
+// 64 (N % 128 != 0, or the launch is short: see the plan) or 128 output channels per block tile
+static int wg_np64(const ConvKParams& p) {
+    const char* env = getenv("STYLEX_WGRAD_PIPE_NP");  // A/B switch: 1 / 2 force the tile
+    if (p.N % 128 != 0 || (env && env[0] == '1')) return 1;
+    if (env && env[0] == '2') return 2;
+    // few stages per block: the partial slices (one 128 x 64 x 9 fp32 tile = 295 KB per block, written once and read once
+    // by the reduce launch) cost as much as the multiplications; the 64 x 64 tile halves them.  Stages per block at 128
+    // channels = total stages / (CUs / output tiles); measured (tools/bench_wgrad.py --np-ab): 64-channel tiles are 1.03-1.16x
+    // faster at <= 32 stages per block, equal from 64 on.
+    const int tw = p.Wo >= 32 ? 32 : 16;
+    const long tiles = (long)p.B * (p.Wo / tw) * (p.Ho / (128 / tw));
+    const long otiles2 = (long)(p.N / 128) * ((p.Ck + 63) / 64);
+    const long cus = g_wg_cus > 0 ? g_wg_cus : 256;
+    const long per_block = tiles * otiles2 / cus;
+    static const long thr = getenv("STYLEX_WGRAD_PIPE_NP_THR") ? atol(getenv("STYLEX_WGRAD_PIPE_NP_THR")) : 48;
+    return per_block < thr ? 1 : 2;
+}
+
+// bf16 activations, 3x3 / s1 / p1, 64-channel tiles on both sides (or exactly 32 channels: the generator's last block),
+// image = whole tiles, no dy scale, tensors below 1.5 GiB (32-bit buffer offsets)
 bool stylex_wgrad_pipe_applicable(const ConvKParams& p) {
     const char* env = getenv("STYLEX_WGRAD_PIPE");  // read per launch: A/B tests toggle it in-process
     if (env && env[0] == '0') return false;
     if (!p.act_bf16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return false;
     if (p.s2d_c || p.a2_scale) return false;
-    if (p.Ck % 64 != 0 || p.N % 64 != 0) return false;
+    if ((p.Ck % 64 != 0 && p.Ck != 32) || (p.N % 64 != 0 && p.N != 32)) return false;
     const int tw = p.Wo >= 32 ? 32 : 16;
     if (p.Wo % tw != 0 || p.Wo < 16) return false;
     const int tr = 128 / tw;
@@ -511,12 +531,12 @@ void stylex_wgrad_pipe_plan(const ConvKParams& p, int* slices, int* tiles_per_sp
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         g_wg_cus = n > 0 ? n : 256;
     }
-    const int np64 = p.N % 128 == 0 ? 2 : 1;
+    const int np64 = wg_np64(p);
     const int tw = p.Wo >= 32 ? 32 : 16;
     const int tr = 128 / tw;
     const long tiles_img = (long)(p.Wo / tw) * (p.Ho / tr);
     const long tiles = (long)p.B * tiles_img;
-    const long otiles = (long)(p.N / (64 * np64)) * (p.Ck / 64);
+    const long otiles = (long)((p.N + 64 * np64 - 1) / (64 * np64)) * ((p.Ck + 63) / 64);
     long want = g_wg_cus / otiles;
     if (want < 1) want = 1;
     if (want > tiles) want = tiles;
@@ -535,7 +555,7 @@ int stylex_launch_wgrad_pipe(ConvKParams p, float* partial, hipStream_t s, int* 
     if (!stylex_wgrad_pipe_applicable(p)) return STYLEX_NOT_APPLICABLE;
     int slices, tps, blocks;
     stylex_wgrad_pipe_plan(p, &slices, &tps, &blocks);
-    const int np64 = p.N % 128 == 0 ? 2 : 1;
+    const int np64 = wg_np64(p);
     const int tw = p.Wo >= 32 ? 32 : 16;
     const int tr = 128 / tw;
     WgArgs wa;
@@ -543,8 +563,8 @@ int stylex_launch_wgrad_pipe(ConvKParams p, float* partial, hipStream_t s, int* 
     wa.ty_count = p.Ho / tr;
     wa.total_tiles = p.B * wa.tx_count * wa.ty_count;
     wa.tiles_per_split = tps;
-    wa.c_tiles = p.Ck / 64;
-    wa.otiles = (p.N / (64 * np64)) * wa.c_tiles;
+    wa.c_tiles = (p.Ck + 63) / 64;
+    wa.otiles = ((p.N + 64 * np64 - 1) / (64 * np64)) * wa.c_tiles;
     p.y = partial;
     *slices_out = slices;
     const bool bias = p.bias_partial != nullptr;

@@ -29,6 +29,8 @@ SHAPES = [
     ("512->256@32", 512, 256, 32),
     ("256->256@32", 256, 256, 32),
     ("512->512@16", 512, 512, 16),
+    ("64->32@256", 64, 32, 256),
+    ("32->32@256", 32, 32, 256),
 ]
 
 
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--new-only", action="store_true", help="time the new kernel only (PMC runs)")
     ap.add_argument("--only", default="")
+    ap.add_argument("--np-ab", action="store_true", help="third arm: the new kernel with 64-channel tiles forced (STYLEX_WGRAD_PIPE_NP=1)")
     a = ap.parse_args()
     prec = hb.BF16_ACT
     dev = "cuda:0"
@@ -123,8 +126,17 @@ def main():
                 t[mode] = min(t.get(mode, 1e9), timeit(fn, a.iters))
             fl = 2.0 * b * res * res * n * c * 9
             t.setdefault("0", float("nan"))
-            print("%-14s %5d | %9.3f %9.3f | %7.1f %7.1f | %.2fx" % (name, b, t["1"], t["0"], fl / t["1"] / 1e9, fl / t["0"] / 1e9,
-                                                                    t["0"] / t["1"]))
+            extra = ""
+            if a.np_ab and n % 128 == 0:
+                os.environ["STYLEX_WGRAD_PIPE"] = "1"
+                os.environ["STYLEX_WGRAD_PIPE_NP"] = "1"
+                t64 = min(timeit(fn, a.iters), timeit(fn, a.iters))
+                os.environ.pop("STYLEX_WGRAD_PIPE_NP")
+                tw_ = 32 if res >= 32 else 16
+                stages = b * (res // tw_) * (res // (128 // tw_)) * (n // 128) * ((c + 63) // 64) / 256.0
+                extra = " | 64-ch tiles %.3f ms (%.2fx of 128), stages/block %.1f" % (t64, t["1"] / t64, stages)
+            print("%-14s %5d | %9.3f %9.3f | %7.1f %7.1f | %.2fx%s" % (name, b, t["1"], t["0"], fl / t["1"] / 1e9, fl / t["0"] / 1e9,
+                                                                      t["0"] / t["1"], extra))
             if b == a.batch:
                 tot[0] += t["1"]
                 tot[1] += t["0"]
