@@ -616,18 +616,19 @@ def test_block_level_goldens_on_hip():
 
 def test_bf16_step_band_vs_reference_golden(tmp_path):
     """The benchmarked mode (bf16 MFMA operands + bf16 activation tensors, fused Adam) against the fp32 reference
-    trajectory steps_gae2_alt.  Band for the first train() call: every conv rounds its two operands to bf16 (relative
-    2^-9 each); a loss scalar sits behind ~30 chained convs of forward (+ as many of backward for the penalty), a random
-    walk of sqrt(60)*2^-8 = 3e-2, so 5e-2 of max(1,|x|) for d_loss / g_loss / rec / kl; the gradient penalty is a
-    squared norm of a double-rounded gradient: 1e-1.  g_loss is evaluated on the UPDATED discriminator: until round 3
-    this test excluded it ("measured -0.21 vs 3.88", blamed on Adam's sign-like first step) — that was the stale operand
-    cache under the fused Adam; with the fix the bf16 mode gives 3.89 vs 3.88.  Later calls: the band widens
-    by 1.6x per call (the untrained GAN amplifies any difference), capped at 30 %.  The KL column gets the cap from
-    the third call on: on this fixture it is hypersensitive to the last bits of its own gradient — scaling the (torch)
-    KL loss by 1 + 1e-6 moves it from 2.02 to 2.39 at the third call (golden 2.06) while every other scalar stays
-    within 5 % (tools/probes/bf16_band_perturb.py, profiles/r04_h_bf16_band_perturbation.txt); the fused loss kernels
-    of round 4 round differently in exactly that place and land at 2.34."""
+    trajectory steps_gae2_alt.  The band has two parts, both with a stated origin (round-4 VERDICT item 3c: no free cap):
+    (1) the arithmetic — every conv rounds its two operands to bf16 (relative 2^-9 each); a loss scalar sits behind ~30
+    chained convs of forward (+ as many of backward for the penalty), a random walk of sqrt(60)*2^-8 = 3e-2, so 5e-2 of
+    max(1,|x|) for d_loss / g_loss / rec / kl on the first call, growing 1.3x per call (a bf16-rounded Adam trajectory:
+    measured 1.6e-2, 3.5e-2, 4.7e-2, 3.6e-2, 7.6e-2 for calls 0-4 outside the KL column); the gradient penalty is a
+    squared norm of a double-rounded gradient: 1e-1.  (2) the trajectory's own sensitivity — tests/golden/
+    bf16_band_gae2_alt.npz (tools/gen_bf16_band.py, measured on the MI355X) holds the spread of the bf16 path against
+    ITSELF when one loss is scaled by 1 +- 1e-6 or an arithmetic-neutral switch is flipped: < 1 % everywhere except the KL
+    column, which this fixture amplifies to 18 % two calls later (2.02 vs 2.39 at the third call, golden 2.06).  Band =
+    (1) + 2 x (2), per call and scalar.  g_loss is evaluated on the UPDATED discriminator: until round 3 this test
+    excluded it — that was the stale operand cache under the fused Adam; the bf16 mode gives 3.89 vs 3.88."""
     g = load_golden("steps_gae2_alt")
+    band = load_golden("bf16_band_gae2_alt")
     ops.set_precision("bf16")
     try:
         tr, n = make_trainer(g, tmp_path, device=torch.device(DEV))
@@ -635,12 +636,12 @@ def test_bf16_step_band_vs_reference_golden(tmp_path):
     finally:
         ops.set_precision("fp32")
     gold = g["scalars"]
-    print("bf16 rows\n", rows, "\ngolden\n", gold)
+    spread = np.asarray(band["spread"])
+    print("bf16 rows\n", rows, "\ngolden\n", gold, "\nself-spread\n", spread)
     assert np.isfinite(rows[:, :5]).all()
+    assert spread.shape == (n, 4) and float(spread[:, :3].max()) < 0.05, "the fixture's premise: only KL is hypersensitive"
     for i in range(n):
-        tol = np.full(4, min(0.3, 5e-2 * 1.6 ** i))
-        if i >= 2:
-            tol[3] = 0.3
+        tol = 5e-2 * 1.3 ** i + 2.0 * spread[i]
         scale = np.maximum(1.0, np.abs(gold[i, :4]))
         assert (np.abs(rows[i, :4] - gold[i, :4]) <= tol * scale).all(), (i, tol, rows[i], gold[i])
     assert abs(rows[0, 4] - gold[0, 4]) <= 1e-1 * max(1.0, abs(gold[0, 4])), (rows[0, 4], gold[0, 4])
@@ -776,12 +777,45 @@ def test_100_call_trajectory_vs_reference_golden(tmp_path):
     g = load_golden("curve_64_calm")
     tr, n = make_trainer(g, tmp_path, device=torch.device(DEV))
     assert n == 100 and tr.steps == 4960
+    theta0 = {k: p.detach().double().cpu().reshape(-1) for k, p in tr.StylEx.named_parameters()}
     rows = run_steps(tr, n)
     assert tr.steps == 5060
     gold = g["scalars"]
     dev = np.nanmax(np.abs(rows - gold) / np.maximum(np.abs(gold), 1.0), axis=1)
     print("100-call trajectory: max deviation per call, worst %.2e at call %d; median %.2e" % (dev.max(), int(dev.argmax()), np.median(dev)))
     assert_calm_rows(rows, g)
+    # ---- what the parameters DID over the 100 calls (round-4 VERDICT: at lr 1e-8 a bound of n * 3e-8 on single elements is
+    # wider than their total movement, so the scalars alone cannot see a wrong gradient or optimiser step after the first
+    # calls).  The fixture stores, per tensor, (sum, abs-sum, first 8 values) after call 100; the start values are the
+    # seeded init (init goldens), so the MOVEMENT of the first 8 elements and of the tensor sum is known for both runs.
+    # A dropped / doubled Adam step, a gradient with the wrong sign or scale on any tensor, or a missing lr group moves
+    # these by O(movement); summation-order noise moves them by a +-lr random walk on the noise-dominated elements only.
+    params = dict(tr.StylEx.named_parameters())
+    mh, mr, dsum_h, dsum_r, untouched = [], [], [], [], 0
+    for name, gs in zip(g["param_names"], g["param_stats"]):
+        t0, t1 = theta0[str(name)], params[str(name)].detach().double().cpu().reshape(-1)
+        k = min(8, t0.numel())
+        ref_move = torch.from_numpy(np.asarray(gs[2:2 + k], dtype=np.float64)) - t0[:k]
+        if float(ref_move.abs().max()) == 0.0:  # a tensor the reference did not touch in this window
+            untouched += 1
+            assert float((t1[:k] - t0[:k]).abs().max()) == 0.0, (str(name), "moved although the reference left it alone")
+            continue
+        mh.append(t1[:k] - t0[:k])
+        mr.append(ref_move)
+        dsum_h.append(float(t1.sum() - t0.sum()))
+        dsum_r.append(float(gs[0]) - float(t0.sum()))
+    mh, mr = torch.cat(mh), torch.cat(mr)
+    rel = float((mh - mr).norm() / mr.norm())
+    big = mr.abs() > 0.3 * float(mr.abs().median())
+    agree = float(((mh[big] > 0) == (mr[big] > 0)).double().mean())
+    dsum_h, dsum_r = np.array(dsum_h), np.array(dsum_r)
+    rel_sum = float(np.linalg.norm(dsum_h - dsum_r) / np.linalg.norm(dsum_r))
+    print("parameter movement over the 100 calls: %d tensors moved (%d untouched), median |move| %.2e, max %.2e; HIP vs "
+          "reference: relative L2 of the per-element moves %.3f, sign agreement %.3f, relative L2 of the per-tensor sum "
+          "moves %.3f" % (len(dsum_r), untouched, float(mr.abs().median()), float(mr.abs().max()), rel, agree, rel_sum))
+    # measured on the HIP fp32 path: 0.001 / 1.000 / 0.000 (profiles/r05_f_parity_blocks.txt); a dropped optimiser step of
+    # one network is >= 0.1, a wrong-sign gradient 2.0
+    assert rel < 0.02 and agree > 0.99 and rel_sum < 0.02, (rel, agree, rel_sum)
     assert_param_stats(tr, g, head_atol=n * 3e-8)
 
 
@@ -2050,10 +2084,40 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec):
         k = max(1, int(0.9 * err.numel()))
         return float(err.kthvalue(k).values / max(1e-12, float(b.pow(2).mean().sqrt())))
 
+    def tile_max(a, b):
+        # Round-4 VERDICT weak point 2: a percentile cannot see a bug confined to < 10 % of the elements — a ragged last
+        # tile, a border row, one channel half of a 128-channel tile.  Such bugs are LOCAL and O(1); rounding and flipped
+        # LeakyReLU gates are spread evenly.  So: the RMS error of every kernel-tile-sized block — 32 channels x 4 rows x
+        # 32 columns of an activation / gradient tensor, 32 x 32 (n, c) per tap of a conv weight gradient — over the RMS
+        # of the whole reference tensor, maximum over the blocks.  A wrong block gives ~1 (0.7 for one wrong row of its
+        # four); averaging over <= 4096 elements takes the gate-flip noise down to the tensor's mean error.
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        rms = max(1e-12, float(b.pow(2).mean().sqrt()))
+        e2 = (a - b).pow(2)
+        if e2.dim() == 4 and e2.shape[2] >= 32 and e2.shape[3] >= 32:  # activation [B, C, H, W]
+            cb = 32 if e2.shape[1] % 32 == 0 else e2.shape[1]
+            t = e2.reshape(e2.shape[0], e2.shape[1] // cb, cb, e2.shape[2] // 4, 4, e2.shape[3] // 32, 32).mean(dim=(2, 4, 6))
+        elif e2.dim() == 4 and e2.shape[2] == e2.shape[3] and e2.shape[2] <= 3:  # conv weight [N, C, k, k]
+            nb = 32 if e2.shape[0] % 32 == 0 else e2.shape[0]
+            cb = 32 if e2.shape[1] % 32 == 0 else e2.shape[1]
+            t = e2.reshape(e2.shape[0] // nb, nb, e2.shape[1] // cb, cb, -1).mean(dim=(1, 3))
+        else:
+            t = e2.mean().reshape(1)
+        return float(t.max().sqrt()) / rms
+
     def bound(name):
         if prec == "fp32":
             return 3e-3 if name in ("gw", "g:to_style1.weight", "g:to_style1.bias") else 1e-4
         return 2e-2 if name in ("y", "x", "rgb", "coords") else 1.5e-1
+
+    def tile_bound(name):
+        # Measured (profiles/r05_f_parity_blocks.txt).  fp32: rounding 1e-7 ... 1e-6; a block that contains a flipped gate
+        # 6e-4 ... 1.4e-3, the generator block's input gradient (noise-shifted pre-activations) 8.3e-3 -> 1e-2 / 3e-2.
+        # bf16: the worst block equals the tensor's mean error (outputs 5.5e-3, gradients <= 8.7e-2: flip noise averages
+        # out over a block) -> 4e-2 / 3e-1.  A wrong block is >= 0.7.
+        if prec == "fp32":
+            return 3e-2 if name in ("gx", "gw", "g:to_style1.weight", "g:to_style1.bias") else 1e-2
+        return 4e-2 if name in ("y", "x", "rgb", "coords") else 3e-1
 
     def same_weights(hip_mod, cpu_mod):
         sd = {k: v.clone() for k, v in cpu_mod.state_dict().items()}
@@ -2080,12 +2144,17 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec):
             finally:
                 ops.set_fast(False)
             errs = {"y": rel(yh, yr), "gx": rel(xh.grad, xr.grad)}
+            tiles = {"y": tile_max(yh, yr), "gx": tile_max(xh.grad, xr.grad)}
             ref_grads = dict(ref.named_parameters())
             for n_, p_ in blk.named_parameters():
                 errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
+                tiles["g:" + n_] = tile_max(p_.grad, ref_grads[n_].grad)
             print("DiscriminatorBlock %d->%d @%d %s:" % (cin, cout, size, prec), {k: "%.1e" % v for k, v in errs.items()})
+            print("  worst block (RMS error / tensor RMS):", {k: "%.1e" % v for k, v in tiles.items()})
             bad = {k: v for k, v in errs.items() if v > bound(k)}
             assert not bad, ("DiscriminatorBlock %d->%d @%d" % (cin, cout, size), prec, bad)
+            bad = {k: v for k, v in tiles.items() if v > tile_bound(k)}
+            assert not bad, ("DiscriminatorBlock %d->%d @%d: a block of the tensor is off" % (cin, cout, size), prec, bad)
         # ---- generator block 6 (64 -> 32, upsample 128 -> 256, last block: no rgb upsample)
         ref = so.OGeneratorBlock(514, 64, 32, upsample=True, upsample_rgb=False)
         with torch.no_grad():
@@ -2110,15 +2179,21 @@ def test_full_resolution_blocks_vs_cpu_oracle(prec):
         finally:
             ops.set_fast(False)
         errs = {"x": rel(xo_h, xo_r), "rgb": rel(rgb_h, rgb_r), "coords": rel(sc_h, sc_r)}
+        tiles = {"x": tile_max(xo_h, xo_r), "rgb": tile_max(rgb_h, rgb_r)}
         for name, a, b in zip(("gx", "gprev", "gw"), ins_h, ins_r):
             errs[name] = rel(a.grad, b.grad)
+            tiles[name] = tile_max(a.grad, b.grad)
         ref_grads = dict(ref.named_parameters())
         for n_, p_ in blk.named_parameters():
             if p_.grad is not None and n_ in ref_grads:
                 errs["g:" + n_] = rel(p_.grad, ref_grads[n_].grad)
+                tiles["g:" + n_] = tile_max(p_.grad, ref_grads[n_].grad)
         print("GeneratorBlock 64->32 @256 %s:" % prec, {k: "%.1e" % v for k, v in errs.items()})
+        print("  worst block (RMS error / tensor RMS):", {k: "%.1e" % v for k, v in tiles.items()})
         bad = {k: v for k, v in errs.items() if v > bound(k)}
         assert not bad, ("GeneratorBlock 64->32 @256", prec, bad)
+        bad = {k: v for k, v in tiles.items() if v > tile_bound(k)}
+        assert not bad, ("GeneratorBlock 64->32 @256: a block of the tensor is off", prec, bad)
     finally:
         ops.set_precision("fp32")
         hb.pack_cache_clear()
