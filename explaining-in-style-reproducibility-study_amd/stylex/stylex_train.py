@@ -628,9 +628,15 @@ class Trainer:
         kl_rec_during_disc = kwargs.pop("kl_rec_during_disc", False)  # cli.py forwards it; only the new architecture reads it
         # new_architecture = the conditional-D variant the reference ships as stylex_train_new.py (cli.py:17-22)
         self.new_architecture = bool(new_architecture)
-        assert not (self.new_architecture and kl_rec_during_disc), \
-            "kl_rec_during_disc only changes what is logged in the reference (its gradients are zeroed by the generator " \
-            "phase's G_opt.zero_grad, stylex_train_new.py:1392-1410,1430) and is not implemented"
+        # Round 5: checked against the reference itself (profiles/r05_kl_rec_during_disc_reference.txt).  With
+        # kl_rec_during_disc=True the reference's own Trainer.train() raises on the first encoder micro-step of the
+        # discriminator phase — "Trying to backward through the graph a second time" at stylex_train_new.py:1408: rec_loss
+        # and kl_loss share the generator's graph and the first backward (:1403) frees it.  There is no behaviour to match,
+        # so the option is rejected here as well, with the reference's own failure as the reason.
+        if self.new_architecture and kl_rec_during_disc:
+            raise RuntimeError("kl_rec_during_disc=True cannot run in the reference either: stylex_train_new.py:1403-1408 "
+                               "backwards twice through one graph (RuntimeError on the first encoder micro-step of the "
+                               "discriminator phase); see profiles/r05_kl_rec_during_disc_reference.txt")
         self.model_params = [args, kwargs]
         self.StylEx = None
         self.kl_scaling, self.rec_scaling = kl_scaling, rec_scaling

@@ -474,6 +474,22 @@ def make_resnet_wrapper(g, tmp_path, size, norm):
         os.chdir(cwd)
 
 
+def test_kl_rec_during_disc_is_rejected_like_the_reference_fails(tmp_path):
+    """stylex_train_new.py:1392-1415.  With kl_rec_during_disc=True the reference's own train() raises on its first call
+    (two backwards through one graph; transcript of the reference run in profiles/r05_kl_rec_during_disc_reference.txt), so
+    there is no behaviour to reproduce: the Trainer refuses the option up front and says why; False is the default path
+    the newarch goldens pin."""
+    import stylex_train_new as stn
+    from lpips_standin import LPIPSStandIn
+    from standins import TinyClassifier
+
+    kw = dict(name="k", base_dir=str(tmp_path), image_size=16, network_capacity=2, fmap_max=16, batch_size=2,
+              classifier=TinyClassifier(seed=99), lpips_fn=LPIPSStandIn(seed=4242), device=torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="backwards twice through one graph"):
+        stn.Trainer(kl_rec_during_disc=True, **kw)
+    assert stn.Trainer(kl_rec_during_disc=False, **kw).new_architecture
+
+
 def test_resnet_wrapper_vs_reference_golden_cpu(tmp_path):
     """A16 on the CPU double: ResNet.classify_images of the product against the reference wrapper's own logits and
     input gradient (tests/golden/resnet_wrapper.npz)."""
