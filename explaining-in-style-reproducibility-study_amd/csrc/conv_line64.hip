@@ -5,7 +5,7 @@
 // Why a kernel of their own.  These launches move 1.07 GB for 77 GFLOP (B = 64): they are bound by the memory side,
 // and the pipelined kernel (conv_pipe.hip) ran them at 2.8-3.1 TB/s with its matrix pipe 44 % busy.  Its K loop walks
 // 16-channel chunks, so every LDS-DMA instruction fetches 32 bytes from each of 32 different 128-byte pixel lines
-// (tools/probes/line_granularity_probe.hip: 3-4.5 TB/s for that pattern against 5.5-6 for whole lines).  With 64 input
+// (tools/line_granularity_probe.hip: 3-4.5 TB/s for that pattern against 5.5-6 for whole lines).  With 64 input
 // channels a pixel IS one 128-byte line, so here
 //   * the K stage is the whole pixel: a DMA instruction fetches 8 complete lines (8 pixels x 128 bytes), four times
 //     fewer line look-ups per byte, and every input line is requested once per tile instead of four times;

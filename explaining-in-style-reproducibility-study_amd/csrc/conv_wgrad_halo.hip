@@ -7,7 +7,7 @@
 // memory (NHWC), i.e. k is the SLOW axis, while an MFMA lane needs 8 consecutive k of one row.  The
 // transpose is done by the LDS transpose-read ds_read_b64_tr_b16: within a 16-lane group, lane i
 // supplies the address of 4 contiguous bf16; lane l receives element (l&3) of rows 4j+(l>>2), j=0..3
-// (measured with tools/probes/tr_probe.hip).  Giving lane i the address [pixel (i>>2)][channel 4*(i&3)]
+// (measured with tools/tr_probe.hip).  Giving lane i the address [pixel (i>>2)][channel 4*(i&3)]
 // returns to lane l the 4 consecutive pixels of channel l — and a 3x3 tap shift is just a different
 // starting ROW, so all 9 taps read the same resident halo with no realignment.
 //

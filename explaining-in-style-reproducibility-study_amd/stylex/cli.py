@@ -63,7 +63,7 @@ def set_seed(seed):
     """reference cli.py:35-40: seeds torch / numpy / random and pins cudnn (here: MIOpen) to deterministic algorithms for
     the frozen classifier / LPIPS.  Round 1 had taken the flag out after two unexplained aborts in ~45 runs of the 64 px
     CLI test with it; they did not come back in round 2 (100 consecutive runs of that test with the flag on and the toRGB
-    side stream on, tools/probes/cli_abort_stress.sh, plus every GPU-suite run of the round), so the reference's
+    side stream on, profiles/probes/cli_abort_stress.sh, plus every GPU-suite run of the round), so the reference's
     behaviour is restored.  STYLEX_DETERMINISTIC=0 opts out (about 1 % of step throughput)."""
     torch.manual_seed(seed)
     if os.environ.get("STYLEX_DETERMINISTIC", "1") != "0":

@@ -1001,7 +1001,7 @@ def _bf16_matrix(w, scale=None, owner=None):
 def conv1x1_gemm_fwd(x, w, bias, owner=None):
     """1x1 / stride-1 conv of a channels_last bf16 tensor as the plain GEMM it is — [B*H*W, C] x [C, N] (+ bias) on
     hipBLASLt (torch.addmm): the residual path of a DiscriminatorBlock after the even-pixel gather.  Measured against
-    the generic implicit-GEMM kernel at B = 128 (tools/probes/gemm1x1_probe.py): 64->128 @64^2 .161 -> .049 ms,
+    the generic implicit-GEMM kernel at B = 128 (profiles/probes/gemm1x1_probe.py): 64->128 @64^2 .161 -> .049 ms,
     128->256 @32^2 .094 -> .025, 256->512 @16^2 .060 -> .021.  Same arithmetic (bf16 operands, fp32 accumulate, one
     rounding of the result)."""
     assert is_cl(x) and x.dtype == torch.bfloat16

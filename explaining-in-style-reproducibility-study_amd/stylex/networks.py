@@ -282,9 +282,9 @@ class Generator(nn.Module):  # reference :747-825
         # streaming to-RGB kernels (csrc/torgb.hip) made the chain cheap: the overlap is worth 0.8 % (645 vs 650
         # images/s), and with the short chain on a side stream the full-size determinism check (tools/
         # determinism_check.py) stopped being bit-identical run to run — single pixels of the gradient handed from
-        # the side chain to the feature path differ (tools/probes/race_locator.py; the kernels themselves are
-        # reproducible under concurrency, tools/probes/torgb_concurrency_probe.py, and the autograd engine's
-        # cross-stream hand-off checks out in isolation, tools/probes/engine_stream_probe.py).  Root cause not found;
+        # the side chain to the feature path differ (profiles/probes/race_locator.py; the kernels themselves are
+        # reproducible under concurrency, profiles/probes/torgb_concurrency_probe.py, and the autograd engine's
+        # cross-stream hand-off checks out in isolation, profiles/probes/engine_stream_probe.py).  Root cause not found;
         # until it is, the chain stays on the caller's stream.
         g_side = os.environ.get("STYLEX_G_SIDE", "0")  # 1: always; 2 / 3 (probes): only without / only with autograd recording
         use_side = g_side == "1" or (g_side == "2" and not torch.is_grad_enabled()) or (g_side == "3" and torch.is_grad_enabled())

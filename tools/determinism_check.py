@@ -41,7 +41,7 @@ def run(steps=5, image_size=256, batch=32, lazy=False, trainers=2):
             # ready nodes by per-thread sequence numbers, and the nodes the double backward of a penalty step creates on
             # the engine's worker thread start from that thread's counter, so in a fresh process they interleave
             # differently with the main thread's nodes — a different accumulation ORDER of the parameter gradients that
-            # receive several contributions (tools/probes/first_diff_probe.py: the call sequences differ; every kernel
+            # receive several contributions (profiles/probes/first_diff_probe.py: the call sequences differ; every kernel
             # output agrees until they do).  Not a race: the check is about run-to-run noise in steady state.
             bench.seed_all(42)
             tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)

@@ -6,7 +6,7 @@
 //   mode 1: LDS-DMA loads,  8 rows x 128 B per instruction (full lines)
 //   mode 2: stores, 32 rows x 32 B per instruction (4 instructions complete a row)                   [the conv's pattern]
 //   mode 3: stores,  8 rows x 128 B per instruction
-// build: hipcc -O3 --offload-arch=gfx950 tools/probes/line_granularity_probe.hip -o /tmp/lgp && /tmp/lgp
+// build: hipcc -O3 --offload-arch=gfx950 tools/line_granularity_probe.hip -o /tmp/lgp && /tmp/lgp
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
