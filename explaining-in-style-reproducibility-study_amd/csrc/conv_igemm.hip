@@ -1173,7 +1173,7 @@ void stylex_wgrad_plan(const ConvKParams& p, int* tn, int* tc, int* splits, long
 
 int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int precision, hipStream_t s, float* db, int* db_done) {
     if (db_done) *db_done = 0;
-    if (precision == STYLEX_BF16 && stylex_wgrad_pipe_applicable(p)) {
+    if (precision == STYLEX_BF16 && !p.s2d_c && stylex_wgrad_pipe_applicable(p)) {  // (s2d: stylex_launch_wgrad_s2d_folded)
         int slices = 0, tps, blocks, bias_done = 0;
         stylex_wgrad_pipe_plan(p, &slices, &tps, &blocks);
         if (db) p.bias_partial = partial + (long)slices * p.N * 9 * p.Ck;  // behind the weight-gradient partials
@@ -1231,6 +1231,14 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
     }
     if (rc) return rc;
     launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, T, splits, s);
+    return (int)hipGetLastError();
+}
+
+int stylex_launch_wgrad_s2d_folded(ConvKParams p, float* partial, float* dw_oihw, hipStream_t s) {
+    int slices = 0;
+    int rc = stylex_launch_wgrad_pipe(p, partial, s, &slices, nullptr);
+    if (rc) return rc == STYLEX_NOT_APPLICABLE ? STYLEX_EINVAL : rc;
+    launch_wgrad_reduce(partial, dw_oihw, p.N, p.s2d_c, 9, slices, s);
     return (int)hipGetLastError();
 }
 

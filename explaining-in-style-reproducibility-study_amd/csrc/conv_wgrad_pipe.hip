@@ -109,7 +109,12 @@ struct WgOps {
 };
 
 // step S of a stage: halo row rho = S % (RW+2), k-step column pw = S / (RW+2)
-template <class Cfg, int S>
+// MASK = the taps (bit kh * 3 + kw) this block multiplies: all nine, or the structurally non-zero taps of one
+// sub-position of a space-to-depth stride-2 conv (stylex_s2d_tap_mask)
+constexpr unsigned WG_ALL_TAPS = 0x1ffu;
+constexpr bool wg_kw_used(unsigned mask, int kw) { return ((mask >> kw) | (mask >> (3 + kw)) | (mask >> (6 + kw))) & 1u; }
+
+template <class Cfg, int S, unsigned MASK = WG_ALL_TAPS>
 __device__ __forceinline__ void issue_reads(WgOps& o, const int (&xb)[4], int dyb) {
     constexpr int rho = S % (Cfg::RW + 2), pw = S / (Cfg::RW + 2), par = S & 1;  // pw < PWS
     // the swizzled half of a pixel row depends on bits 1:0 of its index: (rho * HWD + kw) % 4, and HWD % 4 == 2
@@ -117,12 +122,18 @@ __device__ __forceinline__ void issue_reads(WgOps& o, const int (&xb)[4], int dy
     constexpr int q0 = (rho * Cfg::HWD + pw * 16 + 0) * 128, q1 = (rho * Cfg::HWD + pw * 16 + 1) * 128,
                   q2 = (rho * Cfg::HWD + pw * 16 + 2) * 128;
     constexpr int m0 = (2 * rho + 0) & 3, m1 = (2 * rho + 1) & 3, m2 = (2 * rho + 2) & 3;
-    tr_read<q0>(o.b[par][0][0], xb[m0]);
-    tr_read<q0 + 512>(o.b[par][0][1], xb[m0]);
-    tr_read<q1>(o.b[par][1][0], xb[m1]);
-    tr_read<q1 + 512>(o.b[par][1][1], xb[m1]);
-    tr_read<q2>(o.b[par][2][0], xb[m2]);
-    tr_read<q2 + 512>(o.b[par][2][1], xb[m2]);
+    if constexpr (wg_kw_used(MASK, 0)) {
+        tr_read<q0>(o.b[par][0][0], xb[m0]);
+        tr_read<q0 + 512>(o.b[par][0][1], xb[m0]);
+    }
+    if constexpr (wg_kw_used(MASK, 1)) {
+        tr_read<q1>(o.b[par][1][0], xb[m1]);
+        tr_read<q1 + 512>(o.b[par][1][1], xb[m1]);
+    }
+    if constexpr (wg_kw_used(MASK, 2)) {
+        tr_read<q2>(o.b[par][2][0], xb[m2]);
+        tr_read<q2 + 512>(o.b[par][2][1], xb[m2]);
+    }
     if constexpr (rho < Cfg::RW) {
         constexpr int qa = (rho * Cfg::kTW + pw * 16) * 128;
         tr_read<qa>(o.a[rho & 3][0], dyb);
@@ -145,7 +156,7 @@ __device__ __forceinline__ void wait_reads(WgOps& o) {
 
 // MFMAs of step S: x row rho serves tap row kh of output row r = rho - kh.  BIAS: one more MFMA per new dy fragment,
 // dy x ONES into accb — every column of accb = sum over the pixels of dy[., n] (the bias gradient).
-template <class Cfg, int S, bool BIAS>
+template <class Cfg, int S, bool BIAS, unsigned MASK = WG_ALL_TAPS>
 __device__ __forceinline__ void step_mfma(f32x16 (&acc)[9], f32x16& accb, const WgOps& o, bool do_bias, const bf16x8& ones) {
     constexpr int rho = S % (Cfg::RW + 2), par = S & 1;
     const bf16x8 b0 = cat8(o.b[par][0][0], o.b[par][0][1]);
@@ -156,9 +167,9 @@ __device__ __forceinline__ void step_mfma(f32x16 (&acc)[9], f32x16& accb, const 
         const int r = rho - kh;
         if (r >= 0 && r < Cfg::RW) {
             const bf16x8 av = cat8(o.a[r & 3][0], o.a[r & 3][1]);
-            mfma1(acc[kh * 3 + 0], av, b0);
-            mfma1(acc[kh * 3 + 1], av, b1);
-            mfma1(acc[kh * 3 + 2], av, b2);
+            if ((MASK >> (kh * 3 + 0)) & 1u) mfma1(acc[kh * 3 + 0], av, b0);
+            if ((MASK >> (kh * 3 + 1)) & 1u) mfma1(acc[kh * 3 + 1], av, b1);
+            if ((MASK >> (kh * 3 + 2)) & 1u) mfma1(acc[kh * 3 + 2], av, b2);
         }
     }
     if constexpr (BIAS && rho < Cfg::RW) {
@@ -176,7 +187,10 @@ struct WgCursor {
     int t, b, tx, ty;
 };
 
-template <int NP64, int TW, bool BIAS>
+// S2D: the 3x3 / stride-2 conv in its space-to-depth form (a 3x3 / s1 conv over 4 x s2d_c channels, stylex_internal.h): a
+// 64-channel tile lies in ONE sub-position, whose 1, 2 or 4 structurally non-zero taps are all the block multiplies; its
+// partial goes straight to the FOLDED layout [n][original tap][c] of the stride-2 weight (no dW2, no fold launch).
+template <int NP64, int TW, bool BIAS, bool S2D = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams p, WgArgs wa) {
     using Cfg = WgCfg<NP64, TW>;
     constexpr int TR = Cfg::TR, HWD = Cfg::HWD, XPX = Cfg::XPX, X_PIECES = Cfg::X_PIECES;
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
     static_assert(NSTEP % 2 == 0, "the operand ping-pong restarts at parity 0 every stage");
     static_assert(NSLOT <= 2 * (NSTEP - 1), "at most two DMA pieces per step");
     static_assert(XA <= DA, "issue order inside a stage: the one-ahead stream first");
+    static_assert(!(S2D && BIAS), "the space-to-depth path has no bias sums");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -335,20 +350,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
         for (int k = 0; k < DS; ++k) WG_ISSUE_DY(k)
         WG_END_DY()
     }
-    WgOps o;
+    WgOps o{};  // (zero: a masked variant names fragments it never reads as wait operands)
     wait_vmcnt<WAITN>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue_reads<Cfg, 0>(o, xb, dyb);
     int xslot_c = 0, dslot_c = 0;  // consumer's ring slots
 
     // one step: wait for this step's operands (requested one step ago), request the next step's, MFMAs, DMA issue
     // (two pieces per step from the first step on: everything a stage issues has most of the stage to land)
 #define WG_STEP(S)                                                                     \
     wait_reads<Cfg, S>(o);                                                             \
-    issue_reads<Cfg, (S) + 1>(o, xb, dyb);                                             \
+    issue_reads<Cfg, (S) + 1, MASK_>(o, xb, dyb);                                      \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    step_mfma<Cfg, S, BIAS>(acc, accb, o, do_bias, ones);                              \
+    step_mfma<Cfg, S, BIAS, MASK_>(acc, accb, o, do_bias, ones);                       \
     if constexpr (2 * (S) < NSLOT) { WG_ISSUE(2 * (S)) }                               \
     if constexpr (2 * (S) + 1 < NSLOT) { WG_ISSUE(2 * (S) + 1) }                       \
     __builtin_amdgcn_sched_barrier(0);
@@ -366,33 +380,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
         _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) xb[m_] += dx_;                \
         dyb += dd_;                                                                    \
     }                                                                                  \
-    issue_reads<Cfg, 0>(o, xb, dyb);                                                   \
+    issue_reads<Cfg, 0, MASK_>(o, xb, dyb);                                            \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    step_mfma<Cfg, S, BIAS>(acc, accb, o, do_bias, ones);                              \
+    step_mfma<Cfg, S, BIAS, MASK_>(acc, accb, o, do_bias, ones);                       \
     __builtin_amdgcn_sched_barrier(0);
-
-    for (int j = 0; j < nst; ++j) {
-        WG_STEP(0)
-        WG_STEP(1)
-        WG_STEP(2)
-        WG_STEP(3)
-        WG_STEP(4)
-        if constexpr (NSTEP == 6) {
-            WG_LAST(5)
-        } else {
-            WG_STEP(5)
-            WG_STEP(6)
-            WG_STEP(7)
-            WG_STEP(8)
-            if constexpr (NSTEP == 12) {
-                WG_STEP(9)
-                WG_STEP(10)
-                WG_LAST(11)
-            } else {
-                WG_LAST(9)
-            }
-        }
+    // the stage loop for one tap set (a compile-time mask: a per-tap runtime branch between MFMAs makes every MFMA wait
+    // for its own operand read, conv_wgrad_halo.hip)
+#define WG_LOOP(M)                                        \
+    {                                                     \
+        constexpr unsigned MASK_ = (M);                   \
+        issue_reads<Cfg, 0, MASK_>(o, xb, dyb);           \
+        for (int j = 0; j < nst; ++j) {                   \
+            WG_STEP(0)                                    \
+            WG_STEP(1)                                    \
+            WG_STEP(2)                                    \
+            WG_STEP(3)                                    \
+            WG_STEP(4)                                    \
+            if constexpr (NSTEP == 6) {                   \
+                WG_LAST(5)                                \
+            } else {                                      \
+                WG_STEP(5)                                \
+                WG_STEP(6)                                \
+                WG_STEP(7)                                \
+                WG_STEP(8)                                \
+                if constexpr (NSTEP == 12) {              \
+                    WG_STEP(9)                            \
+                    WG_STEP(10)                           \
+                    WG_LAST(11)                           \
+                } else {                                  \
+                    WG_LAST(9)                            \
+                }                                         \
+            }                                             \
+        }                                                 \
     }
+    const int sub = S2D ? c0 / p.s2d_c : 0;  // sub-position (sy, sx) of this block's channel tile
+    if constexpr (!S2D) {
+        WG_LOOP(WG_ALL_TAPS)
+    } else {
+        if (sub == 0) WG_LOOP(0x010u)
+        else if (sub == 1) WG_LOOP(0x018u)
+        else if (sub == 2) WG_LOOP(0x012u)
+        else WG_LOOP(0x01bu)
+    }
+#undef WG_LOOP
 #undef WG_LAST
 #undef WG_STEP
 #undef WG_ISSUE
@@ -446,6 +476,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
     // ---- partial[split][n][tap][c]; D[i = n][j = c]: col j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int nbase = n0 + (NP64 == 2 ? nb4 : nhalf) * 32;
     const int lj = lane & 31, lh = lane >> 5;
+    if constexpr (S2D) {
+        // folded layout: frame tap (kh2, kw2) of sub-position (sy, sx) is tap (kh, kw) of the stride-2 weight with
+        // kh = kh2 == 0 ? 0 : sy + 1 (stylex_fold_weight_grad_s2d's map read backwards), channel c - sub * s2d_c
+        const int Co = p.s2d_c, sy = sub >> 1, sx = sub & 1;
+        float* outf = p.y + (long)split * N * 9 * Co;
+        const int cl = c0 - sub * Co + cblk * 32 + lj;
+#pragma unroll
+        for (int t2 = 0; t2 < 5; ++t2) {
+            if (t2 == 2) continue;  // frame taps 0, 1, 3, 4
+            const int kh2 = t2 / 3, kw2 = t2 % 3;
+            if ((kh2 == 0 && sy == 0) || (kw2 == 0 && sx == 0)) continue;  // structurally zero for this sub-position
+            const int tap = (kh2 == 0 ? 0 : sy + 1) * 3 + (kw2 == 0 ? 0 : sx + 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                outf[((long)n * 9 + tap) * Co + cl] = acc[t2][r];
+            }
+        }
+        return;
+    }
     float* out = p.y + (long)split * N * 9 * C;
     const int c = c0 + cblk * 32 + lj;
     if (nbase >= N || c0 + cblk * 32 >= C) return;  // N == 32 / C == 32: this wave multiplied the zero half of a row
@@ -465,6 +515,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
 }
 
 template <int NP64, int TW>
+int launch_wg_s2d(const ConvKParams& p, const WgArgs& wa, int blocks, hipStream_t s) {
+    using Cfg = WgCfg<NP64, TW>;
+    static int attr_state = 0;
+    if (attr_state == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_pipe_kernel<NP64, TW, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
+        attr_state = e == hipSuccess ? 1 : -1;
+    }
+    if (attr_state < 0) return STYLEX_NOT_APPLICABLE;
+    stylex_note_kernel("conv3x3_wgrad_pipe_kernel<%d, %d, false, true>", NP64, TW);
+    hipLaunchKernelGGL((conv3x3_wgrad_pipe_kernel<NP64, TW, false, true>), dim3(blocks), dim3(512), Cfg::SMEM, s, p, wa);
+    return (int)hipGetLastError();
+}
+
+template <int NP64, int TW>
 int launch_wg(const ConvKParams& p, const WgArgs& wa, int blocks, bool bias, hipStream_t s) {
     using Cfg = WgCfg<NP64, TW>;
     static bool attr_done = false;
@@ -477,7 +542,7 @@ int launch_wg(const ConvKParams& p, const WgArgs& wa, int blocks, bool bias, hip
         if (e != hipSuccess) return STYLEX_NOT_APPLICABLE;
         attr_done = true;
     }
-    stylex_note_kernel("conv3x3_wgrad_pipe_kernel<%d, %d, %s>", NP64, TW, bias ? "true" : "false");
+    stylex_note_kernel("conv3x3_wgrad_pipe_kernel<%d, %d, %s, false>", NP64, TW, bias ? "true" : "false");
     if (bias) hipLaunchKernelGGL((conv3x3_wgrad_pipe_kernel<NP64, TW, true>), dim3(blocks), dim3(512), Cfg::SMEM, s, p, wa);
     else hipLaunchKernelGGL((conv3x3_wgrad_pipe_kernel<NP64, TW, false>), dim3(blocks), dim3(512), Cfg::SMEM, s, p, wa);
     return (int)hipGetLastError();
@@ -511,7 +576,8 @@ bool stylex_wgrad_pipe_applicable(const ConvKParams& p) {
     const char* env = getenv("STYLEX_WGRAD_PIPE");  // read per launch: A/B tests toggle it in-process
     if (env && env[0] == '0') return false;
     if (!p.act_bf16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return false;
-    if (p.s2d_c || p.a2_scale) return false;
+    if (p.a2_scale) return false;
+    if (p.s2d_c && (p.Ck != 4 * p.s2d_c || p.s2d_c % 64 != 0 || p.N % 64 != 0 || p.a_scale)) return false;
     if ((p.Ck % 64 != 0 && p.Ck != 32) || (p.N % 64 != 0 && p.N != 32)) return false;
     const int tw = p.Wo >= 32 ? 32 : 16;
     if (p.Wo % tw != 0 || p.Wo < 16) return false;
@@ -567,6 +633,12 @@ int stylex_launch_wgrad_pipe(ConvKParams p, float* partial, hipStream_t s, int* 
     wa.otiles = ((p.N + 64 * np64 - 1) / (64 * np64)) * wa.c_tiles;
     p.y = partial;
     *slices_out = slices;
+    if (p.s2d_c) {  // the partial / result is the FOLDED [N][9][s2d_c] gradient (stylex_launch_wgrad folds nothing more)
+        if (bias_done) *bias_done = 0;
+        p.bias_partial = nullptr;
+        if (np64 == 2) return tw == 32 ? launch_wg_s2d<2, 32>(p, wa, blocks, s) : launch_wg_s2d<2, 16>(p, wa, blocks, s);
+        return tw == 32 ? launch_wg_s2d<1, 32>(p, wa, blocks, s) : launch_wg_s2d<1, 16>(p, wa, blocks, s);
+    }
     const bool bias = p.bias_partial != nullptr;
     if (bias_done) *bias_done = bias ? 1 : 0;
     if (np64 == 2) return tw == 32 ? launch_wg<2, 32>(p, wa, blocks, bias, s) : launch_wg<2, 16>(p, wa, blocks, bias, s);

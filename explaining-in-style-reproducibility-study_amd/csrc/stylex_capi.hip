@@ -512,6 +512,31 @@ int stylex_conv2d_bwd_weight_bias(const void* x, const void* dy, float* dw, floa
     return stylex_launch_wgrad(p, (float*)workspace, dw, precision, (hipStream_t)stream, db, db_written);
 }
 
+int stylex_conv2d_bwd_weight_s2d_supported(const int64_t* sh, int s2d_c, int precision) {
+    if (!conv_shape_ok(sh) || precision != STYLEX_BF16_ACT || s2d_c <= 0) return 0;
+    ConvKParams p;
+    wgrad_params(p, sh);
+    p.act_bf16 = 1;
+    p.s2d_c = s2d_c;
+    return stylex_wgrad_pipe_applicable(p) ? 1 : 0;
+}
+
+int stylex_conv2d_bwd_weight_s2d(const void* x2, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
+                                 const int64_t* sh, int s2d_c, int precision, void* stream) {
+    if (!x2 || !dy || !dw || !workspace || !conv_shape_ok(sh) || precision != STYLEX_BF16_ACT || s2d_c <= 0) return STYLEX_EINVAL;
+    if (workspace_bytes < stylex_conv2d_bwd_weight_workspace_bytes(sh)) return STYLEX_EWORKSPACE;
+    ConvKParams p;
+    wgrad_params(p, sh);
+    p.a = (const float*)x2;
+    p.a2 = (const float*)dy;
+    p.act_bf16 = 1;
+    p.s2d_c = s2d_c;
+    if (!stylex_wgrad_pipe_applicable(p)) return STYLEX_EINVAL;
+    double flops = 2.0 * p.M * (double)p.N * p.Ck * 9 / 4.0;
+    ScopedTimer tm(2, flops, conv_bytes(sh, STYLEX_BF16_ACT, true), (hipStream_t)stream, sh, s2d_c);
+    return stylex_launch_wgrad_s2d_folded(p, (float*)workspace, dw, (hipStream_t)stream);
+}
+
 int stylex_pack_weight_s2d(const float* w, void* wf, void* wb, const int64_t* sh, void* stream) {
     if (!w || sh[0] < 1 || sh[1] < 1 || sh[2] != 3 || sh[3] != 3) return STYLEX_EINVAL;
     return stylex_launch_pack_s2d(w, wf, wb, (int)sh[0], (int)sh[1], (hipStream_t)stream);

@@ -102,6 +102,8 @@ int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* 
 bool stylex_wgrad_pipe_applicable(const ConvKParams& p);
 void stylex_wgrad_pipe_plan(const ConvKParams& p, int* slices, int* tiles_per_split, int* blocks);
 int stylex_launch_wgrad_pipe(ConvKParams p, float* partial, hipStream_t s, int* slices_out, int* bias_done = nullptr);
+// space-to-depth stride-2 conv (p.s2d_c > 0): partial slices and result in the FOLDED layout [N][9][s2d_c] -> dw[N][s2d_c][3][3]
+int stylex_launch_wgrad_s2d_folded(ConvKParams p, float* partial, float* dw_oihw, hipStream_t s);
 
 // general bf16 weight gradient with LDS transpose reads (conv_wgrad_tr.hip)
 bool stylex_wgrad_tr_applicable(const ConvKParams& p);

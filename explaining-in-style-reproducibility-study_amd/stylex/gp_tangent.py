@@ -199,8 +199,7 @@ class _DRealPenalty(torch.autograd.Function):
             gw3 = gb3 = None
             if downsample:
                 if s2d:
-                    gw3 = hb.fold_weight_grad_s2d(hb.conv2d_bwd_weight(operand(xb, ab), gz3, (w3.shape[0], 4 * n, 3, 3), 1, 1,
-                                                                       prec, s2d_c=n), tuple(w3.shape))
+                    gw3 = hb.conv2d_bwd_weight_s2d(operand(xb, ab), gz3, tuple(w3.shape), prec)
                 else:
                     gw3 = hb.conv2d_bwd_weight(operand(xb, ab), gz3, tuple(w3.shape), 2, 1, prec)
             if wsc != 1.0:

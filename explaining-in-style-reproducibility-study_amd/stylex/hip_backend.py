@@ -78,6 +78,9 @@ SIGNATURES = {
     "stylex_subsample2_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_pack_weight_s2d": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_fold_weight_grad_s2d": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_conv2d_bwd_weight_s2d_supported": (ctypes.c_int, [_i64p, ctypes.c_int, ctypes.c_int]),
+    "stylex_conv2d_bwd_weight_s2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_rgb_up_blur_add_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -734,6 +737,35 @@ def pack_weight_s2d(w, scale=None):
     if key is not None:
         _cache_put(key, w, wf, wb, recipe=lambda p: pack_weight_s2d(p, scale))
     return wf, wb
+
+
+_S2D_WGRAD_OK = {}
+
+
+def conv2d_bwd_weight_s2d(x2, dy, w_shape, precision):
+    """Weight gradient [N][C][3][3] of the 3x3 / stride-2 conv whose (blurred) input is given space-to-depth (x2: [B, 4C,
+    H/2, W/2]).  One call on the pipelined LDS-DMA weight-gradient kernel where it applies (stylex_conv2d_bwd_weight_s2d:
+    folded layout written directly), else the weight gradient of the s2d conv + stylex_fold_weight_grad_s2d."""
+    lib = _ensure_device(x2)
+    n, c = int(w_shape[0]), int(w_shape[1])
+    ws2 = (n, 4 * c, 3, 3)
+    sh = conv_shape(x2.shape, ws2, 1, 1)
+    key = (tuple(sh), precision)
+    ok = _S2D_WGRAD_OK.get(key)
+    if ok is None:
+        ok = _S2D_WGRAD_OK[key] = bool(precision == BF16_ACT and os.environ.get("STYLEX_WGRAD_PIPE", "1") != "0" and
+                                       lib.stylex_conv2d_bwd_weight_s2d_supported(_shape(*sh), c, precision))
+    if ok and os.environ.get("STYLEX_WGRAD_PIPE", "1") != "0":
+        adt = act_dtype(precision)
+        assert is_cl(x2) and is_cl(dy) and x2.dtype == adt and dy.dtype == adt, (x2.dtype, dy.dtype, adt)
+        shp = _shape(*sh)
+        nbytes = lib.stylex_conv2d_bwd_weight_workspace_bytes(shp)
+        ws = _empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
+        dw = _empty((n, c, 3, 3), dtype=torch.float32, device=x2.device)
+        _check(lib.stylex_conv2d_bwd_weight_s2d(_ptr(x2), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, c, precision, _stream()),
+               "stylex_conv2d_bwd_weight_s2d")
+        return dw
+    return fold_weight_grad_s2d(conv2d_bwd_weight(x2, dy, ws2, 1, 1, precision, s2d_c=c), (n, c, 3, 3))
 
 
 def fold_weight_grad_s2d(dw2, w_shape):

@@ -126,8 +126,7 @@ def _bwd_data(gy, w, x_shape, stride, pad, s2d):
 
 def _bwd_weight(x, gy, w_shape, stride, pad, s2d):
     if s2d:
-        dw2 = hb.conv2d_bwd_weight(x, gy, (w_shape[0], 4 * s2d, 3, 3), 1, 1, _PRECISION, s2d_c=s2d)
-        return hb.fold_weight_grad_s2d(dw2, tuple(w_shape))
+        return hb.conv2d_bwd_weight_s2d(x, gy, tuple(w_shape), _PRECISION)
     return hb.conv2d_bwd_weight(x, gy, w_shape, stride, pad, _PRECISION)
 
 
@@ -715,8 +714,7 @@ class _DownS2DFast(torch.autograd.Function):
             gx2 = hb.conv2d_bwd_data(gz, None, tuple(x2.shape), 1, 1, _PRECISION, packed=wb2, w_shape=(n, 4 * c, 3, 3),
                                      s2d_c=c)
         if ctx.needs_input_grad[1]:
-            dw2 = hb.conv2d_bwd_weight(x2, gz, (n, 4 * c, 3, 3), 1, 1, _PRECISION, s2d_c=c)
-            gw = hb.fold_weight_grad_s2d(dw2, tuple(w.shape))
+            gw = hb.conv2d_bwd_weight_s2d(x2, gz, tuple(w.shape), _PRECISION)
         gb = gsum if want_gb else None
         return gx2, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None
 
@@ -909,8 +907,7 @@ class _DBlockFast(torch.autograd.Function):
                 gxb = hb.conv2d_bwd_data(gz3, None, tuple(xb.shape), 1, 1, prec, packed=wb2, w_shape=(w3.shape[0], 4 * n, 3, 3),
                                          s2d_c=n)
                 if want_w:
-                    gw3 = hb.fold_weight_grad_s2d(hb.conv2d_bwd_weight(xb, gz3, (w3.shape[0], 4 * n, 3, 3), 1, 1, prec, s2d_c=n),
-                                                  tuple(w3.shape))
+                    gw3 = hb.conv2d_bwd_weight_s2d(xb, gz3, tuple(w3.shape), prec)
                 gz2 = hb.blur3x3_s2d_bwd(gxb, gate=y2, gate_mask=m2)  # blur adjoint + LeakyReLU derivative of y2, one pass
             else:
                 wb3 = hb.pack_weight(w3, False, True, prec, scale=c)[1] if alg else None

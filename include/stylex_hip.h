@@ -220,6 +220,17 @@ int stylex_subsample2_fwd(const void* x, void* y, const int64_t* shape, int act_
 int stylex_subsample2_bwd(const void* dy, void* dx, const int64_t* shape, int act_dtype, void* stream);
 int stylex_pack_weight_s2d(const float* w_oihw, void* w_fwd, void* w_bwd, const int64_t* shape, void* stream);
 int stylex_fold_weight_grad_s2d(const float* dw_s2d, float* dw_oihw, const int64_t* shape, void* stream);
+/* Round 5: the weight gradient of that stride-2 conv in ONE call, already in the parameter layout dw[N][s2d_c][3][3]
+ * (the nn.Conv2d(…, 3, padding=1, stride=2) weight of DiscriminatorBlock.downsample, stylex_train.py:733-736) —
+ * x2 / dy / shape / workspace as stylex_conv2d_bwd_weight with s2d_c > 0 (shape describes the 3x3/s1/p1 conv over
+ * 4*s2d_c channels; workspace of stylex_conv2d_bwd_weight_workspace_bytes(shape)).  Served by the pipelined LDS-DMA
+ * weight-gradient kernel, whose blocks each multiply the 1, 2 or 4 live taps of one sub-position and write the folded
+ * layout directly: no dW2 tensor, no fold launch.  _supported returns 1 when a launch with this shape (bf16 activations,
+ * 16-byte aligned tensors) runs there, else 0 — then stylex_conv2d_bwd_weight_s2d returns STYLEX_EINVAL and the caller
+ * uses stylex_conv2d_bwd_weight + stylex_fold_weight_grad_s2d. */
+int stylex_conv2d_bwd_weight_s2d_supported(const int64_t* shape, int s2d_c, int precision);
+int stylex_conv2d_bwd_weight_s2d(const void* x2, const void* dy, float* dw_oihw, void* workspace, int64_t workspace_bytes,
+                                 const int64_t* shape, int s2d_c, int precision, void* stream);
 
 /* y = leaky_relu(x + bias[c] (+ noise[b][w][h]*noise_w[c] + noise_b[c]), 0.2)
  * (nn.Conv2d bias + leaky_relu, stylex_train.py:340-341,726-731; noise add :696-714).

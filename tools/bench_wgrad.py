@@ -62,6 +62,62 @@ def ref_wgrad(x, dy, scale=None):
     return out
 
 
+# (name, C, N, res) of the stride-2 convs whose input arrives space-to-depth: x2 [B, 4C, res/2, res/2]
+S2D_SHAPES = [("s2 64->64@256", 64, 64, 256), ("s2 128->128@128", 128, 128, 128), ("s2 256->256@64", 256, 256, 64),
+              ("s2 512->512@32", 512, 512, 32)]
+
+
+def fold_ref(dw2, c):
+    """stylex_fold_weight_grad_s2d in torch: dW[n][c][kh][kw] = dW2[n][(sy*2+sx)*C + c][kh2][kw2]"""
+    n = dw2.shape[0]
+    out = torch.empty(n, c, 3, 3, dtype=dw2.dtype, device=dw2.device)
+    for kh in range(3):
+        for kw in range(3):
+            kh2, sy = (0, 1) if kh == 0 else (1, kh - 1)
+            kw2, sx = (0, 1) if kw == 0 else (1, kw - 1)
+            s_ = sy * 2 + sx
+            out[:, :, kh, kw] = dw2[:, s_ * c:(s_ + 1) * c, kh2, kw2]
+    return out
+
+
+def s2d_section(a, prec, dev):
+    print("---- space-to-depth stride-2 convs (folded weight gradient [N][C][3][3])")
+    for (name, c, n, res) in S2D_SHAPES:
+        if a.only and a.only not in name:
+            continue
+        h = res // 2
+        if not a.no_check:
+            b = 2
+            x2 = torch.randn(b, 4 * c, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(b, n, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            ref = fold_ref(ref_wgrad(x2.float(), dy.float()), c)
+            errs = {}
+            for mode in ("1", "0"):
+                os.environ["STYLEX_WGRAD_PIPE"] = mode
+                hb._S2D_WGRAD_OK.clear()
+                dw = hb.conv2d_bwd_weight_s2d(x2, dy, (n, c, 3, 3), prec)
+                torch.cuda.synchronize()
+                errs[mode] = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
+            print("%-16s B=%d | rel err new %.2e old %.2e" % (name, b, errs["1"], errs["0"]))
+            assert errs["1"] < 2e-5, errs
+        if a.check_only:
+            continue
+        for b in (a.batch, 2 * a.batch):
+            x2 = torch.randn(b, 4 * c, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(b, n, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            t = {}
+            for mode in (("1",) if a.new_only else ("1", "0", "1", "0")):
+                os.environ["STYLEX_WGRAD_PIPE"] = mode
+                hb._S2D_WGRAD_OK.clear()
+                fn = lambda: hb.conv2d_bwd_weight_s2d(x2, dy, (n, c, 3, 3), prec)
+                t[mode] = min(t.get(mode, 1e9), timeit(fn, a.iters))
+            t.setdefault("0", float("nan"))
+            fl = 2.0 * b * h * h * n * c * 9
+            print("%-16s %5d | %9.3f %9.3f | %7.1f %7.1f | %.2fx" % (name, b, t["1"], t["0"], fl / t["1"] / 1e9, fl / t["0"] / 1e9,
+                                                                    t["0"] / t["1"]))
+            del x2, dy
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
@@ -70,6 +126,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--new-only", action="store_true", help="time the new kernel only (PMC runs)")
     ap.add_argument("--only", default="")
+    ap.add_argument("--skip-s2d", action="store_true")
     ap.add_argument("--np-ab", action="store_true", help="third arm: the new kernel with 64-channel tiles forced (STYLEX_WGRAD_PIPE_NP=1)")
     a = ap.parse_args()
     prec = hb.BF16_ACT
@@ -105,6 +162,9 @@ def main():
     if not a.no_check:
         print("worst relative error of the new kernel: %.3e" % worst)
     assert worst < 2e-5, worst  # same bf16 operands, fp32 accumulation: only the summation order differs
+    if not a.skip_s2d:
+        s2d_section(a, prec, dev)
+    os.environ["STYLEX_WGRAD_PIPE"] = "1"
     if a.check_only:
         return
 
@@ -141,7 +201,8 @@ def main():
                 tot[0] += t["1"]
                 tot[1] += t["0"]
             del x, dy
-    print("TOTAL at B=%d: new %.3f ms, old %.3f ms (%.2fx)" % (a.batch, tot[0], tot[1], tot[1] / tot[0]))
+    if tot[0] > 0:
+        print("TOTAL at B=%d: new %.3f ms, old %.3f ms (%.2fx)" % (a.batch, tot[0], tot[1], tot[1] / tot[0]))
 
 
 if __name__ == "__main__":
