@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pipe_kernel(ConvKParams 
         for (int r = 0; r < 16; ++r) p.bias_partial[(long)split * N + nbase + (r & 3) + 8 * (r >> 2) + 4 * lh] = accb[r];
     }
     // modulated layer: the whole split lies in one sample (plan), its x scale is a factor of the sum
+    if (c >= C) return;  // C == 8: lanes 8 .. 31 of the first channel block multiplied zeros
     const float xsc = p.a_scale ? p.a_scale[(long)(t_begin / (wa.tx_count * wa.ty_count)) * C + c] : 1.f;  // cx.b has moved on
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -578,6 +579,9 @@ bool stylex_wgrad_pipe_applicable(const ConvKParams& p) {
     if (!p.act_bf16 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return false;
     if (p.a2_scale) return false;
     if (p.s2d_c && (p.Ck != 4 * p.s2d_c || p.s2d_c % 64 != 0 || p.N % 64 != 0 || p.a_scale)) return false;
+    // input channels: whole 64-channel tiles, or exactly 32 (the generator's last block).  The padded RGB input of the
+    // first conv (C = 8: one 16-byte slot of the row) runs correctly here as well but no faster than the flattened-tap
+    // kernel of conv_wgrad_tr.hip (0.212 vs 0.212 ms at B = 64, 0.417 vs 0.402 at 128: profiles/r05_l_wgrad_ab.txt), which keeps it
     if ((p.Ck % 64 != 0 && p.Ck != 32) || (p.N % 64 != 0 && p.N != 32)) return false;
     const int tw = p.Wo >= 32 ? 32 : 16;
     if (p.Wo % tw != 0 || p.Wo < 16) return false;

@@ -18,8 +18,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WGRAD = ("conv3x3_wgrad_halo_kernel", "conv3x3_wgrad_halo_dma_kernel", "conv_wgrad_tr_kernel", "conv_wgrad_kernel")
-WGRAD_AUX = ("wgrad_reduce_kernel", "fold_weight_s2d_kernel")
+WGRAD = ("conv3x3_wgrad_pipe_kernel", "conv3x3_wgrad_halo_kernel", "conv3x3_wgrad_halo_dma_kernel", "conv_wgrad_tr_kernel", "conv_wgrad_kernel")
+WGRAD_AUX = ("wgrad_reduce_kernel", "wgrad_reduce_small_kernel", "fold_weight_s2d_kernel")
 FWD = ("conv3x3_halo_bf16_kernel", "conv3x3_halo_dma_kernel", "conv_igemm_kernel", "conv_gather_kernel", "conv3x3_pipe_kernel", "conv3x3_line64_kernel", "conv3x3_rgb_kernel")  # forward and data gradient share these kernels
 FWD_AUX = ("splitk_epilogue_kernel", "pack_weight_kernel", "pack_weight_s2d_kernel")
 
@@ -43,10 +43,10 @@ def run_pass(counter, bench_args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))
     ap.add_argument("--precision", default="bf16")
     a = ap.parse_args()
-    bench_args = ["--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--roofline-steps", "0", "--fp32-steps", "0", "--precision", a.precision]
+    bench_args = ["--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--roofline-steps", "0", "--fp32-steps", "0", "--bench-a-steps", "0", "--precision", a.precision]
     fetch, cnt = run_pass("FETCH_SIZE", bench_args)
     write, _ = run_pass("WRITE_SIZE", bench_args)
     per_kernel = {}
