@@ -450,6 +450,8 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
         if (!on_s2d || !on64 || p.s2d_c % 64 != 0) return STYLEX_NOT_APPLICABLE;
         if (p.flip_taps) {
             if (p.flags || p.N != 4 * p.s2d_c || p.Ck < 64) return STYLEX_NOT_APPLICABLE;
+            const int rc = stylex_launch_s2d_dgrad(p, s);  // round 5: one staged halo for all four sub-positions
+            if (rc != STYLEX_NOT_APPLICABLE) return rc;
         } else {
             static const bool on_fwd = !(getenv("STYLEX_HALO_DMA_S2D_FWD") && getenv("STYLEX_HALO_DMA_S2D_FWD")[0] == '0');
             if (!on_fwd || (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_RESIDUAL)) || p.Ck != 4 * p.s2d_c || p.N % 64 != 0)

@@ -88,6 +88,9 @@ int stylex_launch_rgb(const ConvKParams& p, hipStream_t s);
 int stylex_launch_pipe(const ConvKParams& p, hipStream_t s);
 int stylex_launch_line64(const ConvKParams& p, hipStream_t s);
 
+// round 5: data gradient of the space-to-depth stride-2 conv, all four sub-positions per block (conv_s2d_dgrad.hip)
+int stylex_launch_s2d_dgrad(const ConvKParams& p, hipStream_t s);
+
 // LDS-DMA implicit GEMM for the <= 8x8 px layers (conv_gather.hip): writes fp32 partials and fills p.ksplit / p.partial
 // for the split-K epilogue kernel
 int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_bytes, hipStream_t s);

@@ -216,6 +216,31 @@ def test_s2d_downsample_path_matches_strided_conv(shape):
             close(a, b_, TOLBF * 2, "grad %s fast=%s" % (nm, fast))
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 64, 24, 64), (1, 128, 128, 32, 32), (2, 64, 256, 8, 96), (5, 192, 64, 16, 32)])
+def test_s2d_data_gradient_all_subpositions_kernel(shape, monkeypatch):
+    """conv_s2d_dgrad.hip (round 5: one staged gradient halo for all four sub-positions) against the fp64 definition — the
+    gradient of conv2d(x, w, stride 2, pad 1) w.r.t. x, stored space-to-depth — and against the per-sub-position kernel
+    it replaces (STYLEX_S2D_DGRAD=0): same bf16 operands, same K order, so the two must agree to the last bit.  Shapes
+    (B, C, N, half-res H, W): ragged tile lists (3, 5 images over 256 blocks), one / several 64-channel groups, 2-8 K
+    stages, tiles on every image border."""
+    B, C, N, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn(N, C, 3, 3, generator=g) / 24).bfloat16().float().to(DEV)
+    dy = torch.randn(B, N, H, W, generator=g).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
+    _, wb2 = hb.pack_weight_s2d(w)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("STYLEX_S2D_DGRAD", mode)
+        outs[mode] = hb.conv2d_bwd_data(dy, None, (B, 4 * C, H, W), 1, 1, hb.BF16_ACT, packed=wb2, w_shape=(N, 4 * C, 3, 3),
+                                        s2d_c=C).float().cpu()
+    x = torch.zeros(B, C, 2 * H, 2 * W, dtype=torch.float64, requires_grad=True)
+    (gx,) = torch.autograd.grad(F.conv2d(x, w.double().cpu(), stride=2, padding=1), x, dy.double().cpu())
+    ref = gx.view(B, C, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 4 * C, H, W)
+    scale = float(ref.abs().max())
+    assert float((outs["1"].double() - ref).abs().max()) / scale < 6e-3  # bf16 output rounding (2^-8 of the value)
+    assert torch.equal(outs["1"], outs["0"]), float((outs["1"] - outs["0"]).abs().max())
+
+
 def test_conv_bias_lrelu_and_second_order():
     """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
     g = torch.Generator().manual_seed(5)

@@ -23,6 +23,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     ("conv_wgrad_pipe.hip", ["conv3x3_wgrad_pipe_kernelILi2ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi32ELb0",
                              "conv3x3_wgrad_pipe_kernelILi1ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi16ELb1",
                              "conv3x3_wgrad_pipe_kernelILi1ELi16ELb0"]),
+    ("conv_s2d_dgrad.hip", ["conv_s2d_dgrad_kernel"]),
 ])
 def test_hot_kernels_use_no_scratch(tmp_path, source, kernels):
     out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
