@@ -362,6 +362,7 @@ def main(argv=None, backend="nccl", device=None):
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--roofline-steps", type=int, default=4)
+    ap.add_argument("--per-layer-top", type=int, default=14, help="rows of roofline.per_layer.layers (0 = every layer)")
     ap.add_argument("--fp32-steps", type=int, default=4,
                     help="timed train() calls of the fp32 parity mode for the fp32_parity_mode sub-record (0 = skip)")
     ap.add_argument("--bench-a-steps", type=int, default=12,
@@ -528,7 +529,7 @@ def main(argv=None, backend="nccl", device=None):
                              "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4),
                              "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                              "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)} for kn, v in ktable[:12]],
-                "per_layer": layer_roofline(cls_layers, args.precision),
+                "per_layer": layer_roofline(cls_layers, args.precision, args.per_layer_top or None),
                 "classes": {k: {"tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "ms": round(v["ms"], 2),
                                 "launches": v["launches"]} for k, v in rep.items()}}
     if world > 1:

@@ -440,6 +440,10 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(p.x2) & 15) || (reinterpret_cast<uintptr_t>(p.w2) & 15)) return STYLEX_NOT_APPLICABLE;
     }
     if ((p.flags & STYLEX_EPI_GATE) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15))) return STYLEX_NOT_APPLICABLE;
+    if (p.s2d_c && on_s2d && !p.flip_taps) {  // round 5: the forward as one pipelined K loop (also 16-pixel-wide images)
+        const int rc = stylex_launch_s2d_fwd(p, s);
+        if (rc != STYLEX_NOT_APPLICABLE) return rc;
+    }
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) ||
         (reinterpret_cast<uintptr_t>(p.y) & 15))

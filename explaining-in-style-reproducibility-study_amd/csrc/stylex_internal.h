@@ -90,6 +90,8 @@ int stylex_launch_line64(const ConvKParams& p, hipStream_t s);
 
 // round 5: data gradient of the space-to-depth stride-2 conv, all four sub-positions per block (conv_s2d_dgrad.hip)
 int stylex_launch_s2d_dgrad(const ConvKParams& p, hipStream_t s);
+// round 5: forward of the space-to-depth stride-2 conv as one pipelined K loop over the sub-position phases (conv_s2d_fwd.hip)
+int stylex_launch_s2d_fwd(const ConvKParams& p, hipStream_t s);
 
 // LDS-DMA implicit GEMM for the <= 8x8 px layers (conv_gather.hip): writes fp32 partials and fills p.ksplit / p.partial
 // for the split-K epilogue kernel
