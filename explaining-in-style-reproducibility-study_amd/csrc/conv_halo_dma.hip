@@ -440,8 +440,8 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(p.x2) & 15) || (reinterpret_cast<uintptr_t>(p.w2) & 15)) return STYLEX_NOT_APPLICABLE;
     }
     if ((p.flags & STYLEX_EPI_GATE) && (!p.residual || (reinterpret_cast<uintptr_t>(p.residual) & 15))) return STYLEX_NOT_APPLICABLE;
-    if (p.s2d_c && on_s2d && !p.flip_taps) {  // round 5: the forward as one pipelined K loop (also 16-pixel-wide images)
-        const int rc = stylex_launch_s2d_fwd(p, s);
+    if (p.s2d_c && on_s2d) {  // round 5: the stride-2 kernels of their own (also 16-pixel-wide images)
+        const int rc = p.flip_taps ? stylex_launch_s2d_dgrad(p, s) : stylex_launch_s2d_fwd(p, s);
         if (rc != STYLEX_NOT_APPLICABLE) return rc;
     }
     if (p.N % 8 != 0 || p.Ck % 8 != 0 || p.Wo < 32 || p.Ho < 16) return STYLEX_NOT_APPLICABLE;
@@ -454,8 +454,6 @@ int stylex_launch_halo_dma(const ConvKParams& p, hipStream_t s) {
         if (!on_s2d || !on64 || p.s2d_c % 64 != 0) return STYLEX_NOT_APPLICABLE;
         if (p.flip_taps) {
             if (p.flags || p.N != 4 * p.s2d_c || p.Ck < 64) return STYLEX_NOT_APPLICABLE;
-            const int rc = stylex_launch_s2d_dgrad(p, s);  // round 5: one staged halo for all four sub-positions
-            if (rc != STYLEX_NOT_APPLICABLE) return rc;
         } else {
             static const bool on_fwd = !(getenv("STYLEX_HALO_DMA_S2D_FWD") && getenv("STYLEX_HALO_DMA_S2D_FWD")[0] == '0');
             if (!on_fwd || (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_RESIDUAL)) || p.Ck != 4 * p.s2d_c || p.N % 64 != 0)

@@ -43,15 +43,18 @@ namespace {
 typedef StylexS2dDgradArgs SdArgs;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-constexpr int TH = 8, TW = 32, HR = TH + 1, HC = TW + 1, NPX = HR * HC;  // 297 halo pixels (offsets 0, +1 only)
-constexpr int H_PIECES = (NPX + 15) / 16;                                // 19 DMA pieces of 16 pixel rows x 64 B
-constexpr int H_STAGE = H_PIECES * 1024;
-constexpr int W_ROWS = 9 * 64, W_PIECES = W_ROWS / 16;                   // nine (sub-position, tap) slots x 64 channels
-constexpr int W_STAGE = W_PIECES * 1024;
-constexpr int W_BASE = 2 * H_STAGE;
-constexpr int DUMP_BASE = W_BASE + 2 * W_STAGE;
-constexpr int SMEM = DUMP_BASE + 1024;                                   // 112.6 KB: one block per CU
-constexpr int HS = (H_PIECES + 7) / 8, WS = (W_PIECES + 7) / 8, NSLOT = HS + WS;  // 3 + 5 DMA instructions per wave and stage
+// block = NW waves: 8 (a 64-channel group in four sub-positions = 256 output channels, one block per CU) or 4 (a 32-channel
+// group = 128 output channels, two blocks per CU); pixel tile 8 x 32 or 16 x 16 (TW = 16: images 16 pixels wide)
+template <int TW_, int NW_>
+struct SdCfg {
+    static constexpr int TW = TW_, NW = NW_, TH = 256 / TW, HR = TH + 1, HC = TW + 1, NPX = HR * HC;  // halo: offsets 0, +1 only
+    static constexpr int H_PIECES = (NPX + 15) / 16, H_STAGE = H_PIECES * 1024;  // DMA pieces of 16 pixel rows x 64 B
+    static constexpr int CG = NW * 8;                                            // channels of a group (rows of a weight slot)
+    static constexpr int W_ROWS = 9 * CG, W_PIECES = W_ROWS / 16, W_STAGE = W_PIECES * 1024;  // nine (sub-position, tap) slots
+    static constexpr int W_BASE = 2 * H_STAGE, DUMP_BASE = W_BASE + 2 * W_STAGE, SMEM = DUMP_BASE + 1024;  // 112.6 / 75 KB
+    static constexpr int HS = (H_PIECES + NW - 1) / NW, WS = (W_PIECES + NW - 1) / NW, NSLOT = HS + WS;  // DMA instructions per wave and stage
+    static_assert(NSLOT == 8 || NSLOT == 10, "3 + 5 or 5 + 5 DMA instructions per wave and stage");
+};
 constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* smem, int lds_off, unsigned voff, unsigned soff) {
@@ -91,12 +94,12 @@ __device__ __forceinline__ void read_b(SdOps& o, const int (&bb)[3][2], int lk) 
             lds_read16<0>(o.b[KC][h][d], bb[h][d] + (((KC * 2 + lk) ^ ((bb[h][d] >> 8) & 3)) << 4));
 }
 // slots 3 G .. 3 G + 2 at k-step KC into register set PAR
-template <int G, int KC, int PAR>
+template <int CG, int G, int KC, int PAR>
 __device__ __forceinline__ void read_a(SdOps& o, int ab, int af, int lk) {
     const int addr = ab + (((KC * 2 + lk) ^ af) << 4);
-    lds_read16<((3 * G + 0) * 64) * 64>(o.a[PAR][0], addr);
-    lds_read16<((3 * G + 1) * 64) * 64>(o.a[PAR][1], addr);
-    lds_read16<((3 * G + 2) * 64) * 64>(o.a[PAR][2], addr);
+    lds_read16<((3 * G + 0) * CG) * 64>(o.a[PAR][0], addr);
+    lds_read16<((3 * G + 1) * CG) * 64>(o.a[PAR][1], addr);
+    lds_read16<((3 * G + 2) * CG) * 64>(o.a[PAR][2], addr);
 }
 __device__ __forceinline__ void wait_all(SdOps& o) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -116,14 +119,19 @@ __device__ __forceinline__ void step_mfma(f32x16 (&acc)[2][4], const SdOps& o) {
     }
 }
 
-__global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, SdArgs sa) {
+template <int TW, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams p, SdArgs sa) {
+    using Cfg = SdCfg<TW, NW>;
+    constexpr int TH = Cfg::TH, HC = Cfg::HC, NPX = Cfg::NPX, H_PIECES = Cfg::H_PIECES, H_STAGE = Cfg::H_STAGE, CG = Cfg::CG;
+    constexpr int W_PIECES = Cfg::W_PIECES, W_STAGE = Cfg::W_STAGE, W_BASE = Cfg::W_BASE, DUMP_BASE = Cfg::DUMP_BASE;
+    constexpr int HS = Cfg::HS, WS = Cfg::WS, NSLOT = Cfg::NSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = __builtin_amdgcn_readfirstlane(p.Ho), W = __builtin_amdgcn_readfirstlane(p.Wo);
     const int NI = __builtin_amdgcn_readfirstlane(p.Ck);     // gz channels = K
     const int C = __builtin_amdgcn_readfirstlane(p.s2d_c);   // channels per sub-position; output pixel = 4 C channels
-    const int cgs = C >> 6, tiles_x = W >> 5, tiles_y = H >> 3, tpi = tiles_x * tiles_y;
+    const int cgs = C / CG, tiles_x = W / TW, tiles_y = H / TH, tpi = tiles_x * tiles_y;
     const int nch = NI >> 5;                                 // 32-channel K stages per tile
 
     // static tile list, XCD-contiguous (conv_pipe.hip): the channel groups of one pixel tile are neighbours
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
     auto decode = [&](int k, int& b, int& y0, int& x0, int& c0) {
         const int t = xs + bslot + k * nslots;
         int pt = fastdiv(t, sa.m_cg);
-        c0 = (t - pt * cgs) * 64;
+        c0 = (t - pt * cgs) * CG;
         b = fastdiv(pt, sa.m_tpi);
         pt -= b * tpi;
         const int ty = fastdiv(pt, sa.m_tx);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
     int hdst[HS];
 #pragma unroll
     for (int k = 0; k < HS; ++k) {
-        const int piece = wave + 8 * k;
+        const int piece = wave + NW * k;
         const int R = piece * 16 + prow;
         const int hr = R / HC, hc = R - hr * HC;
         const bool ok = piece < H_PIECES && R < NPX;
@@ -166,9 +174,9 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
     int wdst[WS];
 #pragma unroll
     for (int k = 0; k < WS; ++k) {
-        const int piece = wave + 8 * k;
+        const int piece = wave + NW * k;
         const int wr = piece * 16 + prow;
-        const int j = wr >> 6, oc = wr & 63;
+        const int j = wr / CG, oc = wr % CG;
         const int s = j == 0 ? 0 : j <= 2 ? 1 : j <= 4 ? 2 : 3;
         const int tap = (j == 2 || j == 6) ? 5 : (j == 4 || j == 7) ? 7 : j == 8 ? 8 : 4;
         vw[k] = piece < W_PIECES ? (((unsigned)((s * C + oc) * 9 + (8 - tap)) * (unsigned)NI + lslot * 8u) * 2u) : OOB;
@@ -205,13 +213,16 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
     // ---- wave roles and operand addressing: every wave runs the SAME instruction stream (a per-quartet tap split made the
     // accumulators a two-way phi and spilled 700 registers): row pair rp of the tile, 32-channel half jt of the 64-channel
     // group, all four sub-positions
+    // (NW = 4: one 32-channel group per block, jt = 0).  A row group = two 32-pixel fragments: rows 2 rp + r of a 32-wide tile;
+    // rows 4 rp + r + {0, 2} x 16 pixels of a 16-wide tile (interleaved so that fragment r one row down IS fragment r + 1)
     const int jt = wave >> 2, rp = wave & 3;
     const int li = lane & 31, lk = lane >> 5;
-    int bb[3][2];  // halo fragment (row 2 rp + h, column offset d): byte offset of its row R = (2 rp + h) * HC + li + d
+    const int prow0 = TW == 32 ? 2 * rp : 4 * rp + 2 * (li >> 4), pcol = TW == 32 ? li : (li & 15);
+    int bb[3][2];  // halo fragment (row offset h, column offset d): byte offset of halo pixel (prow0 + h, pcol + d)
 #pragma unroll
     for (int h = 0; h < 3; ++h)
 #pragma unroll
-        for (int d = 0; d < 2; ++d) bb[h][d] = ((2 * rp + h) * HC + li + d) * 64;
+        for (int d = 0; d < 2; ++d) bb[h][d] = ((prow0 + h) * HC + pcol + d) * 64;
     int ab = W_BASE + (jt * 32 + li) * 64;  // weight row jt * 32 + li of a slot; (wr >> 2) & 3 == (li >> 2) & 3
     const int af = (li >> 2) & 3;
 
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
     // q with lane bit 4 (v_permlane16_swap) lets ONE store write the complete 64-byte runs of 16 pixels.
     const unsigned pixb = (unsigned)(4 * C) * 2u;  // bytes per output pixel
     const unsigned lane_off = (unsigned)(lane & 15) * pixb + (unsigned)(2 * ((lane >> 4) & 1) + (lane >> 5)) * 16u;
+    const unsigned kk_off = TW == 32 ? 16u * pixb : 2u * (unsigned)W * pixb;  // second half of a fragment: pixels 16.. / two rows down
     auto pack2 = [](float a, float c) -> unsigned {
         f32x2_t t = {a, c};
         bf16x2_t r = __builtin_convertvector(t, bf16x2_t);
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
                 const unsigned soff = __builtin_amdgcn_readfirstlane(
-                    (unsigned)((((b * H + y0 + 2 * rp + r) * W + x0) * (4 * C)) + sub * C + c0 + jt * 32) * 2u);
+                    (unsigned)((((b * H + y0 + (TW == 32 ? 2 : 4) * rp + r) * W + x0) * (4 * C)) + sub * C + c0 + jt * 32) * 2u);
                 unsigned P[4][2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
                 }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + (unsigned)kk * 16u * pixb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + (unsigned)kk * kk_off, 0);
                     asm volatile("s_nop 1" : "+v"(R[kk]) : : "memory");  // VMEM store data hazard (conv_pipe.hip)
                 }
             }
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
 
     // ---- prologue: stage 0
     SD_ISSUE(0) SD_ISSUE(1) SD_ISSUE(2) SD_ISSUE(3) SD_ISSUE(4) SD_ISSUE(5) SD_ISSUE(6) SD_ISSUE(7)
-    static_assert(NSLOT == 8, "eight DMA instructions per wave and stage");
+    if constexpr (NSLOT > 8) { SD_ISSUE(8 < NSLOT ? 8 : 0) SD_ISSUE(9 < NSLOT ? 9 : 0) }
     SdOps o{};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
         constexpr int S_ = (KC_) * 3 + (G_), GN_ = ((G_) + 1) % 3, KN_ = (G_) == 2 ? 1 : (KC_);          \
         wait_all(o);                                                                                     \
         if constexpr (S_ == 0) read_b<1>(o, bb, lk);                                                     \
-        read_a<GN_, KN_, (S_ + 1) & 1>(o, ab, af, lk);                                                   \
+        read_a<CG, GN_, KN_, (S_ + 1) & 1>(o, ab, af, lk);                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         step_mfma<G_, KC_, S_ & 1>(acc, o);                                                              \
         if constexpr (2 * S_ < NSLOT) { SD_ISSUE(2 * S_ < NSLOT ? 2 * S_ : 0) }                          \
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
             ab += dw_;                                                                                   \
         }                                                                                                \
         read_b<0>(o, bb, lk);                                                                            \
-        read_a<0, 0, 0>(o, ab, af, lk);                                                                  \
+        read_a<CG, 0, 0, 0>(o, ab, af, lk);                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         step_mfma<2, 1, 1>(acc, o);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
 
     // first operands of stage 0
     read_b<0>(o, bb, lk);
-    read_a<0, 0, 0>(o, ab, af, lk);
+    read_a<CG, 0, 0, 0>(o, ab, af, lk);
     for (int g = 0; g < total; ++g) {
         SD_STEP(0, 0) SD_STEP(0, 1) SD_STEP(0, 2) SD_STEP(1, 0) SD_STEP(1, 1)
         SD_LAST()
@@ -346,25 +358,13 @@ __global__ __launch_bounds__(512, 2) void conv_s2d_dgrad_kernel(ConvKParams p, S
 int g_sd_cus = 0;
 unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
-}  // namespace
-
-// data gradient of the space-to-depth stride-2 conv: bf16, no epilogue, whole 8 x 32 tiles, 64-channel groups, 32-channel K stages
-int stylex_launch_s2d_dgrad(const ConvKParams& p, hipStream_t s) {
-    const char* env = getenv("STYLEX_S2D_DGRAD");  // read per launch: A/B tests toggle it in-process
-    if (env && env[0] == '0') return STYLEX_NOT_APPLICABLE;
-    if (!p.act_bf16 || !p.s2d_c || !p.flip_taps || p.flags || p.a_scale || p.x2) return STYLEX_NOT_APPLICABLE;
-    if (p.N != 4 * p.s2d_c || p.s2d_c % 64 != 0 || p.Ck % 32 != 0 || p.Ck < 64) return STYLEX_NOT_APPLICABLE;
-    if (p.Ho % TH != 0 || p.Wo % TW != 0) return STYLEX_NOT_APPLICABLE;
-    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (reinterpret_cast<uintptr_t>(p.y) & 15))
-        return STYLEX_NOT_APPLICABLE;
-    if ((long)p.B * p.Ho * p.Wo * p.Ck * 2 >= (1l << 30) || (long)p.B * p.Ho * p.Wo * p.N * 2 >= (1l << 31) - 16 ||
-        (long)p.N * 9 * p.Ck * 2 >= (1l << 30))
-        return STYLEX_NOT_APPLICABLE;
-    if (p.dry) return 0;
+template <int TW, int NW>
+int launch_sd(const ConvKParams& p, hipStream_t s) {
+    using Cfg = SdCfg<TW, NW>;
     static int attr_state = 0;
     if (attr_state == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_dgrad_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_dgrad_kernel<TW, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
         attr_state = e == hipSuccess ? 1 : -1;
     }
     if (attr_state < 0) return STYLEX_NOT_APPLICABLE;
@@ -375,13 +375,37 @@ int stylex_launch_s2d_dgrad(const ConvKParams& p, hipStream_t s) {
         g_sd_cus = n > 0 ? (n & ~7) : 256;
         if (g_sd_cus < 8) g_sd_cus = 8;
     }
-    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH, cgs = p.s2d_c / 64;
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / Cfg::TH, cgs = p.s2d_c / Cfg::CG;
     SdArgs sa;
     sa.total_tiles = p.B * tiles_x * tiles_y * cgs;
     sa.m_cg = magic_of(cgs);
     sa.m_tpi = magic_of(tiles_x * tiles_y);
     sa.m_tx = magic_of(tiles_x);
-    stylex_note_kernel("conv_s2d_dgrad_kernel");
-    hipLaunchKernelGGL(conv_s2d_dgrad_kernel, dim3((unsigned)g_sd_cus), dim3(512), SMEM, s, p, sa);
+    stylex_note_kernel("conv_s2d_dgrad_kernel<%d, %d>", TW, NW);
+    const int blocks = NW == 4 ? 2 * g_sd_cus : g_sd_cus;  // 4-wave blocks: two per CU
+    hipLaunchKernelGGL((conv_s2d_dgrad_kernel<TW, NW>), dim3((unsigned)blocks), dim3(NW * 64), Cfg::SMEM, s, p, sa);
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// data gradient of the space-to-depth stride-2 conv: bf16, no epilogue, whole 8 x 32 or 16 x 16 tiles, 32- / 64-channel groups,
+// 32-channel K stages
+int stylex_launch_s2d_dgrad(const ConvKParams& p, hipStream_t s) {
+    const char* env = getenv("STYLEX_S2D_DGRAD");  // read per launch: A/B tests toggle it in-process
+    if (env && env[0] == '0') return STYLEX_NOT_APPLICABLE;
+    if (!p.act_bf16 || !p.s2d_c || !p.flip_taps || p.flags || p.a_scale || p.x2 || p.mask || p.gate_mask) return STYLEX_NOT_APPLICABLE;
+    if (p.N != 4 * p.s2d_c || p.s2d_c % 32 != 0 || p.Ck % 32 != 0 || p.Ck < 64) return STYLEX_NOT_APPLICABLE;
+    const bool w32 = p.Wo % 32 == 0 && p.Ho % 8 == 0, w16 = p.Wo % 16 == 0 && p.Ho % 16 == 0;
+    if (!w32 && !w16) return STYLEX_NOT_APPLICABLE;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (reinterpret_cast<uintptr_t>(p.y) & 15))
+        return STYLEX_NOT_APPLICABLE;
+    if ((long)p.B * p.Ho * p.Wo * p.Ck * 2 >= (1l << 30) || (long)p.B * p.Ho * p.Wo * p.N * 2 >= (1l << 31) - 16 ||
+        (long)p.N * 9 * p.Ck * 2 >= (1l << 30))
+        return STYLEX_NOT_APPLICABLE;
+    if (p.dry) return 0;
+    // STYLEX_S2D_DGRAD_TILE=1: 8-wave blocks (64-channel groups, one block per CU) instead of the 4-wave default
+    const char* te = getenv("STYLEX_S2D_DGRAD_TILE");
+    if (te && te[0] == '1' && p.s2d_c % 64 == 0) return w32 ? launch_sd<32, 8>(p, s) : launch_sd<16, 8>(p, s);
+    return w32 ? launch_sd<32, 4>(p, s) : launch_sd<16, 4>(p, s);
 }

@@ -216,14 +216,18 @@ def test_s2d_downsample_path_matches_strided_conv(shape):
             close(a, b_, TOLBF * 2, "grad %s fast=%s" % (nm, fast))
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 64, 24, 64), (1, 128, 128, 32, 32), (2, 64, 256, 8, 96), (5, 192, 64, 16, 32)])
-def test_s2d_data_gradient_all_subpositions_kernel(shape, monkeypatch):
+@pytest.mark.parametrize("tile_mode", ["0", "1"])
+@pytest.mark.parametrize("shape", [(3, 64, 64, 24, 64), (1, 128, 128, 32, 32), (2, 64, 256, 8, 96), (5, 192, 64, 16, 32),
+                                   (3, 128, 128, 16, 16), (1, 64, 64, 32, 48)])
+def test_s2d_data_gradient_all_subpositions_kernel(shape, tile_mode, monkeypatch):
     """conv_s2d_dgrad.hip (round 5: one staged gradient halo for all four sub-positions) against the fp64 definition — the
     gradient of conv2d(x, w, stride 2, pad 1) w.r.t. x, stored space-to-depth — and against the per-sub-position kernel
-    it replaces (STYLEX_S2D_DGRAD=0): same bf16 operands, same K order, so the two must agree to the last bit.  Shapes
-    (B, C, N, half-res H, W): ragged tile lists (3, 5 images over 256 blocks), one / several 64-channel groups, 2-8 K
-    stages, tiles on every image border."""
+    it replaces (STYLEX_S2D_DGRAD=0): same bf16 operands and, where that was the LDS-DMA kernel (>= 16 x 32 images), the same K
+    order, so the two must agree to the last bit there.  Shapes (B, C, N, half-res H, W): ragged tile lists (3, 5 images over 256 blocks), one / several
+    channel groups, 2-8 K stages, tiles on every image border, 16-pixel-wide tiles (the last two); tile_mode 1 = the 8-wave
+    blocks (64-channel groups, one block per CU) instead of the 4-wave default."""
     B, C, N, H, W = shape
+    monkeypatch.setenv("STYLEX_S2D_DGRAD_TILE", tile_mode)
     g = torch.Generator().manual_seed(21)
     w = (torch.randn(N, C, 3, 3, generator=g) / 24).bfloat16().float().to(DEV)
     dy = torch.randn(B, N, H, W, generator=g).bfloat16().to(DEV).contiguous(memory_format=torch.channels_last)
@@ -238,7 +242,52 @@ def test_s2d_data_gradient_all_subpositions_kernel(shape, monkeypatch):
     ref = gx.view(B, C, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 4 * C, H, W)
     scale = float(ref.abs().max())
     assert float((outs["1"].double() - ref).abs().max()) / scale < 6e-3  # bf16 output rounding (2^-8 of the value)
-    assert torch.equal(outs["1"], outs["0"]), float((outs["1"] - outs["0"]).abs().max())
+    if W % 32 == 0 and H >= 16:
+        assert torch.equal(outs["1"], outs["0"]), float((outs["1"] - outs["0"]).abs().max())
+    else:  # the old path of 16-wide / 8-row images is the register-staged kernel: another K order
+        assert float((outs["1"] - outs["0"]).abs().max()) / scale < 6e-3
+
+
+@pytest.mark.parametrize("tile_mode", ["0", "1"])
+@pytest.mark.parametrize("shape", [(3, 64, 128, 24, 64), (1, 128, 256, 32, 32), (5, 32, 256, 16, 16), (2, 256, 512, 16, 48)])
+def test_s2d_forward_pipelined_kernel(shape, tile_mode, monkeypatch):
+    """conv_s2d_fwd.hip (round 5: the stride-2 forward as one pipelined K loop over the sub-position phases) against the
+    fp64 definition conv2d(x, w, stride 2, pad 1) in its three forms — bias only, (conv + bias + residual tensor) * c, and the
+    one-launch block tail (conv + bias + 1x1 conv of the block input) * c — and against the kernels it replaces
+    (STYLEX_S2D_FWD=0).  Shapes (B, C_res, C = N, half-res H, W): 32- and 16-pixel-wide tiles, ragged tile lists, tiles on
+    every image border, 1-4 channel groups; tile_mode 1 = the 8-wave blocks (256 x 256 / 512 x 128 tiles)."""
+    B, CR, C, H, W = shape
+    monkeypatch.setenv("STYLEX_S2D_FWD_TILE", tile_mode)
+    g = torch.Generator().manual_seed(22)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).bfloat16().float().to(DEV)
+    wres = (torch.randn(C, CR, generator=g) / CR ** 0.5).bfloat16().to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    x = torch.randn(B, C, 2 * H, 2 * W, generator=g).bfloat16().float().to(DEV)
+    xs = cl(torch.randn(B, CR, H, W, generator=g).bfloat16().to(DEV))
+    r = cl(torch.randn(B, C, H, W, generator=g).bfloat16().to(DEV))
+    x2 = cl(x.view(B, C, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 4 * C, H, W).bfloat16())
+    wf2, _ = hb.pack_weight_s2d(w)
+    ws = (C, 4 * C, 3, 3)
+    y0 = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1)
+    refs = {"bias": y0, "residual": (y0 + r.double()) * 0.7, "merged": (y0 + F.conv2d(xs.double(), wres.double()[:, :, None, None])) * 0.7}
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("STYLEX_S2D_FWD", mode)
+        hb._S2D_RES_OK.clear()
+        outs[mode, "bias"] = hb.conv2d_fwd(x2, None, 1, 1, hb.BF16_ACT, bias=bias, packed=wf2, w_shape=ws, s2d_c=C)
+        outs[mode, "residual"] = hb.conv2d_fwd(x2, None, 1, 1, hb.BF16_ACT, bias=bias, residual=r, res_scale=0.7, packed=wf2, w_shape=ws,
+                                               s2d_c=C)
+        if hb.s2d_res_supported(tuple(x2.shape), C, C, CR):
+            outs[mode, "merged"] = hb.conv2d_s2d_res_fwd(x2, wf2, xs, wres, bias, C, C, 0.7)
+    hb._S2D_RES_OK.clear()
+    assert ("1", "merged") in outs  # the new kernel takes the block tail at every shape of this test
+    for (mode, form), y in outs.items():
+        ref = refs[form]
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert err < 8e-3, (mode, form, err)  # bf16 output rounding (2^-8 of the value) + fp32 summation order
+    for form in ("bias", "residual"):  # same operands, fp32 accumulation in another order: at most one bf16 ulp apart
+        d = float((outs["1", form].double() - outs["0", form].double()).abs().max() / refs[form].abs().max())
+        assert d < 8e-3, (form, d)
 
 
 def test_conv_bias_lrelu_and_second_order():

@@ -71,9 +71,10 @@ def main():
             d_no = ((outs["1"] - outs["0"]).abs().max() / scale).item()
             print("%-14s B=%d | rel err vs fp64: new %.2e old %.2e | new vs old %.2e" % (name, b, e_new, e_old, d_no))
             assert e_new < 6e-3 and d_no < 6e-3, (e_new, e_old, d_no)  # bf16 output rounding: 2^-8 of the value
+            assert d_no == 0.0 or h % 32 != 0, d_no  # >= 32-wide images: same K order as the old LDS-DMA kernel, bit-identical
         if a.check_only:
             continue
-        for b in (a.batch, 2 * a.batch):
+        for b in (a.batch // 2, a.batch, 2 * a.batch):
             dy = torch.randn(b, c, h, h, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
             fn = lambda: hb.conv2d_bwd_data(dy, None, xs(b), 1, 1, prec, packed=wb2, w_shape=ws, s2d_c=c)
             t = {}
