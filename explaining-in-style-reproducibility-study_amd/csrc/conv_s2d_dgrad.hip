@@ -56,6 +56,15 @@ struct SdCfg {
     static_assert(NSLOT == 8 || NSLOT == 10, "3 + 5 or 5 + 5 DMA instructions per wave and stage");
 };
 constexpr unsigned OOB = 0x80000000u;
+#ifndef SD_EARLY_ISSUE
+#define SD_EARLY_ISSUE 1
+#endif
+#ifdef SD_PROBE_NO_HALO
+constexpr bool SD_NO_HALO = true;  // ablation build: the gradient halo is never fetched (zeros)
+#else
+constexpr bool SD_NO_HALO = false;
+#endif
+constexpr bool SD_EARLY = SD_EARLY_ISSUE != 0;  // 1: the whole DMA of the next stage goes out behind the first MFMAs of a stage
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* smem, int lds_off, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_ptr)(smem + lds_off), 16, voff, soff, 0, 0);
@@ -139,6 +148,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams 
     const int tq = sa.total_tiles >> 3, tr = sa.total_tiles & 7;
     const int xs = xcd * tq + (xcd < tr ? xcd : tr), xn = tq + (xcd < tr ? 1 : 0);
     if (bslot >= xn) return;
+#ifdef SD_STAGGER
+    // second residents of a CU (the upper half of the grid) start about half a tile late, so that the two blocks of a CU are
+    // not in their store bursts at the same time
+    if (NW == 4 && bslot >= (nslots >> 1))
+        for (int i = 0; i < SD_STAGGER * (nch + 2); ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
+#endif
     const int my_tiles = (xn - bslot + nslots - 1) / nslots;
     const int total = my_tiles * nch;
     auto decode = [&](int k, int& b, int& y0, int& x0, int& c0) {
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams 
         if constexpr ((K) < HS) {                                                                                         \
             const unsigned soff_ = (unsigned)((((db * H + dy0) * W + dx0) * NI) + dch * 32) * 2u;                          \
             const unsigned edge_ = (dy0 + TH == H ? 1u : 0u) | (dx0 + TW == W ? 2u : 0u);                                 \
-            const unsigned v_ = ((vh[(K) < HS ? (K) : 0] & edge_) || !more_) ? OOB : (vh[(K) < HS ? (K) : 0] & ~15u);     \
+            const unsigned v_ = ((vh[(K) < HS ? (K) : 0] & edge_) || !more_ || SD_NO_HALO) ? OOB : (vh[(K) < HS ? (K) : 0] & ~15u); \
             dma16(rg, smem, hdst[(K) < HS ? (K) : 0] >= 0 ? dslot * H_STAGE + hdst[(K) < HS ? (K) : 0] : DUMP_BASE, v_,   \
                   more_ ? soff_ : 0u);                                                                                    \
         } else {                                                                                                          \
@@ -280,7 +295,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams 
                 }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+#ifndef SD_PROBE_NO_STORE  // (ablation builds: tools/bench_s2d_dgrad.py with STYLEX_HIP_LIB)
                     __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + (unsigned)kk * kk_off, 0);
+#endif
                     asm volatile("s_nop 1" : "+v"(R[kk]) : : "memory");  // VMEM store data hazard (conv_pipe.hip)
                 }
             }
@@ -306,15 +323,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams 
         read_a<CG, GN_, KN_, (S_ + 1) & 1>(o, ab, af, lk);                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         step_mfma<G_, KC_, S_ & 1>(acc, o);                                                              \
-        if constexpr (2 * S_ < NSLOT) { SD_ISSUE(2 * S_ < NSLOT ? 2 * S_ : 0) }                          \
-        if constexpr (2 * S_ + 1 < NSLOT) { SD_ISSUE(2 * S_ + 1 < NSLOT ? 2 * S_ + 1 : 0) }              \
+        if constexpr (SD_EARLY) {                                                                        \
+            if constexpr (S_ == 0) if (!pre_issued) {                                                    \
+                SD_ISSUE(0) SD_ISSUE(1) SD_ISSUE(2) SD_ISSUE(3) SD_ISSUE(4) SD_ISSUE(5) SD_ISSUE(6) SD_ISSUE(7) \
+                if constexpr (NSLOT > 8) { SD_ISSUE(8 < NSLOT ? 8 : 0) SD_ISSUE(9 < NSLOT ? 9 : 0) }     \
+            }                                                                                            \
+        } else {                                                                                         \
+            if constexpr (2 * S_ < NSLOT) { SD_ISSUE(2 * S_ < NSLOT ? 2 * S_ : 0) }                      \
+            if constexpr (2 * S_ + 1 < NSLOT) { SD_ISSUE(2 * S_ + 1 < NSLOT ? 2 * S_ + 1 : 0) }          \
+        }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
     }
     // the last step of a stage (k-step 1, slots 6..8): the barrier that publishes the next stage sits in front of its MFMAs
 #define SD_LAST()                                                                                        \
     {                                                                                                    \
         wait_all(o);                                                                                     \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        if (pre_issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); /* the 16 stores of the last tile stay in flight */ \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        pre_issued = false;                                                                              \
         __builtin_amdgcn_s_barrier();                                                                    \
         asm volatile("" ::: "memory");                                                                   \
         {                                                                                                \
@@ -330,6 +356,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams 
         __builtin_amdgcn_sched_barrier(0);                                                               \
     }
 
+    // Stores and the stage barrier.  Vector-memory operations complete in issue order (vmcnt), so a stage barrier that waits
+    // for its DMA also waits for every store issued before it: with the stores of a tile issued between two stages' DMA, the
+    // first barrier of the next tile waited for the write path (ablation without the stores: 64 -> 64 @256^2 0.21 -> 0.09 ms,
+    // more than the 0.08 ms the bytes take at the fill rate).  So the DMA of the stage AFTER the next goes out at the end of
+    // a tile, ahead of the 16 stores (its ring slot is free once the tile's last barrier has passed), the next stage issues
+    // nothing and its barrier waits with vmcnt(16): everything but the stores.
+    static_assert(SD_EARLY, "the tile-end pre-issue replaces the step-0 issue of the early-issue schedule");
+    bool pre_issued = false;
     // first operands of stage 0
     read_b<0>(o, bb, lk);
     read_a<CG, 0, 0, 0>(o, ab, af, lk);
@@ -338,6 +372,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_dgrad_kernel(ConvKParams 
         SD_LAST()
         if (++c_ch == nch) {  // tile complete
             c_ch = 0;
+            {  // the DMA of the stage after the next one, ahead of this tile's stores
+                SD_ISSUE(0) SD_ISSUE(1) SD_ISSUE(2) SD_ISSUE(3) SD_ISSUE(4) SD_ISSUE(5) SD_ISSUE(6) SD_ISSUE(7)
+                if constexpr (NSLOT > 8) { SD_ISSUE(8 < NSLOT ? 8 : 0) SD_ISSUE(9 < NSLOT ? 9 : 0) }
+                pre_issued = true;
+            }
             asm volatile("s_nop 15\n\ts_nop 15"
                          : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
                            "+v"(acc[1][2]), "+v"(acc[1][3]));

@@ -255,8 +255,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
         if constexpr (K0 + 8 < K1) issue(std::integral_constant<int, K0 + 8>{});
     };
     using D0 = std::integral_constant<int, 0>;
-    using D1 = std::integral_constant<int, 3>;               // a two-slot stage issues [0, 3), [3, D2), [D2, NDMA) behind its
-    using D2 = std::integral_constant<int, NDMA == 7 ? 5 : 6>;  // first three steps
+#ifndef SF_EARLY_ISSUE
+#define SF_EARLY_ISSUE 1
+#endif
+    // a two-slot stage issues [0, D1), [D1, D2), [D2, NDMA) behind its first three steps (SF_EARLY_ISSUE: all behind the first)
+    using D1 = std::integral_constant<int, SF_EARLY_ISSUE ? NDMA : 3>;
+    using D2 = std::integral_constant<int, SF_EARLY_ISSUE ? NDMA : (NDMA == 7 ? 5 : 6)>;
     using DN = std::integral_constant<int, NDMA>;
 
     // ---- wave roles and operand addressing: every wave runs the same instruction stream.  NT = 256: row group rp = wave & 3,
