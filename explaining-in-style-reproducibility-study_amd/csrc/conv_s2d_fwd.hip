@@ -46,19 +46,25 @@ typedef StylexS2dFwdArgs SfArgs;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr unsigned OOB = 0x80000000u;
 
-// block tile: NW waves x 8 accumulator tiles = PXF 32-pixel fragments x NT output channels; TW = tile width in pixels.
-// <*, 256, 8>: 256 px x 256 n; <32, 128, 8>: 512 px x 128 n; <*, 128, 4>: 256 px x 128 n in a 4-wave block, two blocks per CU
-template <int TW_, int NT_, int NW_>
+// block tile: NW waves x 2 NF accumulator tiles = PXF 32-pixel fragments x NT output channels; TW = tile width in pixels.
+// <*, 128, 4, 4>: 256 px x 128 n in a 4-wave block, two blocks per CU (default); <*, 64, 4, 2>: 256 px x 64 n likewise (N = 64);
+// <*, 128, 8, 2>: the 256 x 128 tile on 8 waves
+// (launches of at most one tile per CU); <*, 256, 8, 4>: 256 px x 256 n; <32, 128, 8, 4>: 512 px x 128 n
+template <int TW_, int NT_, int NW_, int NF_>
 struct FwCfg {
-    static constexpr int TW = TW_, NT = NT_, NW = NW_;
-    static constexpr int PXF = NW * 8 / (NT / 32);
+    static constexpr int TW = TW_, NT = NT_, NW = NW_, NF = NF_;
+    // ring depth: the 8-wave / 2-fragment variant runs alone on its CU (launches of at most one tile per CU), where a stage is
+    // as long as a DMA round trip: its ring is three deep (the DMA of stage g + 2 is issued in stage g, counted vmcnt)
+    static constexpr int RD = (NW_ == 8 && NF_ == 2) ? 3 : 2;
+    static constexpr int NG = NT / (32 * NF), RPN = NW / NG;  // channel groups of a block, row groups (waves per channel group)
+    static constexpr int PXF = RPN * 2;
     static constexpr int TH = PXF * 32 / TW;
     static constexpr int HR = TH + 1, HC = TW + 1, NPX = HR * HC;  // halo: one row above, one column to the left
     static constexpr int H_PIECES = (NPX + 15) / 16, H_STAGE = H_PIECES * 1024;  // DMA pieces of 16 pixel rows x 64 B
     static constexpr int W_PIECES = 2 * NT / 16, W_STAGE = W_PIECES * 1024;     // two tap slots x NT rows
-    static constexpr int W_BASE = 2 * H_STAGE, DUMP_BASE = W_BASE + 2 * W_STAGE, SMEM = DUMP_BASE + 1024;
+    static constexpr int W_BASE = RD * H_STAGE, DUMP_BASE = W_BASE + RD * W_STAGE, SMEM = DUMP_BASE + 1024;
     static constexpr int HS = (H_PIECES + NW - 1) / NW, WS = W_PIECES / NW, NDMA = HS + WS;  // DMA instructions per wave and stage
-    static_assert(NDMA == 7 || NDMA == 9, "3 + 4, 5 + 2 or 5 + 4 DMA instructions per wave and stage");
+    static_assert(NDMA == 5 || NDMA == 7 || NDMA == 9, "3 + 2, 3 + 4, 5 + 2 or 5 + 4 DMA instructions per wave and stage");
     static_assert(W_PIECES % (2 * NW) == 0, "a DMA instruction stays inside one tap slot");
     static_assert(SMEM <= 160 * 1024, "LDS");
 };
@@ -112,13 +118,15 @@ __device__ __forceinline__ void read_b(SfOps& o, const int (&bb)[3][2], int lk) 
         lds_read16<0>(o.b[KC][i], bb[h][d] + (((KC * 2 + lk) ^ ((bb[h][d] >> 8) & 3)) << 4));
     }
 }
-template <int NT, int J, int KC, int PAR>
+template <int NT, int NF, int J, int KC, int PAR>
 __device__ __forceinline__ void read_a(SfOps& o, int ab, int af, int lk) {
     const int addr = ab + (((KC * 2 + lk) ^ af) << 4);
     lds_read16<(J * NT + 0) * 64>(o.a[PAR][0], addr);
     lds_read16<(J * NT + 32) * 64>(o.a[PAR][1], addr);
-    lds_read16<(J * NT + 64) * 64>(o.a[PAR][2], addr);
-    lds_read16<(J * NT + 96) * 64>(o.a[PAR][3], addr);
+    if constexpr (NF == 4) {
+        lds_read16<(J * NT + 64) * 64>(o.a[PAR][2], addr);
+        lds_read16<(J * NT + 96) * 64>(o.a[PAR][3], addr);
+    }
 }
 __device__ __forceinline__ void wait_all(SfOps& o) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -126,20 +134,20 @@ __device__ __forceinline__ void wait_all(SfOps& o) {
                    "+v"(o.b[1][2]), "+v"(o.b[1][3]), "+v"(o.a[0][0]), "+v"(o.a[0][1]), "+v"(o.a[0][2]), "+v"(o.a[0][3]),
                    "+v"(o.a[1][0]), "+v"(o.a[1][1]), "+v"(o.a[1][2]), "+v"(o.a[1][3]));
 }
-// the eight MFMAs of tap slot J at k-step KC: two pixel fragments x four 32-channel groups
-template <class P, int J, int KC, int PAR>
-__device__ __forceinline__ void step_mfma(f32x16 (&acc)[2][4], const SfOps& o) {
+// the 2 NF MFMAs of tap slot J at k-step KC: two pixel fragments x NF 32-channel groups
+template <class P, int NF, int J, int KC, int PAR>
+__device__ __forceinline__ void step_mfma(f32x16 (&acc)[2][NF], const SfOps& o) {
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int r = 0; r < 2; ++r) mfma1(acc[r][nf], o.a[PAR][nf], o.b[KC][P::frag(r + P::dy(J) + 1, P::dx(J) + 1)]);  // D^T = W x X^T
 }
 
-template <int TW, int NT, int NW>
+template <int TW, int NT, int NW, int NF>
 __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p, SfArgs sa) {
-    using Cfg = FwCfg<TW, NT, NW>;
+    using Cfg = FwCfg<TW, NT, NW, NF>;
     constexpr int HC = Cfg::HC, H_STAGE = Cfg::H_STAGE, W_STAGE = Cfg::W_STAGE, W_BASE = Cfg::W_BASE, DUMP_BASE = Cfg::DUMP_BASE;
-    constexpr int HS = Cfg::HS, WS = Cfg::WS, NDMA = Cfg::NDMA, TH = Cfg::TH;
+    constexpr int HS = Cfg::HS, WS = Cfg::WS, NDMA = Cfg::NDMA, TH = Cfg::TH, RD = Cfg::RD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
     const int c2 = p.x2 ? __builtin_amdgcn_readfirstlane(p.c2) : 0;
     const int CK = 4 * C;
     const int ngs = N / NT, tiles_x = W / TW, tiles_y = H / TH, tpi = tiles_x * tiles_y;
-    const int nchC = C >> 5, nch2 = c2 >> 5;  // 32-channel stages per main phase / of the residual phase
+    const int nchC = C >> 5, nch2 = (c2 + 31) >> 5;  // 32-channel stages per main phase / of the residual phase (last one ragged)
     const int first_ph = nch2 ? 0 : 1;
     const int stages_per_tile = nch2 + 5 * nchC;
 
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
     // tile is a non-negative offset; out-of-image halo pixels are never fetched (OOB voffset -> zeros)
     const char* xa = reinterpret_cast<const char*>(p.a) - (long)(W + 1) * CK * 2;
     const char* xr = p.x2 ? reinterpret_cast<const char*>(p.x2) - (long)(W + 1) * c2 * 2 : xa;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xa), 0, 0x40000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xa), 0, 0x7ffffff0, 0x00020000);  // < 2 GiB: OOB stays out of range
     const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xr), 0, 0x40000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, 0x40000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw2 =
@@ -211,7 +219,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
             const unsigned soff = (unsigned)(((db * H + dy0) * W + dx0) * ps + (dph == 0 ? 0 : sub * C * 2) + dch * 64);
             const int edge = (dy0 == 0 ? (1 << 30) : 0) | (dx0 == 0 ? (1 << 29) : 0);
             const int hp = hpix[K];
-            const unsigned v = (hp < 0 || (hp & edge) || !more) ? OOB : (unsigned)((hp & 0x1fffffff) * ps) + lslot * 16u;
+            // (residual segment: channels past c2 in its last 32-channel stage are not fetched)
+            const bool cok = dph != 0 || (int)(lslot * 8u) + dch * 32 < c2;
+            const unsigned v = (hp < 0 || (hp & edge) || !more || !cok) ? OOB : (unsigned)((hp & 0x1fffffff) * ps) + lslot * 16u;
             const int dst = hdst[K] >= 0 ? dslot * H_STAGE + hdst[K] : DUMP_BASE;
             if (dph == 0) dma16(rxr, smem, dst, v, more ? soff : 0u);
             else dma16(rx, smem, dst, v, more ? soff : 0u);
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
             const bool live = more && (slot == 0 || dph >= 2);
             const int dst = W_BASE + dslot * W_STAGE + (wave + NW * kw) * 1024;
             if (dph == 0) {
-                const unsigned v = live ? (unsigned)(wrow[kw] * c2 * 2) + lslot * 16u : OOB;
+                const unsigned v = (live && (int)(lslot * 8u) + dch * 32 < c2) ? (unsigned)(wrow[kw] * c2 * 2) + lslot * 16u : OOB;
                 dma16(rw2, smem, dst, v, live ? (unsigned)(dn0 * c2 * 2 + dch * 64) : 0u);
             } else {
                 const unsigned v = live ? (unsigned)(wrow[kw] * 9 * CK * 2) + lslot * 16u : OOB;
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
             }
         }
         if constexpr (K == NDMA - 1) {
-            dslot ^= 1;
+            dslot = dslot + 1 == RD ? 0 : dslot + 1;
             if (++dch == (dph == 0 ? nch2 : nchC)) {
                 dch = 0;
                 if (++dph == 6) {
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
     // 128-channel half jt = wave >> 2; NT = 128: row group rp = wave, all 128 channels.  A row group = two 32-pixel
     // fragments (NW = 4: rp = wave, all 128 channels): rows 2 rp + r of a 32-wide tile; rows 4 rp + r + {0, 2} x 16 pixels of a 16-wide tile (interleaved so that
     // fragment r shifted down by one row IS fragment r + 1: three halo rows serve both fragments at offsets -1 / 0).
-    const int jt = NT == 256 ? wave >> 2 : 0, rp = NT == 256 ? (wave & 3) : wave;  // NT = 128: NW row groups
+    const int jt = wave / Cfg::RPN, rp = wave % Cfg::RPN;  // channel group (32 NF channels) and row group of this wave
     const int li = lane & 31, lk = lane >> 5;
     const int prow0 = TW == 32 ? 2 * rp : 4 * rp + 2 * (li >> 4), pcol = TW == 32 ? li : (li & 15);
     int bb[3][2];  // halo fragment (row offset h, column offset d): byte offset of halo pixel (prow0 + h, pcol + d)
@@ -275,15 +285,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
     for (int h = 0; h < 3; ++h)
 #pragma unroll
         for (int d = 0; d < 2; ++d) bb[h][d] = ((prow0 + h) * HC + pcol + d) * 64;
-    int ab = W_BASE + (jt * 128 + li) * 64;  // weight row jt * 128 + li of slot 0; ((row >> 2) & 3) == (li >> 2) & 3
+    int ab = W_BASE + (jt * 32 * NF + li) * 64;  // weight row jt * 32 NF + li of slot 0; ((row >> 2) & 3) == (li >> 2) & 3
     const int af = (li >> 2) & 3;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NF];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[r][nf][e] = 0.f;
     };
@@ -305,8 +315,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
     };
     auto epilogue = [&](int b, int y0, int x0, int n0) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int nb = n0 + jt * 128 + nf * 32;  // uniform
+        for (int nf = 0; nf < NF; ++nf) {
+            const int nb = n0 + jt * 32 * NF + nf * 32;  // uniform
             float4 b4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -359,19 +369,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
 
     // ---- prologue: stage 0
     issue_range(D0{}, DN{});
+    if constexpr (RD == 3) issue_range(D0{}, DN{});  // stage 1
     SfOps o{};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 2) * NDMA) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     int cslot = 0;
     // the barrier that publishes the next stage (in front of a stage's last MFMAs), and the ring step of the consumer
     auto publish = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // everything but the newest stage of a three-deep ring (vector-memory operations complete in issue order)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RD - 2) * NDMA) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int dh = cslot ? -H_STAGE : H_STAGE, dw = cslot ? -W_STAGE : W_STAGE;
-        cslot ^= 1;
+        const bool wrap = cslot == RD - 1;
+        const int dh = wrap ? -(RD - 1) * H_STAGE : H_STAGE, dw = wrap ? -(RD - 1) * W_STAGE : W_STAGE;
+        cslot = wrap ? 0 : cslot + 1;
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
             bb[h][0] += dh;
@@ -385,53 +398,53 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
     auto run = [&](auto ph, int n) {
         using P = decltype(ph);
         read_b<P, 0>(o, bb, lk);
-        read_a<NT, 0, 0, 0>(o, ab, af, lk);
+        read_a<NT, NF, 0, 0, 0>(o, ab, af, lk);
         for (int g = 0; g < n; ++g) {
             if constexpr (P::NS == 2) {
                 wait_all(o);
                 read_b<P, 1>(o, bb, lk);
-                read_a<NT, 1, 0, 1>(o, ab, af, lk);
+                read_a<NT, NF, 1, 0, 1>(o, ab, af, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                step_mfma<P, 0, 0, 0>(acc, o);
+                step_mfma<P, NF, 0, 0, 0>(acc, o);
                 issue_range(D0{}, D1{});
                 __builtin_amdgcn_sched_barrier(0);
                 wait_all(o);
-                read_a<NT, 0, 1, 0>(o, ab, af, lk);
+                read_a<NT, NF, 0, 1, 0>(o, ab, af, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                step_mfma<P, 1, 0, 1>(acc, o);
+                step_mfma<P, NF, 1, 0, 1>(acc, o);
                 issue_range(D1{}, D2{});
                 __builtin_amdgcn_sched_barrier(0);
                 wait_all(o);
-                read_a<NT, 1, 1, 1>(o, ab, af, lk);
+                read_a<NT, NF, 1, 1, 1>(o, ab, af, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                step_mfma<P, 0, 1, 0>(acc, o);
+                step_mfma<P, NF, 0, 1, 0>(acc, o);
                 issue_range(D2{}, DN{});
                 __builtin_amdgcn_sched_barrier(0);
                 wait_all(o);
                 publish();
                 if (g + 1 < n) {
                     read_b<P, 0>(o, bb, lk);
-                    read_a<NT, 0, 0, 0>(o, ab, af, lk);
+                    read_a<NT, NF, 0, 0, 0>(o, ab, af, lk);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                step_mfma<P, 1, 1, 1>(acc, o);
+                step_mfma<P, NF, 1, 1, 1>(acc, o);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 wait_all(o);
                 read_b<P, 1>(o, bb, lk);
-                read_a<NT, 0, 1, 1>(o, ab, af, lk);
+                read_a<NT, NF, 0, 1, 1>(o, ab, af, lk);
                 __builtin_amdgcn_sched_barrier(0);
-                step_mfma<P, 0, 0, 0>(acc, o);
+                step_mfma<P, NF, 0, 0, 0>(acc, o);
                 issue_range(D0{}, DN{});
                 __builtin_amdgcn_sched_barrier(0);
                 wait_all(o);
                 publish();
                 if (g + 1 < n) {
                     read_b<P, 0>(o, bb, lk);
-                    read_a<NT, 0, 0, 0>(o, ab, af, lk);
+                    read_a<NT, NF, 0, 0, 0>(o, ab, af, lk);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                step_mfma<P, 0, 1, 1>(acc, o);
+                step_mfma<P, NF, 0, 1, 1>(acc, o);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -446,9 +459,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
         run(PhUp{}, nchC);                // sub-position 2: taps (-1, 0), (0, 0)
         run(PhUpLeft{}, nchC);            // sub-position 3: taps (-1, -1), (-1, 0)
         run(PhLeft{}, nchC);              //                 taps (0, -1), (0, 0)
-        asm volatile("s_nop 15\n\ts_nop 15"
-                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
-                       "+v"(acc[1][2]), "+v"(acc[1][3]));
+        if constexpr (NF == 4)
+            asm volatile("s_nop 15\n\ts_nop 15"
+                         : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                           "+v"(acc[1][2]), "+v"(acc[1][3]));
+        else
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
         epilogue(cb, cy0, cx0, cn0);
         zero_acc();
     }
@@ -460,12 +476,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
 int g_sf_cus = 0;
 unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
-template <int TW, int NT, int NW>
+template <int TW, int NT, int NW, int NF>
 int launch_sf(const ConvKParams& p, hipStream_t s) {
-    using Cfg = FwCfg<TW, NT, NW>;
+    using Cfg = FwCfg<TW, NT, NW, NF>;
     static int attr_state = 0;
     if (attr_state == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_fwd_kernel<TW, NT, NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_fwd_kernel<TW, NT, NW, NF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
         attr_state = e == hipSuccess ? 1 : -1;
     }
@@ -483,9 +499,9 @@ int launch_sf(const ConvKParams& p, hipStream_t s) {
     sa.m_ng = magic_of(ngs);
     sa.m_tpi = magic_of(tiles_x * tiles_y);
     sa.m_tx = magic_of(tiles_x);
-    stylex_note_kernel("conv_s2d_fwd_kernel<%d, %d, %d>", TW, NT, NW);
+    stylex_note_kernel("conv_s2d_fwd_kernel<%d, %d, %d, %d>", TW, NT, NW, NF);
     const int blocks = NW == 4 ? 2 * g_sf_cus : g_sf_cus;  // 4-wave blocks: two per CU
-    hipLaunchKernelGGL((conv_s2d_fwd_kernel<TW, NT, NW>), dim3((unsigned)blocks), dim3(NW * 64), Cfg::SMEM, s, p, sa);
+    hipLaunchKernelGGL((conv_s2d_fwd_kernel<TW, NT, NW, NF>), dim3((unsigned)blocks), dim3(NW * 64), Cfg::SMEM, s, p, sa);
     return (int)hipGetLastError();
 }
 
@@ -498,31 +514,38 @@ int stylex_launch_s2d_fwd(const ConvKParams& p, hipStream_t s) {
     if (env && env[0] == '0') return STYLEX_NOT_APPLICABLE;
     if (!p.act_bf16 || !p.s2d_c || p.flip_taps || p.a_scale || p.mask || p.gate_mask) return STYLEX_NOT_APPLICABLE;
     if (p.flags & ~(STYLEX_EPI_BIAS | STYLEX_EPI_RESIDUAL)) return STYLEX_NOT_APPLICABLE;
-    if (p.Ck != 4 * p.s2d_c || p.s2d_c % 32 != 0 || p.N % 128 != 0) return STYLEX_NOT_APPLICABLE;
+    if (p.Ck != 4 * p.s2d_c || p.s2d_c % 32 != 0 || p.N % 64 != 0) return STYLEX_NOT_APPLICABLE;
     if ((p.flags & STYLEX_EPI_BIAS) && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15))) return STYLEX_NOT_APPLICABLE;
     if ((p.flags & STYLEX_EPI_RESIDUAL) && (!p.residual || p.x2 || (reinterpret_cast<uintptr_t>(p.residual) & 7))) return STYLEX_NOT_APPLICABLE;
     if (p.x2) {
-        if (!p.w2 || p.c2 < 32 || p.c2 % 32 != 0) return STYLEX_NOT_APPLICABLE;
+        if (!p.w2 || p.c2 < 8 || p.c2 % 8 != 0) return STYLEX_NOT_APPLICABLE;
         if ((reinterpret_cast<uintptr_t>(p.x2) & 15) || (reinterpret_cast<uintptr_t>(p.w2) & 15)) return STYLEX_NOT_APPLICABLE;
         if ((long)p.B * p.Ho * p.Wo * p.c2 * 2 >= (1l << 30)) return STYLEX_NOT_APPLICABLE;
     }
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (reinterpret_cast<uintptr_t>(p.y) & 15))
         return STYLEX_NOT_APPLICABLE;
-    if ((long)p.B * p.Ho * p.Wo * p.Ck * 2 >= (1l << 30) || (long)p.B * p.Ho * p.Wo * p.N * 2 >= (1l << 31) - 16 ||
+    if ((long)(p.B * p.Ho + 2) * p.Wo * p.Ck * 2 >= (1l << 31) - 16 || (long)p.B * p.Ho * p.Wo * p.N * 2 >= (1l << 31) - 16 ||
         (long)p.N * 9 * p.Ck * 2 >= (1l << 30))
         return STYLEX_NOT_APPLICABLE;
     const bool n256 = p.N % 256 == 0;
     const bool w32 = p.Wo % 32 == 0 && p.Ho % 8 == 0, w16 = p.Wo % 16 == 0 && p.Ho % 16 == 0;
     if (!w32 && !w16) return STYLEX_NOT_APPLICABLE;
     if (p.dry) return 0;
+    if (p.N % 128 != 0)  // 64-channel layers: 256 px x 64 n tiles in 4-wave blocks (HBM-side work: 0.67 GB per 77 GFLOP at B = 64)
+        return w32 ? launch_sf<32, 64, 4, 2>(p, s) : launch_sf<16, 64, 4, 2>(p, s);
     // Default: 256 px x 128 n tiles in 4-wave blocks, two blocks per CU — measured equal to or faster than the 8-wave blocks
     // with 256 x 256 / 512 x 128 tiles on every layer and batch but one (256 -> 256 @64^2, B = 128: 0.176 vs 0.170 ms): the
     // second resident block covers the other's barriers, phase starts and epilogue, and small launches spread over twice
-    // the tiles (profiles/r05_s_s2d_fwd_tiles.txt).  STYLEX_S2D_FWD_TILE=1 selects the 8-wave blocks.
+    // the tiles (profiles/r05_s_s2d_fwd_tiles.txt).  STYLEX_S2D_FWD_TILE=1 selects the 8-wave blocks with
+    // the wide tiles, =2 the 4-wave blocks whatever the tile count.
     const char* te = getenv("STYLEX_S2D_FWD_TILE");
     if (te && te[0] == '1' && (n256 || (w32 && p.Ho % 16 == 0))) {
-        if (n256) return w32 ? launch_sf<32, 256, 8>(p, s) : launch_sf<16, 256, 8>(p, s);
-        return launch_sf<32, 128, 8>(p, s);
+        if (n256) return w32 ? launch_sf<32, 256, 8, 4>(p, s) : launch_sf<16, 256, 8, 4>(p, s);
+        return launch_sf<32, 128, 8, 4>(p, s);
     }
-    return w32 ? launch_sf<32, 128, 4>(p, s) : launch_sf<16, 128, 4>(p, s);
+    // at most one tile per CU: the same tile on 8 waves (two per SIMD cover each other's waits; a lone 4-wave block is
+    // latency-bound at 1.3 us per stage)
+    const long tiles = (long)p.B * p.Ho * p.Wo / 256 * (p.N / 128);
+    if (!(te && te[0] == '2') && tiles <= 256) return w32 ? launch_sf<32, 128, 8, 2>(p, s) : launch_sf<16, 128, 8, 2>(p, s);
+    return w32 ? launch_sf<32, 128, 4, 4>(p, s) : launch_sf<16, 128, 4, 4>(p, s);
 }

@@ -248,14 +248,17 @@ def test_s2d_data_gradient_all_subpositions_kernel(shape, tile_mode, monkeypatch
         assert float((outs["1"] - outs["0"]).abs().max()) / scale < 6e-3
 
 
-@pytest.mark.parametrize("tile_mode", ["0", "1"])
-@pytest.mark.parametrize("shape", [(3, 64, 128, 24, 64), (1, 128, 256, 32, 32), (5, 32, 256, 16, 16), (2, 256, 512, 16, 48)])
+@pytest.mark.parametrize("tile_mode", ["0", "1", "2"])
+@pytest.mark.parametrize("shape", [(3, 64, 128, 24, 64), (1, 128, 256, 32, 32), (5, 32, 256, 16, 16), (2, 256, 512, 16, 48),
+                                   (3, 8, 64, 16, 64), (2, 40, 64, 16, 16)])
 def test_s2d_forward_pipelined_kernel(shape, tile_mode, monkeypatch):
     """conv_s2d_fwd.hip (round 5: the stride-2 forward as one pipelined K loop over the sub-position phases) against the
     fp64 definition conv2d(x, w, stride 2, pad 1) in its three forms — bias only, (conv + bias + residual tensor) * c, and the
     one-launch block tail (conv + bias + 1x1 conv of the block input) * c — and against the kernels it replaces
     (STYLEX_S2D_FWD=0).  Shapes (B, C_res, C = N, half-res H, W): 32- and 16-pixel-wide tiles, ragged tile lists, tiles on
-    every image border, 1-4 channel groups; tile_mode 1 = the 8-wave blocks (256 x 256 / 512 x 128 tiles)."""
+    every image border, 1-4 channel groups, the 64-channel tile with a ragged residual segment (8 / 40 channels: the padded RGB
+    input of the first block); tile_mode 0 = by tile count (here: 256 x 128 tiles on 8 waves), 1 = the 8-wave blocks
+    with 256 x 256 / 512 x 128 tiles, 2 = 256 x 128 tiles in 4-wave blocks (the default of launches with more than 256 tiles)."""
     B, CR, C, H, W = shape
     monkeypatch.setenv("STYLEX_S2D_FWD_TILE", tile_mode)
     g = torch.Generator().manual_seed(22)

@@ -23,9 +23,12 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     ("conv_wgrad_pipe.hip", ["conv3x3_wgrad_pipe_kernelILi2ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi32ELb0",
                              "conv3x3_wgrad_pipe_kernelILi1ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi16ELb1",
                              "conv3x3_wgrad_pipe_kernelILi1ELi16ELb0"]),
-    ("conv_s2d_dgrad.hip", ["conv_s2d_dgrad_kernel"]),
-    ("conv_s2d_fwd.hip", ["conv_s2d_fwd_kernelILi32ELi128ELi4", "conv_s2d_fwd_kernelILi16ELi128ELi4", "conv_s2d_fwd_kernelILi32ELi256ELi8",
-                          "conv_s2d_fwd_kernelILi16ELi256ELi8", "conv_s2d_fwd_kernelILi32ELi128ELi8"]),
+    ("conv_s2d_dgrad.hip", ["conv_s2d_dgrad_kernelILi32ELi4", "conv_s2d_dgrad_kernelILi16ELi4", "conv_s2d_dgrad_kernelILi32ELi8",
+                            "conv_s2d_dgrad_kernelILi16ELi8"]),
+    ("conv_s2d_fwd.hip", ["conv_s2d_fwd_kernelILi32ELi128ELi4ELi4", "conv_s2d_fwd_kernelILi16ELi128ELi4ELi4",
+                          "conv_s2d_fwd_kernelILi32ELi128ELi8ELi2", "conv_s2d_fwd_kernelILi16ELi128ELi8ELi2",
+                          "conv_s2d_fwd_kernelILi32ELi256ELi8ELi4", "conv_s2d_fwd_kernelILi16ELi256ELi8ELi4",
+                          "conv_s2d_fwd_kernelILi32ELi128ELi8ELi4", "conv_s2d_fwd_kernelILi32ELi64ELi4ELi2", "conv_s2d_fwd_kernelILi16ELi64ELi4ELi2"]),
 ])
 def test_hot_kernels_use_no_scratch(tmp_path, source, kernels):
     out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
