@@ -688,8 +688,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvKParams p) {
 // 27 times per step): the blocks behind the `main_blocks` reduce blocks sum the per-split pixel sums of dy the
 // weight-gradient kernel left in bias_part[split][n].  One wave per channel, lane l takes splits l, l + 64, ..., then a
 // fixed shuffle tree: deterministic.
+// dw = (acc ? dw : 0) + scale * sum, as two rounded fp32 operations: bit-identical to the sum stored, multiplied in place
+// and added by the autograd engine (the launches this replaces)
+__device__ __forceinline__ float wg_out(float sum, float old, float scale, int acc) {
+#pragma clang fp contract(off)  // (hipcc contracts a * b + c into one fma by default — one rounding instead of two)
+    float v = scale * sum;
+    asm volatile("" : "+v"(v));
+    return acc ? old + v : v;
+}
+
 __device__ __forceinline__ void bias_reduce_block(const float* __restrict__ part, float* __restrict__ db, int N, int splits,
-                                                  int blk) {
+                                                  int blk, float scale, int acc) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int n = blk * 4 + w;
     if (n >= N) return;
@@ -697,7 +706,7 @@ __device__ __forceinline__ void bias_reduce_block(const float* __restrict__ part
     for (int s = l; s < splits; s += 64) v += part[(long)s * N + n];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (l == 0) db[n] = v;
+    if (l == 0) db[n] = wg_out(v, acc ? db[n] : 0.f, scale, acc);
 }
 
 // dw_oihw[n][c][t] = sum_split partial[split][n][t][c]   (fixed order => deterministic)
@@ -705,12 +714,12 @@ __device__ __forceinline__ void bias_reduce_block(const float* __restrict__ part
 // 256-byte rows), four slices in flight per tap.  The T results of a thread are consecutive in OIHW, so a block's
 // 256 pairs form one contiguous span of 256*T floats: it is transposed through LDS and written with coalesced
 // rows (the direct form wrote 4 bytes at a 36-byte lane stride).  Fixed summation order -> deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* dw,
                                                            int N, int C, int T, int splits, int main_blocks,
-                                                           const float* __restrict__ bias_part, float* __restrict__ db) {
+                                                           const float* __restrict__ bias_part, float* db, float scale, int accum) {
     __shared__ float tile[256 * 9];
     if ((int)blockIdx.x >= main_blocks) {
-        bias_reduce_block(bias_part, db, N, splits, blockIdx.x - main_blocks);
+        bias_reduce_block(bias_part, db, N, splits, blockIdx.x - main_blocks, scale, accum);
         return;
     }
     const long total = (long)N * C * T;
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int o = j * 256 + threadIdx.x;
-            if (o < span) dw[i0 * 9 + o] = tile[o];
+            if (o < span) dw[i0 * 9 + o] = wg_out(tile[o], accum ? dw[i0 * 9 + o] : 0.f, scale, accum);
         }
         return;
     }
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int t = 0; t < T; ++t) {
         float a = 0.f;
         for (int k = 0; k < splits; ++k) a += src[(long)k * total + (long)t * C];
-        dst[t] = a;
+        dst[t] = wg_out(a, accum ? dst[t] : 0.f, scale, accum);
     }
 }
 
@@ -770,13 +779,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // groups: thread (g, p) sums slices g, g+G, ... of its pair, the G partial sums are combined through LDS in
 // fixed order (deterministic), T outputs per pair.
 template <int PP, int G>
-__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ partial, float* dw,
                                                                  int N, int C, int T, int splits, int main_blocks,
-                                                                 const float* __restrict__ bias_part, float* __restrict__ db) {
+                                                                 const float* __restrict__ bias_part, float* db, float scale, int accum) {
     static_assert(PP * G == 256, "one thread per (pair, slice group)");
     __shared__ float red[G][PP][9];
     if ((int)blockIdx.x >= main_blocks) {
-        bias_reduce_block(bias_part, db, N, splits, blockIdx.x - main_blocks);
+        bias_reduce_block(bias_part, db, N, splits, blockIdx.x - main_blocks, scale, accum);
         return;
     }
     const long total = (long)N * C * T;
@@ -821,28 +830,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
             float sum = 0.f;
 #pragma unroll
             for (int q = 0; q < G; ++q) sum += red[q][pp][t];
-            dw[(long)blockIdx.x * PP * T + o] = sum;
+            float* d = dw + (long)blockIdx.x * PP * T + o;
+            *d = wg_out(sum, accum ? *d : 0.f, scale, accum);
         }
     }
 }
 
 // bias_part / db != null: the same launch also reduces the per-split bias sums (bias_reduce_block)
-static void launch_wgrad_reduce(const float* partial, float* dw, int N, int C, int T, int splits, hipStream_t s,
+struct WgOut {  // dw = (accumulate ? dw : 0) + scale * sum
+    float scale;
+    int accumulate;
+};
+static WgOut wg_out_of(const ConvKParams& p) { return WgOut{p.wg_scale != 0.f ? p.wg_scale : 1.f, p.wg_accumulate}; }
+
+static void launch_wgrad_reduce(const float* partial, float* dw, int N, int C, int T, int splits, hipStream_t s, WgOut wo,
                                 const float* bias_part = nullptr, float* db = nullptr) {
     const long pairs = (long)N * C;
     const unsigned extra = (bias_part && db) ? (unsigned)((N + 3) / 4) : 0u;
     if (T <= 9 && splits >= 32 && (pairs <= 2048 || (pairs <= 8192 && splits >= 256))) {
         const unsigned mb = (unsigned)((pairs + 7) / 8);
         hipLaunchKernelGGL((wgrad_reduce_small_kernel<8, 32>), dim3(mb + extra), dim3(256), 0, s, partial, dw, N, C, T, splits,
-                           (int)mb, bias_part, db);
+                           (int)mb, bias_part, db, wo.scale, wo.accumulate);
     } else if (T <= 9 && splits >= 16 && pairs <= 16384) {
         const unsigned mb = (unsigned)((pairs + 31) / 32);
         hipLaunchKernelGGL((wgrad_reduce_small_kernel<32, 8>), dim3(mb + extra), dim3(256), 0, s, partial, dw, N, C, T, splits,
-                           (int)mb, bias_part, db);
+                           (int)mb, bias_part, db, wo.scale, wo.accumulate);
     } else {
         const unsigned mb = (unsigned)((pairs + 255) / 256);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mb + extra), dim3(256), 0, s, partial, dw, N, C, T, splits, (int)mb,
-                           bias_part, db);
+                           bias_part, db, wo.scale, wo.accumulate);
     }
 }
 
@@ -1181,7 +1197,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         if (rc != STYLEX_NOT_APPLICABLE) {
             if (rc) return rc;
             const bool with_db = db && bias_done;
-            launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, slices, s, with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
+            launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, slices, s, wg_out_of(p), with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
             if (with_db && db_done) *db_done = 1;
             return (int)hipGetLastError();
         }
@@ -1197,7 +1213,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         int rc = stylex_launch_wgrad_halo(p, partial, s, &hs, &bias_done);
         if (rc) return rc;
         const bool with_db = db && bias_done;
-        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s, with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
+        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s, wg_out_of(p), with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
         if (with_db && db_done) *db_done = 1;
         return (int)hipGetLastError();
     }
@@ -1205,7 +1221,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         int ts = 0;
         int rc = stylex_launch_wgrad_tr(p, partial, s, &ts);
         if (rc) return rc;
-        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, p.KH * p.KW, ts, s);
+        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, p.KH * p.KW, ts, s, wg_out_of(p));
         return (int)hipGetLastError();
     }
     int tn, tc, splits;
@@ -1230,7 +1246,7 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
                 : (vec ? launch_wgrad<1, 1, true, false>(p, blocks, s) : launch_wgrad<1, 1, false, false>(p, blocks, s));
     }
     if (rc) return rc;
-    launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, T, splits, s);
+    launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, T, splits, s, wg_out_of(p));
     return (int)hipGetLastError();
 }
 
@@ -1238,7 +1254,7 @@ int stylex_launch_wgrad_s2d_folded(ConvKParams p, float* partial, float* dw_oihw
     int slices = 0;
     int rc = stylex_launch_wgrad_pipe(p, partial, s, &slices, nullptr);
     if (rc) return rc == STYLEX_NOT_APPLICABLE ? STYLEX_EINVAL : rc;
-    launch_wgrad_reduce(partial, dw_oihw, p.N, p.s2d_c, 9, slices, s);
+    launch_wgrad_reduce(partial, dw_oihw, p.N, p.s2d_c, 9, slices, s, wg_out_of(p));
     return (int)hipGetLastError();
 }
 

@@ -492,6 +492,13 @@ int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* wor
 int stylex_conv2d_bwd_weight_bias(const void* x, const void* dy, float* dw, float* db, int* db_written, void* workspace,
                                   int64_t workspace_bytes, const int64_t* sh, const float* x_scale, const float* dy_scale,
                                   int s2d_c, int precision, void* stream) {
+    return stylex_conv2d_bwd_weight_ex(x, dy, dw, db, db_written, workspace, workspace_bytes, sh, x_scale, dy_scale, s2d_c, 1.f, 0,
+                                       precision, stream);
+}
+
+int stylex_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw, float* db, int* db_written, void* workspace,
+                                int64_t workspace_bytes, const int64_t* sh, const float* x_scale, const float* dy_scale,
+                                int s2d_c, float out_scale, int accumulate, int precision, void* stream) {
     if (db_written) *db_written = 0;
     if (db && !db_written) return STYLEX_EINVAL;
     if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh)) return STYLEX_EINVAL;
@@ -506,6 +513,8 @@ int stylex_conv2d_bwd_weight_bias(const void* x, const void* dy, float* dw, floa
     p.act_bf16 = precision == STYLEX_BF16_ACT;
     if (p.act_bf16) precision = STYLEX_BF16;
     p.s2d_c = s2d_c;
+    p.wg_scale = out_scale;
+    p.wg_accumulate = accumulate ? 1 : 0;
     if (s2d_c && (p.Ck != 4 * s2d_c || s2d_c % 64 || p.KH != 3 || p.stride != 1)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * p.KH * p.KW / (s2d_c ? 4.0 : 1.0);
     ScopedTimer tm(2, flops, conv_bytes(sh, p.act_bf16 ? STYLEX_BF16_ACT : precision, true), (hipStream_t)stream, sh, s2d_c);
@@ -522,7 +531,7 @@ int stylex_conv2d_bwd_weight_s2d_supported(const int64_t* sh, int s2d_c, int pre
 }
 
 int stylex_conv2d_bwd_weight_s2d(const void* x2, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
-                                 const int64_t* sh, int s2d_c, int precision, void* stream) {
+                                 const int64_t* sh, int s2d_c, float out_scale, int accumulate, int precision, void* stream) {
     if (!x2 || !dy || !dw || !workspace || !conv_shape_ok(sh) || precision != STYLEX_BF16_ACT || s2d_c <= 0) return STYLEX_EINVAL;
     if (workspace_bytes < stylex_conv2d_bwd_weight_workspace_bytes(sh)) return STYLEX_EWORKSPACE;
     ConvKParams p;
@@ -531,6 +540,8 @@ int stylex_conv2d_bwd_weight_s2d(const void* x2, const void* dy, float* dw, void
     p.a2 = (const float*)dy;
     p.act_bf16 = 1;
     p.s2d_c = s2d_c;
+    p.wg_scale = out_scale;
+    p.wg_accumulate = accumulate ? 1 : 0;
     if (!stylex_wgrad_pipe_applicable(p)) return STYLEX_EINVAL;
     double flops = 2.0 * p.M * (double)p.N * p.Ck * 9 / 4.0;
     ScopedTimer tm(2, flops, conv_bytes(sh, STYLEX_BF16_ACT, true), (hipStream_t)stream, sh, s2d_c);

@@ -45,6 +45,10 @@ struct ConvKParams {
     const void* x2;                 // [B][Ho][Wo][c2] bf16 (the block input at the even pixels), or null
     const void* w2;                 // [N][c2] bf16
     int c2;
+    // weight gradient only: the reduce launch writes dw = (wg_accumulate ? dw : 0) + wg_scale * sum (wg_scale 0 = 1);
+    // a bias sum produced by the same launch likewise
+    float wg_scale;
+    int wg_accumulate;
 };
 
 int stylex_launch_igemm(ConvKParams p, int precision, void* workspace, int64_t workspace_bytes, hipStream_t s);

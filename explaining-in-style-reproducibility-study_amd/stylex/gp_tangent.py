@@ -195,15 +195,14 @@ class _DRealPenalty(torch.autograd.Function):
             # weight gradients: operand s_b * (primal activation) + (tangent activation), gradient = unit chain's
             gw1 = hb.conv2d_bwd_weight(operand(x, t), gz1, tuple(w1p.shape), 1, 1, prec)
             gw2 = hb.conv2d_bwd_weight(operand(y1, a1), gz2, tuple(w2.shape), 1, 1, prec)
-            gw_res = hb.conv2d_bwd_weight(operand(xs, ts), gz3, tuple(wrp.shape), 1, 0, prec)
+            # (the 1/sqrt(2) owed by the gradients computed from the unscaled gz3 rides their reduce launches)
+            gw_res = hb.conv2d_bwd_weight(operand(xs, ts), gz3, tuple(wrp.shape), 1, 0, prec, out_scale=wsc)
             gw3 = gb3 = None
             if downsample:
                 if s2d:
-                    gw3 = hb.conv2d_bwd_weight_s2d(operand(xb, ab), gz3, tuple(w3.shape), prec)
+                    gw3 = hb.conv2d_bwd_weight_s2d(operand(xb, ab), gz3, tuple(w3.shape), prec, out_scale=wsc)
                 else:
-                    gw3 = hb.conv2d_bwd_weight(operand(xb, ab), gz3, tuple(w3.shape), 2, 1, prec)
-            if wsc != 1.0:
-                torch._foreach_mul_([g for g in (gw_res, gw3) if g is not None], wsc)
+                    gw3 = hb.conv2d_bwd_weight(operand(xb, ab), gz3, tuple(w3.shape), 2, 1, prec, out_scale=wsc)
             if cin == 3:
                 gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
             # bias gradients: the hinge term only (the tangent network has no biases)

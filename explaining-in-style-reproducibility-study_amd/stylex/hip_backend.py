@@ -67,6 +67,9 @@ SIGNATURES = {
     "stylex_conv2d_bwd_weight_bias": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
                                                      ctypes.c_int64, _i64p, _c_f, _c_f, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_void_p]),
+    "stylex_conv2d_bwd_weight_ex": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                                                   ctypes.c_int64, _i64p, _c_f, _c_f, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_s2d_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_blur3x3_reflect_bwd_gate": (ctypes.c_int, [_c_f, _c_f, ctypes.c_float, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -80,7 +83,7 @@ SIGNATURES = {
     "stylex_fold_weight_grad_s2d": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_conv2d_bwd_weight_s2d_supported": (ctypes.c_int, [_i64p, ctypes.c_int, ctypes.c_int]),
     "stylex_conv2d_bwd_weight_s2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f, ctypes.c_void_p, ctypes.c_int64, _i64p,
-                                                    ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                                    ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_fwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_upsample2x_bilinear_bwd": (ctypes.c_int, [_c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
     "stylex_rgb_up_blur_add_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -742,10 +745,11 @@ def pack_weight_s2d(w, scale=None):
 _S2D_WGRAD_OK = {}
 
 
-def conv2d_bwd_weight_s2d(x2, dy, w_shape, precision):
+def conv2d_bwd_weight_s2d(x2, dy, w_shape, precision, out_scale=1.0, accumulate_into=None):
     """Weight gradient [N][C][3][3] of the 3x3 / stride-2 conv whose (blurred) input is given space-to-depth (x2: [B, 4C,
     H/2, W/2]).  One call on the pipelined LDS-DMA weight-gradient kernel where it applies (stylex_conv2d_bwd_weight_s2d:
-    folded layout written directly), else the weight gradient of the s2d conv + stylex_fold_weight_grad_s2d."""
+    folded layout written directly), else the weight gradient of the s2d conv + stylex_fold_weight_grad_s2d.
+    out_scale / accumulate_into: the output stage of conv2d_bwd_weight."""
     lib = _ensure_device(x2)
     n, c = int(w_shape[0]), int(w_shape[1])
     ws2 = (n, 4 * c, 3, 3)
@@ -761,11 +765,18 @@ def conv2d_bwd_weight_s2d(x2, dy, w_shape, precision):
         shp = _shape(*sh)
         nbytes = lib.stylex_conv2d_bwd_weight_workspace_bytes(shp)
         ws = _empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
-        dw = _empty((n, c, 3, 3), dtype=torch.float32, device=x2.device)
-        _check(lib.stylex_conv2d_bwd_weight_s2d(_ptr(x2), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, c, precision, _stream()),
+        dw = accumulate_into if accumulate_into is not None else _empty((n, c, 3, 3), dtype=torch.float32, device=x2.device)
+        assert tuple(dw.shape) == (n, c, 3, 3) and dw.dtype == torch.float32 and dw.is_contiguous()
+        _check(lib.stylex_conv2d_bwd_weight_s2d(_ptr(x2), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, c, float(out_scale),
+                                                int(accumulate_into is not None), precision, _stream()),
                "stylex_conv2d_bwd_weight_s2d")
         return dw
-    return fold_weight_grad_s2d(conv2d_bwd_weight(x2, dy, ws2, 1, 1, precision, s2d_c=c), (n, c, 3, 3))
+    dw = fold_weight_grad_s2d(conv2d_bwd_weight(x2, dy, ws2, 1, 1, precision, s2d_c=c), (n, c, 3, 3))
+    if out_scale != 1.0:
+        dw.mul_(out_scale)
+    if accumulate_into is not None:
+        return accumulate_into.add_(dw)
+    return dw
 
 
 def fold_weight_grad_s2d(dw2, w_shape):
@@ -1104,10 +1115,14 @@ def modcoeff_bwd(gd, d, s1, wsq, w, gs1, want_style, want_weight):
     return gstyle, gw
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None, s2d_c=0, want_bias_sum=False):
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_scale=None, s2d_c=0, want_bias_sum=False,
+                      out_scale=1.0, accumulate_into=None, accumulate_bias_into=None):
     """Weight gradient (OIHW fp32).  want_bias_sum=True returns the pair (dw, db): db = dy summed over (b, h, w) in fp32
     — the bias gradient — when the kernel serving this shape produces it from the dy tiles it stages anyway
-    (stylex_conv2d_bwd_weight_bias), else None (the caller reduces dy itself)."""
+    (stylex_conv2d_bwd_weight_bias), else None (the caller reduces dy itself).
+    Output stage of the reduce launch (stylex_conv2d_bwd_weight_ex): dw = (accumulate_into or 0) + out_scale * sum, written
+    into accumulate_into when given (db into accumulate_bias_into likewise) — bit-identical to multiplying the stored sum
+    and adding it with another launch."""
     lib = _ensure_device(x)
     adt = act_dtype(precision)
     assert is_cl(x) and is_cl(dy) and x.dtype == adt and dy.dtype == adt, (x.dtype, dy.dtype, adt)
@@ -1117,8 +1132,27 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
     if nbytes < 0:
         raise StylexHipError("bad wgrad shape %r" % (sh,))
     ws = _empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
-    dw = _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     x_scale, dy_scale = _f32(x_scale), _f32(dy_scale)
+    if out_scale != 1.0 or accumulate_into is not None:
+        acc = accumulate_into is not None
+        dw = accumulate_into if acc else _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+        assert tuple(dw.shape) == tuple(w_shape) and dw.dtype == torch.float32 and dw.is_contiguous()
+        db, written = None, ctypes.c_int(0)
+        if want_bias_sum:
+            # (an accumulating launch adds its bias sums into the tensor given for them, or hands back a plain sum)
+            db = accumulate_bias_into if (acc and accumulate_bias_into is not None) else None
+            if acc and db is None:  # dw accumulates but db has no partner: keep the two stages apart
+                dwn, dbn = conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale, dy_scale, s2d_c, True, out_scale)
+                return dw.add_(dwn), dbn
+            if db is None:
+                db = _empty(w_shape[0], dtype=torch.float32, device=x.device)
+        _check(lib.stylex_conv2d_bwd_weight_ex(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), ctypes.byref(written), _ptr(ws), nbytes, shp,
+                                               _ptr(x_scale), _ptr(dy_scale), int(s2d_c), float(out_scale), int(acc), precision,
+                                               _stream()), "stylex_conv2d_bwd_weight_ex")
+        if want_bias_sum:
+            return dw, (db if written.value else None)
+        return dw
+    dw = _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     if want_bias_sum:
         db = _empty(w_shape[0], dtype=torch.float32, device=x.device)
         written = ctypes.c_int(0)

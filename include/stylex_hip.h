@@ -161,6 +161,17 @@ int stylex_conv2d_bwd_weight(const void* x, const void* dy, float* dw, void* wor
 int stylex_conv2d_bwd_weight_bias(const void* x, const void* dy, float* dw, float* db, int* db_written, void* workspace,
                                   int64_t workspace_bytes, const int64_t* shape, const float* x_scale,
                                   const float* dy_scale, int s2d_c, int precision, void* stream);
+/* Round 5: as stylex_conv2d_bwd_weight_bias (db may be NULL) with an output stage in the reduce launch:
+ *   dw = (accumulate ? dw : 0) + out_scale * sum        (db likewise when it is written)
+ * computed as two rounded fp32 operations, i.e. bit-identical to storing the sum, multiplying it in place and letting
+ * autograd's AccumulateGrad add it to an existing gradient.  out_scale replaces the multi-tensor multiply of
+ * DiscriminatorBlock's 1/sqrt(2) (reference stylex_train.py:743: (x + res) * (1 / math.sqrt(2))) on the weight gradients
+ * computed from the unscaled output gradient; accumulate lets the second use of a twice-used parameter (the encoder of a
+ * generator phase: E(x) and E(G(x)), stylex_train.py:1383-1395) add into the first use's gradient tensor instead of
+ * handing the engine a second tensor to add. */
+int stylex_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw, float* db, int* db_written, void* workspace,
+                                int64_t workspace_bytes, const int64_t* shape, const float* x_scale, const float* dy_scale,
+                                int s2d_c, float out_scale, int accumulate, int precision, void* stream);
 
 /* Elementwise / resampling entry points take `act_dtype`: 0 = fp32 activations, 1 = bf16 activations
  * (the storage type of STYLEX_BF16_ACT); arithmetic is fp32 either way.
@@ -229,8 +240,9 @@ int stylex_fold_weight_grad_s2d(const float* dw_s2d, float* dw_oihw, const int64
  * 16-byte aligned tensors) runs there, else 0 — then stylex_conv2d_bwd_weight_s2d returns STYLEX_EINVAL and the caller
  * uses stylex_conv2d_bwd_weight + stylex_fold_weight_grad_s2d. */
 int stylex_conv2d_bwd_weight_s2d_supported(const int64_t* shape, int s2d_c, int precision);
+/* out_scale / accumulate: the output stage of stylex_conv2d_bwd_weight_ex. */
 int stylex_conv2d_bwd_weight_s2d(const void* x2, const void* dy, float* dw_oihw, void* workspace, int64_t workspace_bytes,
-                                 const int64_t* shape, int s2d_c, int precision, void* stream);
+                                 const int64_t* shape, int s2d_c, float out_scale, int accumulate, int precision, void* stream);
 
 /* y = leaky_relu(x + bias[c] (+ noise[b][w][h]*noise_w[c] + noise_b[c]), 0.2)
  * (nn.Conv2d bias + leaky_relu, stylex_train.py:340-341,726-731; noise add :696-714).

@@ -105,7 +105,9 @@ for (b, h, c, n, k, stride, pad), prec, flagset in itertools.product(
     lib.stylex_conv2d_bwd_weight(ptr(x), ptr(y), ptr(dw), ptr(ws), i64(wsb), sh, ptr(sc_in), ptr(sc_out), 0, prec, None)
     lib.stylex_conv2d_bwd_weight_bias(ptr(x), ptr(y), ptr(dw), ptr(db), ctypes.byref(wrote), ptr(ws), i64(wsb), sh, None, None, 0,
                                       prec, None)
-    calls += 9
+    lib.stylex_conv2d_bwd_weight_ex(ptr(x), ptr(y), ptr(dw), ptr(db), ctypes.byref(wrote), ptr(ws), i64(wsb), sh, None, None, 0,
+                                    ctypes.c_float(0.5), 1, prec, None)
+    calls += 10
 # invalid arguments must be rejected, not dereferenced
 bad = shape(0, -1, 8, 8, 8, 3, 3, 1, 1, 8, 8)
 assert lib.stylex_conv2d_fwd(None, None, None, bad, 0, None, 2, None, i64(0), None) != 0

@@ -293,6 +293,39 @@ def test_s2d_forward_pipelined_kernel(shape, tile_mode, monkeypatch):
         assert d < 8e-3, (form, d)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 128, 32, 32, 3, 1, 1, 0), (2, 64, 128, 16, 16, 1, 1, 0, 0), (4, 512, 512, 4, 4, 3, 1, 1, 0),
+                                  (2, 8, 64, 32, 32, 3, 1, 1, 0), (2, 64, 64, 32, 32, 3, 1, 1, 64)])
+def test_weight_gradient_output_stage_is_the_two_launches_it_replaces(case):
+    """stylex_conv2d_bwd_weight_ex / _s2d (round 5): dw = (accumulate ? dw : 0) + out_scale * sum inside the reduce launch must
+    be BIT-identical to the plain weight gradient followed by an in-place multiply and autograd's add into an existing
+    gradient — for every weight-gradient kernel family (pipelined LDS-DMA, 1x1 / transpose-read, <= 8 px, padded RGB, the
+    folded stride-2 form) and for the bias sums that ride the same launch."""
+    B, C, N, H, W, k, s, p, s2d = case
+    g = torch.Generator().manual_seed(31)
+    xc = 4 * C if s2d else C
+    x = cl(torch.randn(B, xc, H, W, generator=g).bfloat16().to(DEV))
+    dy = cl(torch.randn(B, N, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, generator=g).bfloat16().to(DEV))
+    old = torch.randn(N, C, k, k, generator=g).to(DEV)
+    oldb = torch.randn(N, generator=g).to(DEV)
+    sc = 0.7071067811865476
+    if s2d:
+        plain = hb.conv2d_bwd_weight_s2d(x, dy, (N, C, 3, 3), hb.BF16_ACT)
+        scaled = hb.conv2d_bwd_weight_s2d(x, dy, (N, C, 3, 3), hb.BF16_ACT, out_scale=sc)
+        acc = hb.conv2d_bwd_weight_s2d(x, dy, (N, C, 3, 3), hb.BF16_ACT, out_scale=sc, accumulate_into=old.clone())
+        assert torch.equal(scaled, plain * sc) and torch.equal(acc, old + plain * sc)
+        return
+    plain, pb = hb.conv2d_bwd_weight(x, dy, (N, C, k, k), s, p, hb.BF16_ACT, want_bias_sum=True)
+    scaled, sb = hb.conv2d_bwd_weight(x, dy, (N, C, k, k), s, p, hb.BF16_ACT, want_bias_sum=True, out_scale=sc)
+    acc, ab = hb.conv2d_bwd_weight(x, dy, (N, C, k, k), s, p, hb.BF16_ACT, want_bias_sum=True, out_scale=sc,
+                                   accumulate_into=old.clone(), accumulate_bias_into=oldb.clone())
+    assert torch.equal(scaled, plain * sc) and torch.equal(acc, old + plain * sc)
+    assert (pb is None) == (sb is None) == (ab is None)
+    if pb is not None:
+        assert torch.equal(sb, pb * sc) and torch.equal(ab, oldb + pb * sc)
+    only_w = hb.conv2d_bwd_weight(x, dy, (N, C, k, k), s, p, hb.BF16_ACT, accumulate_into=old.clone())
+    assert torch.equal(only_w, old + plain)
+
+
 def test_conv_bias_lrelu_and_second_order():
     """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
     g = torch.Generator().manual_seed(5)
