@@ -250,6 +250,20 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class RawGrad:
+    """A gradient tensor the autograd engine is holding, named by address and shape only: a reference to the tensor itself
+    would keep AccumulateGrad from stealing it (it clones a gradient somebody else still refers to).  Accepted as
+    accumulate_into / accumulate_bias_into of conv2d_bwd_weight / conv2d_bwd_weight_s2d (ops._gacc_*)."""
+    __slots__ = ("ptr", "shape")
+
+    def __init__(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self.ptr, self.shape = t.data_ptr(), tuple(t.shape)
+
+    def data_ptr(self):
+        return self.ptr
+
+
 def is_cl(t):
     return t.is_contiguous(memory_format=torch.channels_last)
 
@@ -766,14 +780,16 @@ def conv2d_bwd_weight_s2d(x2, dy, w_shape, precision, out_scale=1.0, accumulate_
         nbytes = lib.stylex_conv2d_bwd_weight_workspace_bytes(shp)
         ws = _empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2.device)
         dw = accumulate_into if accumulate_into is not None else _empty((n, c, 3, 3), dtype=torch.float32, device=x2.device)
-        assert tuple(dw.shape) == (n, c, 3, 3) and dw.dtype == torch.float32 and dw.is_contiguous()
+        assert tuple(dw.shape) == (n, c, 3, 3) and (isinstance(dw, RawGrad) or (dw.dtype == torch.float32 and dw.is_contiguous()))
         _check(lib.stylex_conv2d_bwd_weight_s2d(_ptr(x2), _ptr(dy), _ptr(dw), _ptr(ws), nbytes, shp, c, float(out_scale),
                                                 int(accumulate_into is not None), precision, _stream()),
                "stylex_conv2d_bwd_weight_s2d")
-        return dw
+        return None if isinstance(dw, RawGrad) else dw
     dw = fold_weight_grad_s2d(conv2d_bwd_weight(x2, dy, ws2, 1, 1, precision, s2d_c=c), (n, c, 3, 3))
     if out_scale != 1.0:
         dw.mul_(out_scale)
+    if isinstance(accumulate_into, RawGrad):
+        return dw  # (no tensor to add into: the caller hands this one to the engine)
     if accumulate_into is not None:
         return accumulate_into.add_(dw)
     return dw
@@ -1136,21 +1152,25 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale=None, dy_s
     if out_scale != 1.0 or accumulate_into is not None:
         acc = accumulate_into is not None
         dw = accumulate_into if acc else _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
-        assert tuple(dw.shape) == tuple(w_shape) and dw.dtype == torch.float32 and dw.is_contiguous()
+        raw = isinstance(dw, RawGrad)
+        assert tuple(dw.shape) == tuple(w_shape) and (raw or (dw.dtype == torch.float32 and dw.is_contiguous()))
         db, written = None, ctypes.c_int(0)
         if want_bias_sum:
             # (an accumulating launch adds its bias sums into the tensor given for them, or hands back a plain sum)
             db = accumulate_bias_into if (acc and accumulate_bias_into is not None) else None
-            if acc and db is None:  # dw accumulates but db has no partner: keep the two stages apart
-                dwn, dbn = conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale, dy_scale, s2d_c, True, out_scale)
-                return dw.add_(dwn), dbn
+            if acc and db is None:  # dw accumulates but db has no partner: dw alone in this launch, the caller reduces dy
+                return conv2d_bwd_weight(x, dy, w_shape, stride, pad, precision, x_scale, dy_scale, s2d_c, False, out_scale,
+                                         accumulate_into), None
             if db is None:
                 db = _empty(w_shape[0], dtype=torch.float32, device=x.device)
         _check(lib.stylex_conv2d_bwd_weight_ex(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), ctypes.byref(written), _ptr(ws), nbytes, shp,
                                                _ptr(x_scale), _ptr(dy_scale), int(s2d_c), float(out_scale), int(acc), precision,
                                                _stream()), "stylex_conv2d_bwd_weight_ex")
+        dw = None if raw else dw  # (a RawGrad names a tensor the engine holds: nothing to hand back)
         if want_bias_sum:
-            return dw, (db if written.value else None)
+            if not written.value:
+                return dw, None
+            return dw, (True if isinstance(db, RawGrad) else db)  # True: the sums were added into accumulate_bias_into
         return dw
     dw = _empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     if want_bias_sum:

@@ -888,12 +888,13 @@ class _DBlockFast(torch.autograd.Function):
             wbr = hb.pack_weight(wrp, False, True, prec, scale=c)[1] if alg else None
             return hb.conv2d_bwd_data(gz3, wrp, tuple(xs.shape), 1, 0, prec, packed=wbr, w_shape=tuple(wrp.shape))
 
+        a_res = _gacc_get(w_res) if (want_w and cin != 3) else None
         if side_bwd is not None:
             side_bwd.wait_stream(main)
             with torch.cuda.stream(side_bwd):
                 s_gw = s_gx = None
                 if want_w:
-                    s_gw = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec, out_scale=wsc)
+                    s_gw = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec, out_scale=wsc, accumulate_into=a_res)
                 if want_x:
                     s_gx = res_dgrad()
                 side_out = (s_gw, s_gx)
@@ -907,34 +908,61 @@ class _DBlockFast(torch.autograd.Function):
                 gxb = hb.conv2d_bwd_data(gz3, None, tuple(xb.shape), 1, 1, prec, packed=wb2, w_shape=(w3.shape[0], 4 * n, 3, 3),
                                          s2d_c=n)
                 if want_w:
-                    gw3 = hb.conv2d_bwd_weight_s2d(xb, gz3, tuple(w3.shape), prec, out_scale=wsc)
+                    a3 = _gacc_get(w3)
+                    gw3 = hb.conv2d_bwd_weight_s2d(xb, gz3, tuple(w3.shape), prec, out_scale=wsc, accumulate_into=a3)
+                    if a3 is None and need[7]:
+                        _gacc_put(w3, gw3)
                 gz2 = hb.blur3x3_s2d_bwd(gxb, gate=y2, gate_mask=m2)  # blur adjoint + LeakyReLU derivative of y2, one pass
             else:
                 wb3 = hb.pack_weight(w3, False, True, prec, scale=c)[1] if alg else None
                 gxb = hb.conv2d_bwd_data(gz3, w3, tuple(xb.shape), 2, 1, prec, packed=wb3, w_shape=tuple(w3.shape))
                 if want_w:
-                    gw3 = hb.conv2d_bwd_weight(xb, gz3, tuple(w3.shape), 2, 1, prec, out_scale=wsc)
+                    a3 = _gacc_get(w3)
+                    gw3 = hb.conv2d_bwd_weight(xb, gz3, tuple(w3.shape), 2, 1, prec, out_scale=wsc, accumulate_into=a3)
+                    if a3 is None and need[7]:
+                        _gacc_put(w3, gw3)
                 gz2 = hb.blur3x3_bwd_gate(gxb, y2)
         else:
             gz2 = hb.bias_act_bwd(gz3, y2)
         # bias gradients = per-channel sums of gz2 / gz1: taken from the weight-gradient kernel (which stages those
         # tensors anyway) where it can, else a read-only reduction pass
         fuse_b = want_b and want_w and os.environ.get("STYLEX_WGRAD_BIAS", "1") != "0"
+        acc_b2 = False
         if want_w:
-            gw2 = hb.conv2d_bwd_weight(y1, gz2, tuple(w2.shape), 1, 1, prec, want_bias_sum=fuse_b)
+            a2w, a2b = _gacc_get(w2), _gacc_get(w2, "b")
+            gw2 = hb.conv2d_bwd_weight(y1, gz2, tuple(w2.shape), 1, 1, prec, want_bias_sum=fuse_b, accumulate_into=a2w,
+                                       accumulate_bias_into=a2b if a2w is not None else None)
             if fuse_b:
                 gw2, gb2 = gw2
-        if want_b and gb2 is None:
+                if gb2 is True:  # added into the first use's bias gradient
+                    gb2, acc_b2 = None, True
+            if a2w is None:  # (only what this node really hands to the engine may be named)
+                if need[5]:
+                    _gacc_put(w2, gw2)
+                if need[6]:
+                    _gacc_put(w2, gb2, "b")
+        if want_b and gb2 is None and not acc_b2:
             gb2 = _channel_sum(gz2)
         gz1 = hb.conv2d_bwd_data(gz2, w2, tuple(y1.shape), 1, 1, prec, gate=y1, gate_mask=m1)  # + LeakyReLU derivative of y1
         if getattr(ctx, "keep_gz", False):  # hand-driven backward (gp_tangent): the pre-activation gradients are reused
             ctx.gz = (gz3, gz2, gz1, alg)
         gxs = None
+        acc_b1 = False
         if want_w:
-            gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec, want_bias_sum=fuse_b)
+            a1w = _gacc_get(w1) if cin != 3 else None  # (the padded-RGB block returns a slice of its gradient)
+            a1b = _gacc_get(w1, "b") if a1w is not None else None
+            gw1 = hb.conv2d_bwd_weight(x, gz1, tuple(w1p.shape), 1, 1, prec, want_bias_sum=fuse_b, accumulate_into=a1w,
+                                       accumulate_bias_into=a1b)
             if fuse_b:
                 gw1, gb1 = gw1
-        if want_b and gb1 is None:
+                if gb1 is True:
+                    gb1, acc_b1 = None, True
+            if a1w is None and cin != 3:
+                if need[3]:
+                    _gacc_put(w1, gw1)
+                if need[4]:
+                    _gacc_put(w1, gb1, "b")
+        if want_b and gb1 is None and not acc_b1:
             gb1 = _channel_sum(gz1)
         if want_x:
             pk1 = dict(packed=hb.pack_weight(w1p, False, True, prec, owner=w1)[1], w_shape=tuple(w1p.shape)) \
@@ -948,11 +976,13 @@ class _DBlockFast(torch.autograd.Function):
                     t.record_stream(main)
         else:
             if want_w:
-                gw_res = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec, out_scale=wsc)
+                gw_res = hb.conv2d_bwd_weight(xs, gz3, tuple(wrp.shape), 1, 0, prec, out_scale=wsc, accumulate_into=a_res)
             if want_x:
                 gxs = res_dgrad()
         # (round 5: the 1/sqrt(2) owed by gw_res, gw3 and gsum3 rides their reduce launches — it was a multi-tensor multiply
         # of 26 us per block, 0.47 ms per step)
+        if want_w and a_res is None and cin != 3 and need[1]:
+            _gacc_put(w_res, gw_res)
         if want_w and cin == 3:
             gw1, gw_res = gw1[:, :3].contiguous(), gw_res[:, :3].contiguous()
         if want_x:
@@ -965,6 +995,37 @@ class _DBlockFast(torch.autograd.Function):
         return (gx, gw_res if need[1] else None, gb_res if need[2] else None, gw1 if need[3] else None,
                 gb1 if need[4] else None, gw2 if need[5] else None, gb2 if need[6] else None,
                 gw3 if need[7] else None, gb3 if need[8] else None, None)
+
+
+# Gradient accumulation inside the weight-gradient launches (round 5).  A parameter used by several fast-path nodes of ONE
+# backward pass (the encoder of a generator phase: E(x) and E(G(x)), reference stylex_train.py:1383-1395) used to hand the
+# autograd engine one gradient tensor per use, which the engine sums with an add launch per parameter (117 per step).  Now
+# the first node to run hands the engine its tensor and notes its ADDRESS (hb.RawGrad: a reference would keep AccumulateGrad
+# from stealing the tensor); a later node of the same graph task adds into that tensor in its reduce launch
+# (stylex_conv2d_bwd_weight_ex, accumulate) and returns None.  The engine keeps the first tensor alive, unmodified, until
+# the parameter's AccumulateGrad node runs — after every use, by its dependency count.  Same two rounded fp32 operations as
+# the engine's add: bit-identical gradients (tests/test_hip_parity.py::test_twice_used_block_accumulates_in_the_reduce_launch).
+_GACC = {}
+_GACC_TASK = [-2]
+_GACC_ON = os.environ.get("STYLEX_GRAD_ACC", "1") != "0"
+
+
+def _gacc_get(w, tag=""):
+    """The gradient tensor an earlier node of this backward pass produced for parameter w (tag: "b" = its layer's bias)."""
+    if not _GACC_ON or not w.is_cuda:
+        return None
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return None
+    if task != _GACC_TASK[0]:
+        _GACC.clear()
+        _GACC_TASK[0] = task
+    return _GACC.get((w.data_ptr(), tag))
+
+
+def _gacc_put(w, g, tag=""):
+    if _GACC_ON and g is not None and w.is_cuda and torch._C._current_graph_task_id() == _GACC_TASK[0] and g.is_contiguous():
+        _GACC[(w.data_ptr(), tag)] = hb.RawGrad(g)
 
 
 def _channel_sum(t, scale=1.0):

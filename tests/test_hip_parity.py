@@ -326,6 +326,50 @@ def test_weight_gradient_output_stage_is_the_two_launches_it_replaces(case):
     assert torch.equal(only_w, old + plain)
 
 
+@pytest.mark.parametrize("case", [(64, 64, 64, True), (64, 128, 32, True), (256, 256, 16, True), (64, 64, 2, False), (3, 64, 64, True)])
+def test_twice_used_block_accumulates_in_the_reduce_launch(case):
+    """A DiscriminatorBlock applied to two inputs in ONE graph (the encoder of a generator phase: E(x) and E(G(x)), reference
+    stylex_train.py:1383-1395): the second node to run adds its weight / bias gradients into the first node's tensors inside
+    its reduce launches (ops._gacc_*, stylex_conv2d_bwd_weight_ex accumulate) instead of handing the engine a second tensor
+    per parameter.  Same two rounded fp32 operations as the engine's add: every gradient bit-identical to the path without
+    it (STYLEX_GRAD_ACC=0), and fewer add launches."""
+    from torch.profiler import ProfilerActivity, profile
+
+    cin, cout, size, down = case
+    ops.set_precision("bf16")
+    torch.manual_seed(11)
+    blk = st.DiscriminatorBlock(cin, cout, downsample=down).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    g = torch.Generator(device=DEV).manual_seed(12)
+    xa = torch.randn(3, cin, size, size, device=DEV, generator=g)
+    xb = torch.randn(3, cin, size, size, device=DEV, generator=g)
+    results, adds = [], []
+    keep = ops._GACC_ON
+    try:
+        for on in (False, True):
+            ops._GACC_ON = on
+            blk.zero_grad()
+            ops.set_fast(True)
+            try:
+                with profile(activities=[ProfilerActivity.CPU]) as prof:
+                    ya, yb = blk(xa), blk(xb)
+                    ((ya.float() ** 2).mean() + 0.5 * (yb.float() ** 3).mean()).backward()
+                    torch.cuda.synchronize()
+            finally:
+                ops.set_fast(False)
+            adds.append(sum(1 for e in prof.events() if e.name in ("aten::add_", "aten::add")))
+            results.append([p.grad.clone() for p in blk.parameters()])
+    finally:
+        ops._GACC_ON = keep
+    for (name, _), a, b in zip(blk.named_parameters(), *results):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    if cin != 3:  # (the padded-RGB block hands the engine slices of its gradients: it keeps the engine's adds)
+        assert adds[1] <= adds[0] - 3, adds  # at least the block's three or four weight gradients
+
+
 def test_conv_bias_lrelu_and_second_order():
     """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
     g = torch.Generator().manual_seed(5)
