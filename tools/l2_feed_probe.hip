@@ -4,6 +4,7 @@
 //   mode 0: LDS-DMA   buffer_load_dwordx4 ... lds, whole 128-byte lines (8 lanes per line), `depth` instructions in flight per wave
 //   mode 1: VGPR loads buffer_load_dwordx4 into registers (discarded), same addresses, same depth
 //   mode 2: LDS-DMA of 64-byte half lines (the 32-channel stages of the stride-2 kernels: 4 lanes per 64-byte row)
+//   mode 3: LDS-DMA of 32-byte quarter lines (the 16-channel groups of conv_gather.hip / conv_halo_dma.hip: 2 lanes per row)
 // and prints bytes / clock / CU at the measured kernel time (clock = s_memrealtime-free: elapsed ms x 2.1 GHz nominal AND
 // wall-clock GB/s, so the figure can be re-based on the real clock).
 // build: hipcc -O3 --offload-arch=gfx950 tools/l2_feed_probe.hip -o /tmp/l2p && /tmp/l2p [blocks_per_cu=1] [waves=8] [depth=8]
@@ -20,8 +21,10 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 0x7fffffff, 0x00020000);
     // a wave instruction covers 1 KiB: 8 lines of 128 B (mode 0 / 1) or 16 half-lines of 64 B out of 16 different lines (mode 2)
-    const unsigned lane_off = MODE == 2 ? (unsigned)(lane >> 2) * 128u + (unsigned)(lane & 3) * 16u : (unsigned)lane * 16u;
-    const unsigned step = MODE == 2 ? 2048u : 1024u;  // bytes of address space per instruction
+    const unsigned lane_off = MODE == 2   ? (unsigned)(lane >> 2) * 128u + (unsigned)(lane & 3) * 16u
+                              : MODE == 3 ? (unsigned)(lane >> 1) * 128u + (unsigned)(lane & 1) * 16u
+                                          : (unsigned)lane * 16u;
+    const unsigned step = MODE == 2 ? 2048u : MODE == 3 ? 4096u : 1024u;  // bytes of address space per instruction
     const unsigned base = (unsigned)(((long)blockIdx.x * window) & 0x3fffffff);
     unsigned acc = 0;
     unsigned off = (unsigned)wave * step;
@@ -81,6 +84,8 @@ int main(int argc, char** argv) {
     run<0, 16>("LDS-DMA whole lines", src, window, blocks, waves, sink);
     run<2, 8>("LDS-DMA 64-byte half lines", src, window, blocks, waves, sink);
     run<2, 16>("LDS-DMA 64-byte half lines", src, window, blocks, waves, sink);
+    run<3, 8>("LDS-DMA 32-byte quarter lines", src, window, blocks, waves, sink);
+    run<3, 16>("LDS-DMA 32-byte quarter lines", src, window, blocks, waves, sink);
     run<1, 4>("VGPR loads whole lines", src, window, blocks, waves, sink);
     run<1, 8>("VGPR loads whole lines", src, window, blocks, waves, sink);
     run<1, 16>("VGPR loads whole lines", src, window, blocks, waves, sink);

@@ -15,7 +15,7 @@ with gzip.open(path, "rt") as f:
     for _ in range(n):
         k, nm = f.readline().rstrip("\n").split("\t", 1)
         names[int(k)] = nm
-    rows = sorted(tuple(int(v) for v in line.split(",")) for line in f)
+    rows = sorted(tuple(int(v) for v in line.split(",")[:3]) for line in f)  # (a 4th column, the stream id, is ignored here)
 rows.sort(key=lambda r: r[1])
 adam = [k for k, nm in names.items() if ("FusedOptimizerTensorListMetadata" in nm or "adam_pack_kernel" in nm)]  # the fused Adam only (other multi-tensor ops exist)
 ad = [r for r in rows if r[0] in adam]

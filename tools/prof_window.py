@@ -12,7 +12,7 @@ with gzip.open(path, "rt") as f:
     for _ in range(n):
         k, nm = f.readline().rstrip("\n").split("\t", 1)
         names[int(k)] = nm
-    rows = [tuple(int(v) for v in line.split(",")) for line in f]
+    rows = [tuple(int(v) for v in line.split(",")[:3]) for line in f]  # (a 4th column, the stream id, is ignored here)
 t_end = max(r[2] for r in rows)
 t0 = t_end - int(window_ms * 1e6)
 agg = {}
