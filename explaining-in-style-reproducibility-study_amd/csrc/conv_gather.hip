@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
         if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES_PER_WAVE) : "memory");
         else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // everyone's pieces of stage s are visible; everyone is done with ring slot (s + 3) % RING
+        // everyone's pieces of stage s are visible; everyone is done with ring slot (s + 3) % RING.  A RAW barrier:
+        // __syncthreads() carries an s_waitcnt vmcnt(0), which drained the three stages in flight at every stage (round 5:
+        // found in the ISA; the kernel ran one DMA round trip per stage, 1.9 us, for 0.25 us of MFMA work)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         const bool more = s + 3 < nst;
         if (more) stage_setup(s_begin + s + 3);
         const char* base = smem + (s % RING) * STAGE_BYTES;
@@ -208,6 +213,199 @@ __global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
                 else if (ok) out[(long)mm * p.N + n] = acc[i][j][r];
             }
         }
+}
+
+
+// ---- round 5: the same GEMM with WHOLE-LINE staging on 8 waves.  The kernel above stages 16-channel groups: every DMA
+// instruction fetches 32 bytes from each of 32 rows, a request shape the vector-memory path serves at 15-17 B/clk/CU whatever
+// is in flight (tools/l2_feed_probe.hip), and with the ring no longer drained at every barrier that rate IS its stage time
+// (32 KiB per stage = 1.0 us for 0.25 us of MFMA work).  Here a K stage is the same 64 channels of one tap, but an operand row
+// is ONE 128-byte line in global memory and in LDS: a DMA instruction fetches 8 complete lines (33-37 B/clk/CU with 8 waves
+// issuing), 16-byte slot q of row R lives at physical slot q ^ ((R >> 1) & 7) (conv_line64.hip: an operand read of 16
+// consecutive rows and one logical slot covers all 64 banks).  Waves 0-3 stage the A rows (gather), waves 4-7 the W rows;
+// wave (wm, wn) = (wave >> 1, wave & 1) owns a 32 (m) x 64 (n) part of the 128 x 128 tile.
+constexpr int LROW = 128;                        // bytes of an operand row: 64 channels
+constexpr int LSTAGE = (GBM + GBN) * LROW;       // 32 KiB
+constexpr int LPIECES = 4;                       // DMA instructions per wave and stage (8 rows x 128 B each)
+
+__device__ __forceinline__ void lds16(bf16x8& dst, int addr) {  // (asm: the compiler must not wait for it right away)
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+__global__ __launch_bounds__(512, 1) void conv_gather_line_kernel(GatherParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (p.N + GBN - 1) / GBN;
+    const int n0 = (int)(blockIdx.x % n_tiles) * GBN;
+    int mt = (int)(blockIdx.x / n_tiles);
+    const bool phased = p.sign < 0 && p.stride == 2;  // stride-2 data gradient: rows grouped by output parity class (above)
+    int py = 0, px = 0;
+    if (phased) {
+        const int tpp = p.m_tiles >> 2;
+        const int ph = mt / tpp;
+        mt -= ph * tpp;
+        py = ph >> 1;
+        px = ph & 1;
+    }
+    const int m0 = mt * GBM;
+    const int rows = phased ? p.B * p.Hs * p.Ws : p.M;
+    const int cpt = p.C >> 6;  // stages per tap
+    const int ks = blockIdx.y;
+    const int s_begin = ks * p.stages_per_split;
+    const int s_end = min(s_begin + p.stages_per_split, phased ? (1 + py) * (1 + px) * cpt : p.stages);
+    const int nst = max(s_end - s_begin, 0);
+    const int T = p.KH * p.KH, K = T * p.C;
+
+    // ---- staging role of this lane: DMA instruction `it` of a stage = rows (wave & 3) * 32 + it * 8 + (lane >> 3) of the A
+    // panel (waves 0-3) or of the W panel (waves 4-7); physical slot lane & 7 holds logical slot (lane & 7) ^ swz(row).
+    // Everything a stage's DMA needs per lane is a byte offset computed from registers: buffer loads with an out-of-range
+    // offset for padding / missing rows (zeros in LDS), the tap and channel-chunk terms as the scalar offset.  (The first
+    // version computed 64-bit pointers per piece through branches and re-read kernel arguments from memory inside the loop:
+    // eight scalar-load round trips per stage in front of every wave's MFMAs.)
+    const bool stage_w = wave >= 4;
+    const int rbase = (wave & 3) * 32 + (lane >> 3);
+    const int Hs = __builtin_amdgcn_readfirstlane(p.Hs), Ws = __builtin_amdgcn_readfirstlane(p.Ws);
+    const int C = __builtin_amdgcn_readfirstlane(p.C), KH = __builtin_amdgcn_readfirstlane(p.KH);
+    const int pad = __builtin_amdgcn_readfirstlane(p.pad), sgn = __builtin_amdgcn_readfirstlane(p.sign);
+    const int strd = __builtin_amdgcn_readfirstlane(p.stride);
+    const int gw = phased ? Ws : p.W;
+    const int hw = phased ? Hs * Ws : p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, 0x7ffffff0, 0x00020000);
+    constexpr unsigned OOBV = 0x80000000u;
+    int r_oh[LPIECES], r_ow[LPIECES];
+    unsigned r_off[LPIECES];  // A: byte offset of (image, channel slot) or OOBV when the row is past the tile's rows; W: of (n, slot)
+#pragma unroll
+    for (int it = 0; it < LPIECES; ++it) {
+        const int row = rbase + it * 8;
+        const unsigned chan = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        r_oh[it] = r_ow[it] = 0;
+        if (stage_w) {
+            const int n = n0 + row;
+            r_off[it] = n < p.N ? ((unsigned)n * (unsigned)K + chan) * 2u : OOBV;
+        } else {
+            const int m = m0 + row;
+            if (m < rows) {
+                const int b = m / hw, q = m - b * hw;
+                r_oh[it] = q / gw;
+                r_ow[it] = q - r_oh[it] * gw;
+                r_off[it] = ((unsigned)b * (unsigned)(Hs * Ws) * (unsigned)C + chan) * 2u;
+            } else {
+                r_off[it] = OOBV;
+            }
+        }
+    }
+    int i_tap = s_begin / cpt, i_chunk = s_begin - i_tap * cpt;  // the stage the DMA stream fetches next
+    auto issue_stage = [&](int rs) {
+        int tap = i_tap, dh, dw, sh = 1;  // source pixel = (oh * sh + dh, ow * sh + dw)
+        if (phased) {  // tap = index into the class's live taps; (2q + py + 1 - kh) / 2 = q + (py && kh == 0)
+            const int nkw = 1 + px;
+            const int a = tap / nkw, bq = tap - a * nkw;
+            const int kh = py ? 2 * a : 1, kw = px ? 2 * bq : 1;
+            dh = (py && kh == 0) ? 1 : 0;
+            dw = (px && kw == 0) ? 1 : 0;
+            tap = kh * 3 + kw;
+        } else {
+            const int kh = KH == 3 ? (tap >= 6 ? 2 : tap >= 3 ? 1 : 0) : 0, kw = tap - kh * KH;
+            if (sgn > 0) {
+                sh = strd;
+                dh = kh - pad;
+                dw = kw - pad;
+            } else {
+                dh = pad - kh;
+                dw = pad - kw;
+            }
+        }
+        const int dst = rs * LSTAGE + (stage_w ? GBM * LROW : 0) + (wave & 3) * 32 * LROW;
+        if (stage_w) {
+            const unsigned soff = (unsigned)(tap * C + (i_chunk << 6)) * 2u;
+#pragma unroll
+            for (int it = 0; it < LPIECES; ++it)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_ptr)(smem + dst + it * 8 * LROW), 16, r_off[it], soff, 0, 0);
+        } else {
+            const unsigned soff = (unsigned)(i_chunk << 6) * 2u;
+#pragma unroll
+            for (int it = 0; it < LPIECES; ++it) {
+                const int ih = r_oh[it] * sh + dh, iw = r_ow[it] * sh + dw;
+                const bool ok = r_off[it] != OOBV && (unsigned)ih < (unsigned)Hs && (unsigned)iw < (unsigned)Ws;
+                const unsigned v = ok ? r_off[it] + (unsigned)((ih * Ws + iw) * C) * 2u : OOBV;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_ptr)(smem + dst + it * 8 * LROW), 16, v, soff, 0, 0);
+            }
+        }
+        if (++i_chunk == cpt) {
+            i_chunk = 0;
+            ++i_tap;
+        }
+    };
+
+    // ---- MFMA operand rows: A rows wm * 32 + li, W rows wn * 64 + j * 32 + li; (row >> 1) & 7 == (li >> 1) & 7 for all of them
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    const int s0 = lk ^ ((li >> 1) & 7);  // logical slot 2 g + lk of k-step g sits at physical slot (2 g) ^ s0
+    const int lds0 = (int)(unsigned)(uintptr_t)(lds_void_ptr)smem;  // LDS byte address of the dynamic allocation
+    const int a_off = lds0 + (wm * 32 + li) * LROW;
+    const int b_off = lds0 + GBM * LROW + (wn * 64 + li) * LROW;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // prologue: three stages in flight
+    for (int s = 0; s < 3 && s < nst; ++s) issue_stage(s);
+    for (int s = 0; s < nst; ++s) {
+        // stage s must have landed; loads complete in order, so allowing the LPIECES DMA instructions of each younger stage in
+        // flight proves it
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPIECES) : "memory");
+        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // (raw: __syncthreads() would drain the ring)
+        asm volatile("" ::: "memory");
+        if (s + 3 < nst) issue_stage((s + 3) % RING);
+        // operand reads run one 16-channel group ahead of the MFMAs (the per-group read -> wait -> MFMA chain of the kernel
+        // above exposes the LDS latency four times per stage: with one or two waves per SIMD that chain WAS the stage time)
+        const int base = (s % RING) * LSTAGE;
+        bf16x8 av[2], bv[2][2];
+        lds16(av[0], base + a_off + (s0 << 4));
+        lds16(bv[0][0], base + b_off + (s0 << 4));
+        lds16(bv[0][1], base + b_off + 32 * LROW + (s0 << 4));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+                const int so = ((2 * (g + 1)) ^ s0) << 4;
+                lds16(av[(g + 1) & 1], base + a_off + so);
+                lds16(bv[(g + 1) & 1][0], base + b_off + so);
+                lds16(bv[(g + 1) & 1][1], base + b_off + 32 * LROW + so);
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(av[g & 1]), "+v"(bv[g & 1][0]), "+v"(bv[g & 1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[g & 1]), "+v"(bv[g & 1][0]), "+v"(bv[g & 1][1]));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[g & 1], bv[g & 1][j], acc[j], 0, 0, 0);
+        }
+    }
+
+    // raw fp32 partials: D[row = m][col = n], col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* out = p.partial + (long)ks * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int mm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const bool ok = mm < rows && n < p.N;
+            if (phased && ok) {  // class row -> natural (b, oh, ow) order of the partial buffer
+                const int bb = mm / hw, qq = mm - bb * hw;
+                const int qh = qq / p.Ws, qw = qq - qh * p.Ws;
+                mm = (bb * p.H + 2 * qh + py) * p.W + 2 * qw + px;
+            }
+            if (ok && p.y) p.y[(long)mm * p.N + n] = f2bf_rne(acc[j][r]);
+            else if (ok) out[(long)mm * p.N + n] = acc[j][r];
+        }
+    }
 }
 
 }  // namespace
@@ -272,8 +470,13 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_line_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RING * LSTAGE);
+        if (e != hipSuccess) return (int)e;
         attr = true;
     }
+    const char* le = getenv("STYLEX_GATHER_LINE");  // read per launch: A/B tests toggle it in-process
+    const bool line = !(le && le[0] == '0');
     GatherParams g;
     g.x = reinterpret_cast<const unsigned short*>(p.a);
     g.w = reinterpret_cast<const unsigned short*>(p.w);
@@ -298,8 +501,9 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
     g.ksplit = ks;
     g.stages_per_split = per;
     const long tiles = (long)g.m_tiles * ((p.N + GBN - 1) / GBN);
-    stylex_note_kernel("conv_gather_kernel");
-    hipLaunchKernelGGL(conv_gather_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), SMEM_BYTES, s, g);
+    stylex_note_kernel(line ? "conv_gather_line_kernel" : "conv_gather_kernel");
+    if (line) hipLaunchKernelGGL(conv_gather_line_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(512), RING * LSTAGE, s, g);
+    else hipLaunchKernelGGL(conv_gather_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), SMEM_BYTES, s, g);
     p.ksplit = direct ? 0 : ks;  // 0: output complete, the caller skips the split-K epilogue
     p.kt_per_split = per;
     p.partial = (float*)workspace;

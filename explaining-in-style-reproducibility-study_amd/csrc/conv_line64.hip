@@ -155,7 +155,11 @@ __global__ __launch_bounds__(512) void conv3x3_line64_kernel(ConvKParams p, Styl
         // tile k-1 (>= 4 per wave), so vmcnt(4) proves it without waiting for those stores.
         if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __syncthreads();  // everyone's pieces of halo(k) are visible; everyone is done reading the other stage
+        // everyone's pieces of halo(k) are visible; everyone is done reading the other stage.  A RAW barrier (round 5):
+        // __syncthreads() carries an s_waitcnt vmcnt(0) of its own, i.e. it waited for the stores of tile k-1 after all
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         int b, y0, x0;
         decode(k, b, y0, x0);
         const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((((b * H + y0 + wave) * W + x0) * 64) * 2));

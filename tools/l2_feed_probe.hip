@@ -5,6 +5,8 @@
 //   mode 1: VGPR loads buffer_load_dwordx4 into registers (discarded), same addresses, same depth
 //   mode 2: LDS-DMA of 64-byte half lines (the 32-channel stages of the stride-2 kernels: 4 lanes per 64-byte row)
 //   mode 3: LDS-DMA of 32-byte quarter lines (the 16-channel groups of conv_gather.hip / conv_halo_dma.hip: 2 lanes per row)
+//   mode 4: LDS-DMA of whole lines that lie `stride` bytes apart (operand rows of a GEMM: 8 rows per instruction; all blocks of an
+//           XCD read the SAME window, as the blocks of one weight tile do) — does the L2 serve some strides worse than others?
 // and prints bytes / clock / CU at the measured kernel time (clock = s_memrealtime-free: elapsed ms x 2.1 GHz nominal AND
 // wall-clock GB/s, so the figure can be re-based on the real clock).
 // build: hipcc -O3 --offload-arch=gfx950 tools/l2_feed_probe.hip -o /tmp/l2p && /tmp/l2p [blocks_per_cu=1] [waves=8] [depth=8]
@@ -16,16 +18,17 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, int DEPTH>
-__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long window, int iters, unsigned* sink) {
+__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long window, int iters, unsigned* sink, unsigned stride = 128) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, 0x7fffffff, 0x00020000);
     // a wave instruction covers 1 KiB: 8 lines of 128 B (mode 0 / 1) or 16 half-lines of 64 B out of 16 different lines (mode 2)
     const unsigned lane_off = MODE == 2   ? (unsigned)(lane >> 2) * 128u + (unsigned)(lane & 3) * 16u
                               : MODE == 3 ? (unsigned)(lane >> 1) * 128u + (unsigned)(lane & 1) * 16u
+                              : MODE == 4 ? (unsigned)(lane >> 3) * stride + (unsigned)(lane & 7) * 16u
                                           : (unsigned)lane * 16u;
-    const unsigned step = MODE == 2 ? 2048u : MODE == 3 ? 4096u : 1024u;  // bytes of address space per instruction
-    const unsigned base = (unsigned)(((long)blockIdx.x * window) & 0x3fffffff);
+    const unsigned step = MODE == 2 ? 2048u : MODE == 3 ? 4096u : MODE == 4 ? 8u * stride : 1024u;  // address space per instruction
+    const unsigned base = MODE == 4 ? 0u : (unsigned)(((long)blockIdx.x * window) & 0x3fffffff);  // mode 4: one shared window
     unsigned acc = 0;
     unsigned off = (unsigned)wave * step;
     for (int it = 0; it < iters; ++it) {
@@ -48,17 +51,17 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, long 
 }
 
 template <int MODE, int DEPTH>
-static void run(const char* name, const char* src, long window, int blocks, int waves, unsigned* sink) {
+static void run(const char* name, const char* src, long window, int blocks, int waves, unsigned* sink, unsigned stride = 128) {
     const int iters = 2000 / DEPTH * 8;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     const size_t sm = (size_t)waves * DEPTH * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(probe<MODE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(blocks), dim3(waves * 64), sm, 0, src, window, 10, sink);
+    hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(blocks), dim3(waves * 64), sm, 0, src, window, 10, sink, stride);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(blocks), dim3(waves * 64), sm, 0, src, window, iters, sink);
+    hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(blocks), dim3(waves * 64), sm, 0, src, window, iters, sink, stride);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0;
@@ -86,6 +89,14 @@ int main(int argc, char** argv) {
     run<2, 16>("LDS-DMA 64-byte half lines", src, window, blocks, waves, sink);
     run<3, 8>("LDS-DMA 32-byte quarter lines", src, window, blocks, waves, sink);
     run<3, 16>("LDS-DMA 32-byte quarter lines", src, window, blocks, waves, sink);
+    {  // shared 2 MiB window read as rows `stride` apart: contiguous, pixel rows of a 512-channel tensor, weight rows [N][9][512]
+        const unsigned strides[] = {128, 1024, 1024 + 128, 9216, 9216 + 128, 4608, 4608 + 128, 2048, 4096};
+        for (unsigned st : strides) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "LDS-DMA lines %u B apart (shared)", st);
+            run<4, 8>(nm, src, 2 << 20, blocks, waves, sink, st);
+        }
+    }
     run<1, 4>("VGPR loads whole lines", src, window, blocks, waves, sink);
     run<1, 8>("VGPR loads whole lines", src, window, blocks, waves, sink);
     run<1, 16>("VGPR loads whole lines", src, window, blocks, waves, sink);
