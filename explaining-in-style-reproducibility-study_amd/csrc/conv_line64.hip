@@ -25,6 +25,11 @@
 
 #include "stylex_internal.h"
 
+// cache policy of the output stores (buffer_store aux bits; 2 = nt, streaming: tools/bench_s2d_dgrad.py A/B, DESIGN §3 "Round 5")
+#ifndef LN_STORE_AUX
+#define LN_STORE_AUX 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(512) void conv3x3_line64_kernel(ConvKParams p, Styl
             }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {  // register kk: pixels 8kk .. 8kk + 7
-            __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + kk * (8 * 64 * 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + kk * (8 * 64 * 2), LN_STORE_AUX);
             asm volatile("s_nop 1" : "+v"(R[kk]) : : "memory");  // VMEM store data hazard (see conv_pipe.hip)
         }
     }

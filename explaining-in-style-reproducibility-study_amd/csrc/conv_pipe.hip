@@ -28,6 +28,11 @@
 
 #include "stylex_internal.h"
 
+// cache policy of the output stores (buffer_store aux bits; 2 = nt, streaming: tools/bench_s2d_dgrad.py A/B, DESIGN §3 "Round 5")
+#ifndef PIPE_STORE_AUX
+#define PIPE_STORE_AUX 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(ConvKParams p, Pip
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {  // register k = 2 * (pixel bit 4) + (pixel bit 3): pixels 8k .. 8k + 7
                     const unsigned voff = (row_ok && x0 + 8 * k + (lane & 7) < W) ? lane_off : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(R[k], ry, voff, soff + k * pixb8, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(R[k], ry, voff, soff + k * pixb8, PIPE_STORE_AUX);
                     // A VMEM store of more than 8 bytes needs a wait state before a VALU write of its data registers.
                     // hipcc does not pad it for a buffer store with an SGPR soffset (LLVM's rule ties the hazard to an
                     // immediate soffset), yet gfx950 showed it: `buffer_store_dwordx4 v[172:175]` directly followed by

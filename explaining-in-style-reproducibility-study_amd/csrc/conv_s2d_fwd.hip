@@ -29,6 +29,11 @@
 
 #include "stylex_internal.h"
 
+// cache policy of the output stores (buffer_store aux bits; 2 = nt, streaming: tools/bench_s2d_dgrad.py A/B, DESIGN §3 "Round 5")
+#ifndef SF_STORE_AUX
+#define SF_STORE_AUX 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_s2d_fwd_kernel(ConvKParams p,
                 }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + (unsigned)kk * kk_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(R[kk], ry, lane_off, soff + (unsigned)kk * kk_off, SF_STORE_AUX);
                     asm volatile("s_nop 1" : "+v"(R[kk]) : : "memory");  // VMEM store data hazard (conv_pipe.hip)
                 }
             }
