@@ -15,6 +15,10 @@
 // row, as in conv_halo_dma.hip).  Launches that cannot fill the chip are split along K; every launch writes fp32
 // partials [ksplit][M][N] and the existing deterministic split-K epilogue kernel (conv_igemm.hip) applies the fused
 // epilogue (scales, bias, noise, residual, gate, activation) and the bf16 rounding.
+//
+// Round 5: conv_gather_line_kernel (below) is the kernel that runs — same tile, split-K plan and partial layout, operand rows
+// staged as whole 128-byte lines on 8 waves and, above all, a DMA issue path without branches, 64-bit pointer arithmetic or
+// kernel-argument reloads inside the loop; conv_gather_kernel stays behind STYLEX_GATHER_LINE=0 for A/B runs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

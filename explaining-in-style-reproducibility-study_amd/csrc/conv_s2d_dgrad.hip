@@ -9,18 +9,23 @@
 //
 // Why a kernel of its own.  conv3x3_halo_dma_kernel<2, true> gives every 64-channel tile of the 4C output channels its own
 // block: the gradient halo is staged once per SUB-POSITION for 1-4 taps of MFMA work (8-32 MFMAs per wave between two
-// vmcnt(0) + barrier drains; round-4 counters: matrix pipe 24-31 % busy).  Here a block owns a 64-channel group in all four
-// sub-positions (256 output channels) over an 8 x 32 pixel tile, so one staged halo feeds all nine (sub-position, tap)
-// pairs: 55 KB of DMA per 288 MFMAs instead of 46-70 KB per 64-256.  One 8-wave block per CU walks a static tile list; the
-// K loop (gz channels, 32 per stage) streams through two-deep LDS rings across tile boundaries, the DMA of the next stage is
-// issued two pieces per step behind the first MFMAs of a stage, one barrier per stage in front of its last MFMAs
-// (conv_wgrad_pipe.hip's recipe).  A wave owns two pixel rows x one 32-channel half of the group x all four sub-positions
-// (acc[2][4] = 128 registers), keeps the six distinct halo fragments of a 16-channel k-step in registers and reads three
-// weight fragments per six MFMAs; all eight waves run the same instruction stream.  LDS rows are 64 bytes (32 channels);
-// 16-byte slot q of row R lives at slot q ^ ((R >> 2) & 3), which spreads every lane group of a ds_read_b128 over all 64
-// banks.  Epilogue: conv_line64.hip's register transpose; a store writes the 64-byte channel runs of 16 pixels.
-// Results are bit-identical to conv3x3_halo_dma_kernel<2, true>'s (same operands, same K order); STYLEX_S2D_DGRAD=0 selects
-// that kernel (A/B: tools/bench_s2d_dgrad.py).
+// vmcnt(0) + barrier drains; round-4 counters: matrix pipe 24-31 % busy).  Here a block owns a channel group in all four
+// sub-positions over a 256-pixel tile (8 x 32, or 16 x 16 for 16-pixel-wide images), so one staged halo feeds all nine
+// (sub-position, tap) pairs.  Blocks: 4 waves and a 32-channel group (128 output channels; 75 KB of LDS, two blocks per CU —
+// the default) or 8 waves and a 64-channel group (256 output channels, one block per CU: STYLEX_S2D_DGRAD_TILE=1).  A
+// persistent block walks a static tile list; the K loop (gz channels, 32 per stage = 19 KB of halo + 18 / 36 KB of the nine
+// weight slots) streams through two-deep LDS rings across tile boundaries; the whole DMA of the next stage is issued behind
+// the FIRST MFMAs of a stage, one barrier per stage in front of its last MFMAs (conv_wgrad_pipe.hip's recipe).  Vector-memory
+// operations complete in issue order, so at a tile's end the DMA of the stage AFTER the next goes out ahead of the tile's 16
+// stores and the following barrier waits with vmcnt(16) — everything but the stores.  A wave owns two 32-pixel fragments x
+// one 32-channel group x all four sub-positions (acc[2][4] = 128 registers), keeps the six distinct halo fragments of a
+// 16-channel k-step in registers and reads three weight fragments per six MFMAs; every wave runs the same instruction stream
+// (a per-quartet split of the nine pairs made the accumulators a two-way phi: 705 spilled registers).  LDS rows are 64 bytes
+// (32 channels); 16-byte slot q of row R lives at slot q ^ ((R >> 2) & 3), which spreads every lane group of a ds_read_b128
+// over all 64 banks.  Epilogue: conv_line64.hip's register transpose; a store writes the 64-byte channel runs of 16 pixels.
+// Results are bit-identical to conv3x3_halo_dma_kernel<2, true>'s where that kernel ran (same operands, same K order);
+// STYLEX_S2D_DGRAD=0 selects the old kernels (A/B: tools/bench_s2d_dgrad.py; ablation builds: SD_PROBE_NO_STORE /
+// SD_PROBE_NO_HALO / SD_STAGGER, DESIGN §3 "Round 5").
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

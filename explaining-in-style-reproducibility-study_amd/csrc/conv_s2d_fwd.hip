@@ -11,8 +11,10 @@
 // Why a kernel of its own.  conv3x3_halo_dma_kernel<2, true> runs the four sub-positions as four chunk loops of 16 channels
 // with a vmcnt(0) + barrier drain per 8-32 MFMAs per wave and a 64-channel output tile per block (two blocks per CU);
 // 16-pixel-wide images (512 -> 512 @32^2 -> 16^2) fall to the register-staged kernel at 0.26-0.45 PF.  Here: persistent
-// blocks walk a static tile list; a tile = 256 pixels x 128 channels in a 4-wave block, two blocks per CU (default), or
-// 256 x 256 / 512 x 128 in an 8-wave block; 8 accumulator tiles per wave either way.  The K loop is a sequence of PHASES — [residual 1x1 segment,] s0 {(0,0)}, s1 {(0,-1), (0,0)}, s2 {(-1,0), (0,0)},
+// blocks walk a static tile list; a tile = 256 pixels x 128 channels in a 4-wave block, two blocks per CU (default), the
+// same tile on 8 waves with a three-deep ring for launches of at most one tile per CU, 256 x 64 for N = 64, or 256 x 256 /
+// 512 x 128 in an 8-wave block (STYLEX_S2D_FWD_TILE); 8 (4) accumulator tiles per wave.  The K loop is a sequence of PHASES
+// — [residual 1x1 segment,] s0 {(0,0)}, s1 {(0,-1), (0,0)}, s2 {(-1,0), (0,0)},
 // s3 {(-1,-1), (-1,0)}, s3 {(0,-1), (0,0)} — each a run of 32-channel stages: the phase's input halo (offsets -1 / 0 only:
 // top row + left column) and its one or two tap slots of weights stream through two-deep LDS-DMA rings that are never
 // drained, across phase and tile boundaries; the next stage's DMA is issued behind the first MFMAs of a stage, one barrier
