@@ -76,7 +76,7 @@ def main():
             y = fwd()
             dy = torch.randn_like(y)
             bwd = lambda: hb.conv2d_bwd_data(dy, None, tuple(x.shape), 1, 1, prec, packed=wb2, w_shape=ws, s2d_c=c)
-            wgr = lambda: hb.conv2d_bwd_weight(x, dy, ws, 1, 1, prec, s2d_c=c)
+            wgr = lambda: hb.conv2d_bwd_weight_s2d(x, dy, (n, c, 3, 3), prec)  # the product's call: folded layout in one launch pair
         else:
             x = torch.randn(a.batch, cp, res, res, device=dev).to(adt).contiguous(memory_format=torch.channels_last)
             fwd = lambda: hb.conv2d_fwd(x, w, s, p, prec)
