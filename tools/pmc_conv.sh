@@ -20,7 +20,7 @@ def load(d):
     return agg,cnt,dur
 agg,cnt,_=load("/tmp/pmc1")
 for k,v in agg.items():
-    if "halo" in k or "igemm" in k or "wgrad" in k or "pipe" in k or "gather" in k or "line64" in k:
+    if "halo" in k or "igemm" in k or "wgrad" in k or "pipe" in k or "gather" in k or "line64" in k or "s2d" in k:
         n=max(cnt[k],1); w=v["SQ_WAVES"]/n
         wc=v["SQ_WAVE_CYCLES"]/n
         print("%-48s disp=%d waves=%d  cyc/wave=%.0f  wait=%.0f%% inst_stall=%.0f%% active=%.0f%%  mfma_cyc/wave=%.0f  lds_conf/lds=%.2f" % (
@@ -30,7 +30,7 @@ try:
     agg,cnt,dur=load("/tmp/pmc2")
     print(sorted(set(c for v in agg.values() for c in v)))
     for k,v in agg.items():
-        if "halo" in k or "igemm" in k or "wgrad" in k or "pipe" in k or "gather" in k or "line64" in k:
+        if "halo" in k or "igemm" in k or "wgrad" in k or "pipe" in k or "gather" in k or "line64" in k or "s2d" in k:
             n=max(cnt[k],1)
             print("%-48s disp=%d  gui_active/disp=%.0f  dur_us=%.1f  clock_GHz=%.2f  valu=%.0f lds=%.0f salu=%.0f vmem=%.0f lds_wait=%.0f" % (
                 k, n, v["GRBM_GUI_ACTIVE"]/n, dur[k]/n/1e3, v["GRBM_GUI_ACTIVE"]/max(dur[k],1), v["SQ_INSTS_VALU"]/n, v["SQ_INSTS_LDS"]/n, v["SQ_INSTS_SALU"]/n, v["SQ_INSTS_VMEM"]/n, v["SQ_WAIT_INST_LDS"]/n))
