@@ -82,6 +82,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvKParams p) {
     const int m_end = (int)min((long)p.M, (long)m_begin + p.split_len);
     const int nk = (m_end - m_begin + BKP - 1) / BKP;
     const int hw = p.Ho * p.Wo;
+    // pixel -> (b, oh, ow): two unsigned divisions per staged 16-byte slot were most of this kernel's instructions (PMC, round 5:
+    // 25 VALU instructions per MFMA at 8x8 px); every StylEx grid is a power of two, so they are shifts behind a uniform branch
+    const bool pow2 = (hw & (hw - 1)) == 0 && (p.Wo & (p.Wo - 1)) == 0;
+    const int sh_hw = __builtin_ctz((unsigned)hw), sh_w = __builtin_ctz((unsigned)p.Wo);
 
     constexpr int A_SLOTS = BNn / 8, B_SLOTS = BC / 8;
     constexpr int A_PER = BKP * A_SLOTS / 256, B_PER = BKP * B_SLOTS / 256;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvKParams p) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (m < m_end && n < N) {
                 v = *reinterpret_cast<const uint4*>(dy + (long)m * N + n);
-                if (p.a2_scale) v = scaled(v, p.a2_scale + (long)((unsigned)m / (unsigned)hw) * N + n);
+                if (p.a2_scale) v = scaled(v, p.a2_scale + (long)(pow2 ? (unsigned)m >> sh_hw : (unsigned)m / (unsigned)hw) * N + n);
             }
             ra[j] = v;
         }
@@ -132,9 +136,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvKParams p) {
             }
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (ok) {
-                const int b = (int)((unsigned)m / (unsigned)hw);
+                int b, oh;
+                if (pow2) {
+                    b = (int)((unsigned)m >> sh_hw);
+                    oh = (int)(((unsigned)m & (unsigned)(hw - 1)) >> sh_w);
+                } else {
+                    b = (int)((unsigned)m / (unsigned)hw);
+                    oh = (int)((unsigned)(m - b * hw) / (unsigned)p.Wo);
+                }
                 const int r = m - b * hw;
-                const int oh = (int)((unsigned)r / (unsigned)p.Wo), ow = r - oh * p.Wo;
+                const int ow = r - oh * p.Wo;
                 const int ih = oh * p.stride + th - p.pad, iw = ow * p.stride + tw - p.pad;
                 if (ih >= 0 && ih < p.Hi && iw >= 0 && iw < p.Wi) {
                     v = *reinterpret_cast<const uint4*>(xs + (((long)b * p.Hi + ih) * p.Wi + iw) * C + c);
