@@ -251,14 +251,22 @@ def _ptr(t):
 
 
 class RawGrad:
-    """A gradient tensor the autograd engine is holding, named by address and shape only: a reference to the tensor itself
-    would keep AccumulateGrad from stealing it (it clones a gradient somebody else still refers to).  Accepted as
-    accumulate_into / accumulate_bias_into of conv2d_bwd_weight / conv2d_bwd_weight_s2d (ops._gacc_*)."""
-    __slots__ = ("ptr", "shape")
+    """A gradient tensor the autograd engine is holding, named WITHOUT a reference: a strong reference would keep
+    AccumulateGrad from stealing it (it clones a gradient somebody else still refers to).  A weak reference tells whether the
+    tensor still exists (the engine may have replaced it by an out-of-place sum with another node's gradient): `alive()`
+    must be checked right before use; the address is read from the live tensor then.  Accepted as accumulate_into /
+    accumulate_bias_into of conv2d_bwd_weight / conv2d_bwd_weight_s2d (ops._gacc_*)."""
+    __slots__ = ("ref", "ptr", "shape")
 
     def __init__(self, t):
+        import weakref
+
         assert t.dtype == torch.float32 and t.is_contiguous()
-        self.ptr, self.shape = t.data_ptr(), tuple(t.shape)
+        self.ref, self.ptr, self.shape = weakref.ref(t), t.data_ptr(), tuple(t.shape)
+
+    def alive(self):
+        t = self.ref()
+        return t is not None and t.data_ptr() == self.ptr and tuple(t.shape) == self.shape
 
     def data_ptr(self):
         return self.ptr

@@ -1000,8 +1000,8 @@ class _DBlockFast(torch.autograd.Function):
 # Gradient accumulation inside the weight-gradient launches (round 5).  A parameter used by several fast-path nodes of ONE
 # backward pass (the encoder of a generator phase: E(x) and E(G(x)), reference stylex_train.py:1383-1395) used to hand the
 # autograd engine one gradient tensor per use, which the engine sums with an add launch per parameter (117 per step).  Now
-# the first node to run hands the engine its tensor and notes its ADDRESS (hb.RawGrad: a reference would keep AccumulateGrad
-# from stealing the tensor); a later node of the same graph task adds into that tensor in its reduce launch
+# the first node to run hands the engine its tensor and notes it through a WEAK reference (hb.RawGrad: a strong one would keep
+# AccumulateGrad from stealing the tensor; the weak one also tells if the engine dropped it for an out-of-place sum); a later node of the same graph task adds into that tensor in its reduce launch
 # (stylex_conv2d_bwd_weight_ex, accumulate) and returns None.  The engine keeps the first tensor alive, unmodified, until
 # the parameter's AccumulateGrad node runs — after every use, by its dependency count.  Same two rounded fp32 operations as
 # the engine's add: bit-identical gradients (tests/test_hip_parity.py::test_twice_used_block_accumulates_in_the_reduce_launch).
@@ -1020,7 +1020,11 @@ def _gacc_get(w, tag=""):
     if task != _GACC_TASK[0]:
         _GACC.clear()
         _GACC_TASK[0] = task
-    return _GACC.get((w.data_ptr(), tag))
+    slot = _GACC.get((w.data_ptr(), tag))
+    if slot is not None and not slot.alive():  # the engine no longer holds that tensor (replaced by an out-of-place sum)
+        del _GACC[(w.data_ptr(), tag)]
+        return None
+    return slot
 
 
 def _gacc_put(w, g, tag=""):
