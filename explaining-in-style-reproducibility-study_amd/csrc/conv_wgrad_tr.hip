@@ -19,6 +19,7 @@
 // blocks each using 8 of 64 MFMA columns.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "stylex_internal.h"
 
@@ -231,6 +232,176 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvKParams p) {
     }
 }
 
+// ---- round 5: the 128 x 128 tile of the kernel above with LDS-DMA staging (conv_gather_line_kernel's lesson: at <= 8 px the
+// register-staged version spends 25 VALU instructions per MFMA on addresses, bounds and ds_writes — PMC: matrix pipe 10 % busy).
+// Same tile, taps-per-block, partial layout and LDS image (pixel-major 32-channel panels of 64-byte rows, read with
+// ds_read_b64_tr_b16); 8 waves; a K stage = 64 pixels = 32 DMA instructions of 16 rows x 64 B (waves 0-3: the dy panels,
+// 4-7: the x panels), four-stage ring with three stages in flight, counted vmcnt + raw barrier; everything a DMA needs per
+// lane is a 32-bit offset in a register (dy: constant, the stage term is the scalar offset; x: pixel decode by shifts,
+// out-of-range offset for padding).  Conditions: bf16, stride 1, power-of-two grid, N and C multiples of 128, no scales.
+constexpr int DSTAGES = 4, DPIECES = 4;
+constexpr int DSTAGE_BYTES = 8 * PANEL;
+
+struct TrOps {  // the six transpose reads of one 16-pixel k-step: dy fragment (2 x b64), two x fragments
+    s16x4 a[2];
+    s16x4 b[2][2];
+};
+template <int OFF>
+__device__ __forceinline__ void tr_asm(s16x4& dst, int addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int KS>
+__device__ __forceinline__ void tr_issue(TrOps& o, int a_addr, int b_addr) {
+    tr_asm<KS * 16 * 64>(o.a[0], a_addr);
+    tr_asm<KS * 16 * 64 + 4 * 64>(o.a[1], a_addr);
+    tr_asm<KS * 16 * 64>(o.b[0][0], b_addr);
+    tr_asm<KS * 16 * 64 + 4 * 64>(o.b[0][1], b_addr);
+    tr_asm<PANEL + KS * 16 * 64>(o.b[1][0], b_addr);
+    tr_asm<PANEL + KS * 16 * 64 + 4 * 64>(o.b[1][1], b_addr);
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(TrOps& o) {  // all but the N newest LDS reads have landed
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(o.a[0]), "+v"(o.a[1]), "+v"(o.b[0][0]), "+v"(o.b[0][1]), "+v"(o.b[1][0]), "+v"(o.b[1][1])
+                 : "n"(N));
+}
+__device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__global__ __launch_bounds__(512, 1) void conv_wgrad_tr_dma_kernel(ConvKParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.KH * p.KW;
+    const int N = __builtin_amdgcn_readfirstlane(p.N), C = __builtin_amdgcn_readfirstlane(p.Ck);
+    const int n_tiles = N >> 7, c_tiles = C >> 7;
+    const int per_split = n_tiles * c_tiles * T;
+    const int bid = blockIdx.x;
+    const int tile = bid % per_split, split = bid / per_split;
+    const int tap = tile % T;
+    const int n0 = ((tile / T) / c_tiles) << 7;
+    const int c0 = ((tile / T) % c_tiles) << 7;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int m_begin = (int)((long)split * p.split_len);
+    const int m_end = (int)min((long)p.M, (long)m_begin + p.split_len);
+    const int nk = (m_end - m_begin + BKP - 1) / BKP;
+    const int Wo = __builtin_amdgcn_readfirstlane(p.Wo), hw = __builtin_amdgcn_readfirstlane(p.Ho * p.Wo);
+    const int Hi = __builtin_amdgcn_readfirstlane(p.Hi), Wi = __builtin_amdgcn_readfirstlane(p.Wi);
+    const int sh_hw = __builtin_ctz((unsigned)hw), sh_w = __builtin_ctz((unsigned)Wo);
+    const int dh = kh - p.pad, dw = kw - p.pad;
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a2), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 0x7ffffff0, 0x00020000);
+    constexpr unsigned OOBV = 0x80000000u;
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+    // ---- staging: DMA instruction `it` of a stage = pixel rows it * 16 + (lane >> 2) of this wave's panel, slot lane & 3
+    const bool stage_x = wave >= 4;
+    const int panel = wave & 3;
+    const int chan = panel * 32 + (lane & 3) * 8;
+    int mrow[DPIECES];
+    unsigned a_off[DPIECES];
+#pragma unroll
+    for (int it = 0; it < DPIECES; ++it) {
+        mrow[it] = m_begin + it * 16 + (lane >> 2);
+        a_off[it] = ((unsigned)mrow[it] * (unsigned)N + (unsigned)(n0 + chan)) * 2u;
+    }
+    int i_kt = 0;  // the K-tile the DMA stream fetches next
+    auto issue_stage = [&](int rs) {
+        const int dst = rs * DSTAGE_BYTES + ((stage_x ? 4 : 0) + panel) * PANEL;
+        const int mshift = i_kt * BKP;
+        if (!stage_x) {
+            const unsigned soff = (unsigned)mshift * (unsigned)N * 2u;
+#pragma unroll
+            for (int it = 0; it < DPIECES; ++it) {
+                const unsigned v = mrow[it] + mshift < m_end ? a_off[it] : OOBV;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_ptr)(smem + dst + it * 1024), 16, v, soff, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < DPIECES; ++it) {
+                const int m = mrow[it] + mshift;
+                const int b = (int)((unsigned)m >> sh_hw), r = m & (hw - 1);
+                const int ih = (r >> sh_w) + dh, iw = (r & (Wo - 1)) + dw;
+                const bool ok = m < m_end && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+                const unsigned v = ok ? ((unsigned)((b * Hi + ih) * Wi + iw) * (unsigned)C + (unsigned)(c0 + chan)) * 2u : OOBV;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_ptr)(smem + dst + it * 1024), 16, v, 0u, 0, 0);
+            }
+        }
+        ++i_kt;
+    };
+
+    // ---- MFMA roles: wave (wn, wc) = (wave >> 1, wave & 1): dy panel wn (32 n) x x panels 2 wc, 2 wc + 1 (64 c)
+    const int wn = wave >> 1, wc = wave & 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int lane_off = ((g >> 1) * 8 + (i16 >> 2)) * 64 + ((g & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int lds0 = (int)(unsigned)(uintptr_t)(lds_void_ptr)smem;  // LDS byte address of the dynamic allocation
+
+    for (int s = 0; s < 3 && s < nk; ++s) issue_stage(s);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPIECES) : "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // (raw: __syncthreads() would drain the ring)
+        asm volatile("" ::: "memory");
+        if (kt + 3 < nk) issue_stage((kt + 3) % DSTAGES);
+        // operand reads as asm (hipcc puts an s_waitcnt vmcnt(0) in front of every LDS read it can see behind a load-to-LDS,
+        // which would drain the ring), one k-step ahead of the MFMAs
+        const int a_addr = lds0 + (kt % DSTAGES) * DSTAGE_BYTES + wn * PANEL + lane_off;
+        const int b_addr = lds0 + (kt % DSTAGES) * DSTAGE_BYTES + (4 + wc * 2) * PANEL + lane_off;
+        TrOps o[2];
+        tr_issue<0>(o[0], a_addr, b_addr);
+#pragma unroll
+        for (int ks = 0; ks < BKP / 16; ++ks) {
+            if (ks + 1 < BKP / 16) {
+                if (ks == 0) tr_issue<1>(o[1], a_addr, b_addr);
+                if (ks == 1) tr_issue<2>(o[0], a_addr, b_addr);
+                if (ks == 2) tr_issue<3>(o[1], a_addr, b_addr);
+                tr_wait<6>(o[ks & 1]);
+            } else {
+                tr_wait<0>(o[ks & 1]);
+            }
+            const bf16x8 av = cat8(o[ks & 1].a[0], o[ks & 1].a[1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, cat8(o[ks & 1].b[0][0], o[ks & 1].b[0][1]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, cat8(o[ks & 1].b[1][0], o[ks & 1].b[1][1]), acc[1], 0, 0, 0);
+        }
+    }
+
+    // partial[split][n][tap][c]; D[i=n][j=c]: col j = lane&31, row i = (r&3)+8*(r>>2)+4*(lane>>5)
+    const int lj = lane & 31, lh = lane >> 5;
+    float* out = p.y + (long)split * N * T * C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cj = c0 + (wc * 2 + j) * 32 + lj;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((long)n * T + tap) * C + cj] = acc[j][r];
+        }
+    }
+}
+
+static bool tr_dma_applicable(const ConvKParams& p) {
+    const char* env = getenv("STYLEX_WGRAD_TR_DMA");  // read per launch: A/B tests toggle it in-process
+    if (env && env[0] == '0') return false;
+    const int hw = p.Ho * p.Wo;
+    if (!p.act_bf16 || p.a_scale || p.a2_scale || p.s2d_c || p.stride != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    if (!((p.KH == 3 && p.KW == 3 && p.pad == 1) || (p.KH == 1 && p.KW == 1 && p.pad == 0))) return false;
+    if (p.N % 128 != 0 || p.Ck % 128 != 0 || (hw & (hw - 1)) || (p.Wo & (p.Wo - 1)) || hw > 64) return false;
+    if ((long)p.M * p.N * 2 >= (1l << 31) - 16 || (long)p.M * p.Ck * 2 >= (1l << 31) - 16) return false;
+    return true;
+}
+
 template <int TN_, int TC_, bool C8>
 int launch_tr(const ConvKParams& p, int blocks, hipStream_t s) {
     auto k = conv_wgrad_tr_kernel<TN_, TC_, C8>;
@@ -272,8 +443,9 @@ void stylex_wgrad_tr_plan(const ConvKParams& p, int* mode, int* splits, long* sp
         *mode = 1;
         tiles = (long)((p.N + 63) / 64) * ((p.Ck + 63) / 64) * T;
     }
-    long want = (768 + tiles - 1) / tiles;                      // ~3 blocks per CU
-    long max_by_len = ((long)p.M + 2 * BKP - 1) / (2 * BKP);    // at least 2 K-tiles per split
+    const bool dma = *mode == 0 && tr_dma_applicable(p);         // one 8-wave block per CU: ~1.5 blocks per CU, >= 8 K-tiles each
+    long want = ((dma ? 384 : 768) + tiles - 1) / tiles;        // (else ~3 blocks per CU)
+    long max_by_len = ((long)p.M + (dma ? 8 : 2) * BKP - 1) / ((dma ? 8 : 2) * BKP);  // at least 2 K-tiles per split
     long sp = want < 1 ? 1 : want;
     if (sp > max_by_len) sp = max_by_len;
     if (sp < 1) sp = 1;
@@ -293,6 +465,18 @@ int stylex_launch_wgrad_tr(ConvKParams p, float* partial, hipStream_t s, int* sp
     *splits_out = splits;
     const int T = p.KH * p.KW;
     if (mode == 2) return launch_tr<1, 2, true>(p, ((p.N + 63) / 64) * splits, s);
+    if (mode == 0 && tr_dma_applicable(p)) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_tr_dma_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, DSTAGES * DSTAGE_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        stylex_note_kernel("conv_wgrad_tr_dma_kernel");
+        hipLaunchKernelGGL(conv_wgrad_tr_dma_kernel, dim3((p.N / 128) * (p.Ck / 128) * T * splits), dim3(512), DSTAGES * DSTAGE_BYTES, s, p);
+        return (int)hipGetLastError();
+    }
     if (mode == 0) return launch_tr<2, 2, false>(p, ((p.N + 127) / 128) * ((p.Ck + 127) / 128) * T * splits, s);
     return launch_tr<1, 1, false>(p, ((p.N + 63) / 64) * ((p.Ck + 63) / 64) * T * splits, s);
 }

@@ -23,6 +23,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     ("conv_wgrad_pipe.hip", ["conv3x3_wgrad_pipe_kernelILi2ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi32ELb0",
                              "conv3x3_wgrad_pipe_kernelILi1ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi16ELb1",
                              "conv3x3_wgrad_pipe_kernelILi1ELi16ELb0"]),
+    ("conv_wgrad_tr.hip", ["conv_wgrad_tr_dma_kernel", "conv_wgrad_tr_kernelILi2ELi2ELb0"]),
     ("conv_gather.hip", ["conv_gather_line_kernel", "conv_gather_kernel"]),
     ("conv_s2d_dgrad.hip", ["conv_s2d_dgrad_kernelILi32ELi4", "conv_s2d_dgrad_kernelILi16ELi4", "conv_s2d_dgrad_kernelILi32ELi8",
                             "conv_s2d_dgrad_kernelILi16ELi8"]),
