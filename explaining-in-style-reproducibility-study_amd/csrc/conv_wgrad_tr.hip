@@ -397,7 +397,8 @@ static bool tr_dma_applicable(const ConvKParams& p) {
     const int hw = p.Ho * p.Wo;
     if (!p.act_bf16 || p.a_scale || p.a2_scale || p.s2d_c || p.stride != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return false;
     if (!((p.KH == 3 && p.KW == 3 && p.pad == 1) || (p.KH == 1 && p.KW == 1 && p.pad == 0))) return false;
-    if (p.N % 128 != 0 || p.Ck % 128 != 0 || (hw & (hw - 1)) || (p.Wo & (p.Wo - 1)) || hw > 64) return false;
+    if (p.N % 128 != 0 || p.Ck % 128 != 0 || (hw & (hw - 1)) || (p.Wo & (p.Wo - 1))) return false;
+    if (hw > 64 && p.KH != 1) return false;  // larger 3x3 grids belong to the pipelined kernel; 1x1 convs (the residual convs) run here at any size
     if ((long)p.M * p.N * 2 >= (1l << 31) - 16 || (long)p.M * p.Ck * 2 >= (1l << 31) - 16) return false;
     return true;
 }
