@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvKParams p) {
 // ds_read_b64_tr_b16); 8 waves; a K stage = 64 pixels = 32 DMA instructions of 16 rows x 64 B (waves 0-3: the dy panels,
 // 4-7: the x panels), four-stage ring with three stages in flight, counted vmcnt + raw barrier; everything a DMA needs per
 // lane is a 32-bit offset in a register (dy: constant, the stage term is the scalar offset; x: pixel decode by shifts,
-// out-of-range offset for padding).  Conditions: bf16, stride 1, power-of-two grid, N and C multiples of 128, no scales.
+// out-of-range offset for padding).  Conditions: bf16, stride 1 (or the stride-2 3x3 down conv), power-of-two grid, N and C
+// multiples of 128, no scales.
 constexpr int DSTAGES = 4, DPIECES = 4;
 constexpr int DSTAGE_BYTES = 8 * PANEL;
 
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_dma_kernel(ConvKParams p
     const int Wo = __builtin_amdgcn_readfirstlane(p.Wo), hw = __builtin_amdgcn_readfirstlane(p.Ho * p.Wo);
     const int Hi = __builtin_amdgcn_readfirstlane(p.Hi), Wi = __builtin_amdgcn_readfirstlane(p.Wi);
     const int sh_hw = __builtin_ctz((unsigned)hw), sh_w = __builtin_ctz((unsigned)Wo);
-    const int dh = kh - p.pad, dw = kw - p.pad;
+    const int dh = kh - p.pad, dw = kw - p.pad, strd = __builtin_amdgcn_readfirstlane(p.stride);
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a2), 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 0x7ffffff0, 0x00020000);
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_dma_kernel(ConvKParams p
             for (int it = 0; it < DPIECES; ++it) {
                 const int m = mrow[it] + mshift;
                 const int b = (int)((unsigned)m >> sh_hw), r = m & (hw - 1);
-                const int ih = (r >> sh_w) + dh, iw = (r & (Wo - 1)) + dw;
+                const int ih = (r >> sh_w) * strd + dh, iw = (r & (Wo - 1)) * strd + dw;
                 const bool ok = m < m_end && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
                 const unsigned v = ok ? ((unsigned)((b * Hi + ih) * Wi + iw) * (unsigned)C + (unsigned)(c0 + chan)) * 2u : OOBV;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_ptr)(smem + dst + it * 1024), 16, v, 0u, 0, 0);
@@ -395,8 +396,10 @@ static bool tr_dma_applicable(const ConvKParams& p) {
     const char* env = getenv("STYLEX_WGRAD_TR_DMA");  // read per launch: A/B tests toggle it in-process
     if (env && env[0] == '0') return false;
     const int hw = p.Ho * p.Wo;
-    if (!p.act_bf16 || p.a_scale || p.a2_scale || p.s2d_c || p.stride != 1 || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    if (!p.act_bf16 || p.a_scale || p.a2_scale || p.s2d_c) return false;
     if (!((p.KH == 3 && p.KW == 3 && p.pad == 1) || (p.KH == 1 && p.KW == 1 && p.pad == 0))) return false;
+    // stride 1, or the 3x3 / stride-2 down conv of the small blocks (16^2 -> 8^2 and below: x is [B][2 Ho][2 Wo][C])
+    if (!((p.stride == 1 && p.Hi == p.Ho && p.Wi == p.Wo) || (p.stride == 2 && p.KH == 3 && p.Hi == 2 * p.Ho && p.Wi == 2 * p.Wo))) return false;
     if (p.N % 128 != 0 || p.Ck % 128 != 0 || (hw & (hw - 1)) || (p.Wo & (p.Wo - 1))) return false;
     if (hw > 64 && p.KH != 1) return false;  // larger 3x3 grids belong to the pipelined kernel; 1x1 convs (the residual convs) run here at any size
     if ((long)p.M * p.N * 2 >= (1l << 31) - 16 || (long)p.M * p.Ck * 2 >= (1l << 31) - 16) return false;

@@ -370,6 +370,29 @@ def test_twice_used_block_accumulates_in_the_reduce_launch(case):
         assert adds[1] <= adds[0] - 3, adds  # at least the block's three or four weight gradients
 
 
+@pytest.mark.parametrize("case", [(4, 128, 128, 8, 8, 3, 1, 1), (4, 256, 128, 16, 16, 3, 2, 1), (4, 128, 256, 32, 32, 1, 1, 0),
+                                  (3, 128, 128, 2, 2, 3, 1, 1), (5, 128, 128, 4, 8, 3, 1, 1)])
+def test_small_grid_weight_gradient_dma_kernel(case, monkeypatch):
+    """conv_wgrad_tr_dma_kernel (round 5: LDS-DMA staging for the 128 x 128 tile of the general weight-gradient kernel — <= 8 px
+    3x3 layers, the small stride-2 down convs, 1x1 convs at any power-of-two grid) against the fp64 gradient of F.conv2d and
+    against the register-staged kernel it replaces (STYLEX_WGRAD_TR_DMA=0): same bf16 operands, fp32 accumulation."""
+    B, C, N, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(41)
+    x = cl(torch.randn(B, C, H, W, generator=g).bfloat16().to(DEV))
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = cl(torch.randn(B, N, Ho, Wo, generator=g).bfloat16().to(DEV))
+    w = torch.zeros(N, C, k, k, dtype=torch.float64, device=DEV, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), w, stride=s, padding=p), w, dy.double())
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("STYLEX_WGRAD_TR_DMA", mode)
+        outs[mode] = hb.conv2d_bwd_weight(x, dy, (N, C, k, k), s, p, hb.BF16_ACT).double()
+    scale = float(ref.abs().max())
+    for mode in ("1", "0"):
+        assert float((outs[mode] - ref).abs().max()) / scale < 2e-5, mode
+    assert float((outs["1"] - outs["0"]).abs().max()) / scale < 2e-5
+
+
 def test_conv_bias_lrelu_and_second_order():
     """conv+bias+lrelu, then a gradient-penalty style double backward through it."""
     g = torch.Generator().manual_seed(5)
