@@ -472,12 +472,18 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
             }
         }
     }
-    if (p.Ck % 8 == 0 && p.N % 8 == 0) {  // bf16-activation tr kernel plan
-        int mode, ts;
-        long tl;
-        stylex_wgrad_tr_plan(p, &mode, &ts, &tl);
-        if (ts > splits) splits = ts;
+    if (p.Ck % 8 == 0 && p.N % 8 == 0) {  // tr kernel plans: the register-staged one and (bf16 activations) the LDS-DMA one
+        for (int abf = 0; abf < 2; ++abf) {
+            ConvKParams q = p;
+            q.act_bf16 = abf;
+            int mode, ts;
+            long tl;
+            stylex_wgrad_tr_plan(q, &mode, &ts, &tl);
+            if (ts > splits) splits = ts;
+        }
     }
+    // (the space-to-depth form of the pipelined kernel has the plan of its 4C-channel stride-1 shape, which the loop above
+    // covers: s2d_c narrows the applicability test only)
     // + room for the per-split bias sums of stylex_conv2d_bwd_weight_bias
     return (int64_t)splits * p.N * p.Ck * p.KH * p.KW * (int64_t)sizeof(float) + (int64_t)splits * p.N * (int64_t)sizeof(float);
 }

@@ -778,10 +778,11 @@ def conv2d_bwd_weight_s2d(x2, dy, w_shape, precision, out_scale=1.0, accumulate_
     sh = conv_shape(x2.shape, ws2, 1, 1)
     key = (tuple(sh), precision)
     ok = _S2D_WGRAD_OK.get(key)
-    if ok is None:
-        ok = _S2D_WGRAD_OK[key] = bool(precision == BF16_ACT and os.environ.get("STYLEX_WGRAD_PIPE", "1") != "0" and
+    if ok is None:  # the shape-dependent part only: the switch and the pointers are looked at per call
+        ok = _S2D_WGRAD_OK[key] = bool(precision == BF16_ACT and
                                        lib.stylex_conv2d_bwd_weight_s2d_supported(_shape(*sh), c, precision))
-    if ok and os.environ.get("STYLEX_WGRAD_PIPE", "1") != "0":
+    # (the probe sees null = aligned pointers; the launch wants 16-byte aligned operands: a misaligned view takes the fold path)
+    if ok and os.environ.get("STYLEX_WGRAD_PIPE", "1") != "0" and x2.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0:
         adt = act_dtype(precision)
         assert is_cl(x2) and is_cl(dy) and x2.dtype == adt and dy.dtype == adt, (x2.dtype, dy.dtype, adt)
         shp = _shape(*sh)
@@ -1533,8 +1534,18 @@ def torgb_bwd(x, gy, s1, w, want_gx=True):
     return gx, (partial.sum(dim=1) if nch > 1 else partial[:, 0])
 
 
+# every kernel name a timing_kernels() call has reported in this process (the kernel-coverage check of the GPU suite
+# collects them per test: tests/conftest.py)
+KERNELS_SEEN = set()
+_TIMING_ON = False
+
+
 def timing_enable(on):
+    global _TIMING_ON
+    if _TIMING_ON:
+        timing_kernels()  # enabling clears the C side's tables: keep the names of what ran so far
     load_library().stylex_timing_enable(int(on))
+    _TIMING_ON = bool(on)
 
 
 def timing_report():
@@ -1559,8 +1570,10 @@ def timing_kernels(cap=256):
     vals = (ctypes.c_double * (cap * 3))()
     n = lib.stylex_timing_kernels(names, meta, vals, cap)
     cls = ("fwd", "bwd_data", "bwd_weight")
-    return [dict(cls=cls[meta[r * 2]], kernel=names.raw[r * 112:(r + 1) * 112].split(b"\0", 1)[0].decode(),
+    rows = [dict(cls=cls[meta[r * 2]], kernel=names.raw[r * 112:(r + 1) * 112].split(b"\0", 1)[0].decode(),
                  launches=meta[r * 2 + 1], ms=vals[r * 3], flops=vals[r * 3 + 1], bytes=vals[r * 3 + 2]) for r in range(n)]
+    KERNELS_SEEN.update((r["cls"], r["kernel"]) for r in rows if r["kernel"])
+    return rows
 
 
 def timing_layers(cap=512):
