@@ -157,7 +157,8 @@ def build_trainer(args, device, rank, world):
                     evaluate_every=10 ** 9, save_every=10 ** 9, tensorboard_dir=None,
                     is_ddp=world > 1 or os.environ.get("STYLEX_FORCE_DDP") == "1", rank=rank,
                     world_size=world, device=device, graphs=bool(getattr(args, "graphs", 0)),
-                    pl_every=int(getattr(args, "pl_every", 32)))
+                    pl_every=int(getattr(args, "pl_every", 32)),
+                    device_rng=(bool(getattr(args, "device_rng", 0)) and device.type == "cuda") or None)
     tr.loader = st.cycle(ring)
     tr.dataset = list(range(10 ** 6))
     tr.save = lambda *a, **k: None
@@ -377,6 +378,11 @@ def main(argv=None, backend="nccl", device=None):
     ap.add_argument("--start-step", type=int, default=0,
                     help="Trainer.steps at the start of the timed region (0: one call in 4 carries the gradient penalty, "
                          "no path-length steps; 5024: path-length steps every --pl-every calls as well)")
+    ap.add_argument("--device-rng", type=int, default=1, choices=[0, 1],
+                    help="1 (default): latents / noise planes drawn on the GPU generator — what every rank of the data-parallel "
+                         "path does (Trainer: device_rng defaults to True under DDP), so the N = 1 line is the same program as "
+                         "the N > 1 lines of the scaling curve; 0: the reference's CPU-generator draws + upload "
+                         "(stylex_train.py:319-337; the Trainer's single-GPU default, what every parity fixture pins)")
     ap.add_argument("--host-share", type=int, default=int(os.environ.get("STYLEX_HOST_SHARE", "1")),
                     help="emulate the host share of one rank on an N-GPU node: pin this process (before anything touches "
                          "the GPU; no re-exec) to 1/N of the cores it may run on")
@@ -568,6 +574,9 @@ def main(argv=None, backend="nccl", device=None):
                        "gradient_accumulate_every": args.gae, "global_batch": world * args.batch,
                        "parallelism": "dp%d" % world,
                        "host_cores": len(os.sched_getaffinity(0)),
+                       "rng": ("latents / noise planes drawn on the GPU generator (as every rank of the data-parallel path; "
+                               "--device-rng 0 = the reference's CPU draws + upload: -3 %, profiles/r06_d_ab_imagegrad_devrng.txt)")
+                              if args.device_rng else "CPU generator draws + upload (reference order)",
                        "frozen_nets": "stock MIOpen fp32, immediate mode (reference cli.py:38; what a cli.py run uses)"
                                       if not args.miopen_find else "stock MIOpen fp32, algorithms searched during the warm-up"},
             "algorithmic_conv_gflop_per_image": round(gf, 1),

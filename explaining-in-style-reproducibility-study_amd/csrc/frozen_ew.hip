@@ -148,23 +148,29 @@ __global__ __launch_bounds__(256) void affine_relu_maxpool_bwd_kernel(const floa
 constexpr float LPIPS_EPS = 1e-10f;
 constexpr int LP_PIX = 64;  // pixels per block = one wave width; the block's 4 waves split the channels
 
-// Sum over the block's 4 waves (channel slices) of a per-lane value, in fixed order; every lane of every wave gets it.
+// Sum over the block's SL waves (channel slices) of a per-lane value, in fixed order; every lane of every wave gets it.
+template <int SL>
 __device__ __forceinline__ float lp_cross_wave(float v, float (*buf)[LP_PIX], int wave, int lane) {
     buf[wave][lane] = v;
     __syncthreads();
-    const float r = (buf[0][lane] + buf[1][lane]) + (buf[2][lane] + buf[3][lane]);
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; k += 4) r += (buf[k][lane] + buf[k + 1][lane]) + (buf[k + 2][lane] + buf[k + 3][lane]);
     __syncthreads();
     return r;
 }
 
-// grid (ceil(HW / 64), B), block 256: lane = pixel (coalesced along HW), wave w takes channels w, w + 4, ...; the channel
+// grid (ceil(HW / 64), B), block 64 * SL: lane = pixel (coalesced along HW), wave w takes channels w, w + SL, ...; the channel
 // loops are unrolled 8x so that 16 independent loads are in flight per lane (a one-lane-per-pixel loop over 384 channels
-// was pure load latency: 360 us per tap at 15x15).
-__global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+// was pure load latency: 360 us per tap at 15x15).  SL = 4, or 16 for the small taps (round 6: the 15 x 15 taps are 128 blocks
+// whatever the block size — with 4 waves each lane walked 96 channels in 12 dependent round trips, ~130 us per launch; 16
+// waves make it 3).
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void lpips_tap_fwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                             const float* __restrict__ lin, float* __restrict__ partial,
                                                             float* __restrict__ r0, float* __restrict__ r1, int C, int HW,
                                                             long partial_stride) {
-    __shared__ float buf[4][LP_PIX];
+    __shared__ float buf[SL][LP_PIX];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x * LP_PIX + lane;
     const bool ok = p < HW;
@@ -172,12 +178,12 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restr
     const float* q = f1 + (size_t)b * C * HW + (ok ? p : 0);
     float s0 = 0.f, s1 = 0.f;
     int c = wave;
-    for (; c + 28 < C; c += 32) {
+    for (; c + 7 * SL < C; c += 8 * SL) {
         float x[8], y[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            x[u] = a[(size_t)(c + 4 * u) * HW];
-            y[u] = q[(size_t)(c + 4 * u) * HW];
+            x[u] = a[(size_t)(c + SL * u) * HW];
+            y[u] = q[(size_t)(c + SL * u) * HW];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -185,13 +191,13 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restr
             s1 = fmaf(y[u], y[u], s1);
         }
     }
-    for (; c < C; c += 4) {
+    for (; c < C; c += SL) {
         const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
         s0 = fmaf(x, x, s0);
         s1 = fmaf(y, y, s1);
     }
-    s0 = lp_cross_wave(s0, buf, wave, lane);
-    s1 = lp_cross_wave(s1, buf, wave, lane);
+    s0 = lp_cross_wave<SL>(s0, buf, wave, lane);
+    s1 = lp_cross_wave<SL>(s1, buf, wave, lane);
     const float n0 = sqrtf(s0), n1 = sqrtf(s1);
     if (ok && wave == 0) {
         if (r0) r0[(size_t)b * HW + p] = n0;
@@ -200,13 +206,13 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restr
     const float i0 = 1.f / (n0 + LPIPS_EPS), i1 = 1.f / (n1 + LPIPS_EPS);
     float d = 0.f;
     c = wave;
-    for (; c + 28 < C; c += 32) {
+    for (; c + 7 * SL < C; c += 8 * SL) {
         float x[8], y[8], l[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            x[u] = a[(size_t)(c + 4 * u) * HW];
-            y[u] = q[(size_t)(c + 4 * u) * HW];
-            l[u] = lin[c + 4 * u];
+            x[u] = a[(size_t)(c + SL * u) * HW];
+            y[u] = q[(size_t)(c + SL * u) * HW];
+            l[u] = lin[c + SL * u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -214,11 +220,11 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restr
             d = fmaf(l[u] * t, t, d);
         }
     }
-    for (; c < C; c += 4) {
+    for (; c < C; c += SL) {
         const float t = a[(size_t)c * HW] * i0 - q[(size_t)c * HW] * i1;
         d = fmaf(lin[c] * t, t, d);
     }
-    d = lp_cross_wave(ok ? d : 0.f, buf, wave, lane);
+    d = lp_cross_wave<SL>(ok ? d : 0.f, buf, wave, lane);
     if (wave == 0) {  // fixed-order sum over the block's 64 pixels
         for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
         if (lane == 0) partial[(size_t)b * partial_stride + blockIdx.x] = d / (float)HW;
@@ -228,11 +234,12 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restr
 // d out[b] / d f1[c][p] = g[b] / HW * ( q_c / B - (sum_k q_k y_k) / (B^2 r1) * y_c ),  q_c = -2 lin_c (x_c / A - y_c / B),
 // A = r0 + eps, B = r1 + eps  (and symmetrically for f0).  A pixel whose features are all zero gives 0 / 0 = NaN, as the
 // reference's sqrt backward does.  Same thread layout as the forward.
-__global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void lpips_tap_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                             const float* __restrict__ lin, const float* __restrict__ r0,
                                                             const float* __restrict__ r1, const float* __restrict__ gout,
                                                             float* __restrict__ g0, float* __restrict__ g1, int C, int HW) {
-    __shared__ float buf[4][LP_PIX];
+    __shared__ float buf[SL][LP_PIX];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x * LP_PIX + lane;
     const bool ok = p < HW;
@@ -244,13 +251,13 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const float* __restr
     const float iA = 1.f / A, iB = 1.f / Bn;
     float dot0 = 0.f, dot1 = 0.f;  // sum_c lin_c t_c x_c, sum_c lin_c t_c y_c  (t = n0 - n1)
     int c = wave;
-    for (; c + 28 < C; c += 32) {
+    for (; c + 7 * SL < C; c += 8 * SL) {
         float x[8], y[8], l[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            x[u] = a[(size_t)(c + 4 * u) * HW];
-            y[u] = q[(size_t)(c + 4 * u) * HW];
-            l[u] = lin[c + 4 * u];
+            x[u] = a[(size_t)(c + SL * u) * HW];
+            y[u] = q[(size_t)(c + SL * u) * HW];
+            l[u] = lin[c + SL * u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -259,41 +266,266 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const float* __restr
             dot1 = fmaf(lt, y[u], dot1);
         }
     }
-    for (; c < C; c += 4) {
+    for (; c < C; c += SL) {
         const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
         const float lt = lin[c] * (x * iA - y * iB);
         dot0 = fmaf(lt, x, dot0);
         dot1 = fmaf(lt, y, dot1);
     }
-    dot0 = lp_cross_wave(dot0, buf, wave, lane);
-    dot1 = lp_cross_wave(dot1, buf, wave, lane);
+    dot0 = lp_cross_wave<SL>(dot0, buf, wave, lane);
+    dot1 = lp_cross_wave<SL>(dot1, buf, wave, lane);
     if (!ok) return;
     const float gs = gout[b] / (float)HW;
     // d/dx_c = 2 lin_c t_c / A - 2 dot0 / (A^2 n0) x_c ;  d/dy_c = -2 lin_c t_c / B + 2 dot1 / (B^2 n1) y_c
     const float k0 = 2.f * dot0 / (A * A * n0), k1 = 2.f * dot1 / (Bn * Bn * n1);
     c = wave;
-    for (; c + 28 < C; c += 32) {
+    for (; c + 7 * SL < C; c += 8 * SL) {
         float x[8], y[8], l[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            x[u] = a[(size_t)(c + 4 * u) * HW];
-            y[u] = q[(size_t)(c + 4 * u) * HW];
-            l[u] = lin[c + 4 * u];
+            x[u] = a[(size_t)(c + SL * u) * HW];
+            y[u] = q[(size_t)(c + SL * u) * HW];
+            l[u] = lin[c + SL * u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float lt2 = 2.f * l[u] * (x[u] * iA - y[u] * iB);
-            if (g0) g0[base + (size_t)(c + 4 * u) * HW] = gs * (lt2 * iA - k0 * x[u]);
-            if (g1) g1[base + (size_t)(c + 4 * u) * HW] = gs * (k1 * y[u] - lt2 * iB);
+            if (g0) g0[base + (size_t)(c + SL * u) * HW] = gs * (lt2 * iA - k0 * x[u]);
+            if (g1) g1[base + (size_t)(c + SL * u) * HW] = gs * (k1 * y[u] - lt2 * iB);
         }
     }
-    for (; c < C; c += 4) {
+    for (; c < C; c += SL) {
         const float x = a[(size_t)c * HW], y = q[(size_t)c * HW];
         const float lt2 = 2.f * lin[c] * (x * iA - y * iB);
         if (g0) g0[base + (size_t)c * HW] = gs * (lt2 * iA - k0 * x);
         if (g1) g1[base + (size_t)c * HW] = gs * (k1 * y - lt2 * iB);
     }
 }
+
+// ---- the same tap on bf16 NHWC features (round 6: LPIPS-AlexNet on this library's bf16 conv kernels in the speed mode) ----------
+// f[b][p][c]: a pixel's channels are contiguous, so the channel reductions that cost the NCHW kernels a strided sweep are 16-byte
+// loads here.  8 lanes per pixel (lane s of the octet takes the 8-channel slots s, s + 8, ...: 128 contiguous bytes per octet and
+// load), 8 pixels per wave, 32 per block; octet sums by DPP-free xor shuffles in fixed order.  Same arithmetic as the NCHW
+// kernels (two sweeps, no expanded square); partial[b][block] = sum of the block's 32 pixels / HW, block = 0 .. ceil(HW / 32) - 1.
+constexpr int LPN_PIX = 32;
+
+__device__ __forceinline__ void lp_unpack8(uint4 v, float* o) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        o[2 * d] = __uint_as_float(w[d] << 16);
+        o[2 * d + 1] = __uint_as_float(w[d] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ unsigned lp_pack2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 t = {a, b};
+    bf2 r = __builtin_convertvector(t, bf2);
+    return *reinterpret_cast<unsigned*>(&r);
+}
+__device__ __forceinline__ float lp_octet_sum(float v) {  // over the 8 lanes of a pixel, fixed order
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void lpips_tap_nhwc_fwd_kernel(const unsigned short* __restrict__ f0,
+                                                                 const unsigned short* __restrict__ f1,
+                                                                 const float* __restrict__ lin, float* __restrict__ partial,
+                                                                 float* __restrict__ r0, float* __restrict__ r1, int C, int HW,
+                                                                 long partial_stride) {
+    __shared__ float wsum[4];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 7, p = blockIdx.x * LPN_PIX + wave * 8 + (lane >> 3);
+    const bool ok = p < HW;
+    const size_t base = ((size_t)b * HW + (ok ? p : 0)) * C;
+    const int slots = C >> 3;
+    float s0 = 0.f, s1 = 0.f;
+    for (int q = s; q < slots; q += 8) {
+        float x[8], y[8];
+        lp_unpack8(*reinterpret_cast<const uint4*>(f0 + base + q * 8), x);
+        lp_unpack8(*reinterpret_cast<const uint4*>(f1 + base + q * 8), y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s0 = fmaf(x[e], x[e], s0);
+            s1 = fmaf(y[e], y[e], s1);
+        }
+    }
+    s0 = lp_octet_sum(s0);
+    s1 = lp_octet_sum(s1);
+    const float n0 = sqrtf(s0), n1 = sqrtf(s1);
+    if (ok && s == 0) {
+        if (r0) r0[(size_t)b * HW + p] = n0;
+        if (r1) r1[(size_t)b * HW + p] = n1;
+    }
+    const float i0 = 1.f / (n0 + LPIPS_EPS), i1 = 1.f / (n1 + LPIPS_EPS);
+    float d = 0.f;
+    for (int q = s; q < slots; q += 8) {
+        float x[8], y[8];
+        lp_unpack8(*reinterpret_cast<const uint4*>(f0 + base + q * 8), x);
+        lp_unpack8(*reinterpret_cast<const uint4*>(f1 + base + q * 8), y);
+        const float4 l0 = *reinterpret_cast<const float4*>(lin + q * 8), l1 = *reinterpret_cast<const float4*>(lin + q * 8 + 4);
+        const float l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = x[e] * i0 - y[e] * i1;
+            d = fmaf(l[e] * t, t, d);
+        }
+    }
+    d = lp_octet_sum(ok ? d : 0.f);
+    // the wave's 8 pixels, then the block's 4 waves, in fixed order
+    d += __shfl_xor(d, 8, 64);
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    if (lane == 0) wsum[wave] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * partial_stride + blockIdx.x] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)HW;
+}
+
+// gradients as lpips_tap_bwd_kernel (same formulas), written bf16 NHWC
+__global__ __launch_bounds__(256) void lpips_tap_nhwc_bwd_kernel(const unsigned short* __restrict__ f0,
+                                                                 const unsigned short* __restrict__ f1,
+                                                                 const float* __restrict__ lin, const float* __restrict__ r0,
+                                                                 const float* __restrict__ r1, const float* __restrict__ gout,
+                                                                 unsigned short* __restrict__ g0, unsigned short* __restrict__ g1,
+                                                                 int C, int HW) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 7, p = blockIdx.x * LPN_PIX + wave * 8 + (lane >> 3);
+    const bool ok = p < HW;
+    const size_t base = ((size_t)b * HW + (ok ? p : 0)) * C;
+    const int slots = C >> 3;
+    const float n0 = r0[(size_t)b * HW + (ok ? p : 0)], n1 = r1[(size_t)b * HW + (ok ? p : 0)];
+    const float A = n0 + LPIPS_EPS, Bn = n1 + LPIPS_EPS;
+    const float iA = 1.f / A, iB = 1.f / Bn;
+    float dot0 = 0.f, dot1 = 0.f;
+    for (int q = s; q < slots; q += 8) {
+        float x[8], y[8];
+        lp_unpack8(*reinterpret_cast<const uint4*>(f0 + base + q * 8), x);
+        lp_unpack8(*reinterpret_cast<const uint4*>(f1 + base + q * 8), y);
+        const float4 l0 = *reinterpret_cast<const float4*>(lin + q * 8), l1 = *reinterpret_cast<const float4*>(lin + q * 8 + 4);
+        const float l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float lt = l[e] * (x[e] * iA - y[e] * iB);
+            dot0 = fmaf(lt, x[e], dot0);
+            dot1 = fmaf(lt, y[e], dot1);
+        }
+    }
+    dot0 = lp_octet_sum(dot0);
+    dot1 = lp_octet_sum(dot1);
+    if (!ok) return;
+    const float gs = gout[b] / (float)HW;
+    const float k0 = 2.f * dot0 / (A * A * n0), k1 = 2.f * dot1 / (Bn * Bn * n1);
+    for (int q = s; q < slots; q += 8) {
+        float x[8], y[8], a[8], c[8];
+        lp_unpack8(*reinterpret_cast<const uint4*>(f0 + base + q * 8), x);
+        lp_unpack8(*reinterpret_cast<const uint4*>(f1 + base + q * 8), y);
+        const float4 l0 = *reinterpret_cast<const float4*>(lin + q * 8), l1 = *reinterpret_cast<const float4*>(lin + q * 8 + 4);
+        const float l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float lt2 = 2.f * l[e] * (x[e] * iA - y[e] * iB);
+            a[e] = gs * (lt2 * iA - k0 * x[e]);
+            c[e] = gs * (k1 * y[e] - lt2 * iB);
+        }
+        if (g0) *reinterpret_cast<uint4*>(g0 + base + q * 8) = make_uint4(lp_pack2(a[0], a[1]), lp_pack2(a[2], a[3]), lp_pack2(a[4], a[5]), lp_pack2(a[6], a[7]));
+        if (g1) *reinterpret_cast<uint4*>(g1 + base + q * 8) = make_uint4(lp_pack2(c[0], c[1]), lp_pack2(c[2], c[3]), lp_pack2(c[4], c[5]), lp_pack2(c[6], c[7]));
+    }
+}
+
+
+// ---- input gradient of a frozen network's FIRST convolution (round 6) -------------------------------------------------------
+// dx[b][c][ih][iw] = sum_n sum_{kh,kw} dy[b][n][(ih + pad - kh) / S][(iw + pad - kw) / S] * w[n][c][kh][kw]   (exact divisions only)
+// for the K x K / stride-S stems whose input is the 3-channel image: ResNet conv1 (7 x 7, stride 2, pad 3; torchvision
+// resnet.py) and LPIPS-AlexNet's first layer (11 x 11, stride 4, pad 2; reference stylex_train.py:404, lpips 0.1.4) — the only
+// gradient these networks owe the generator.  The libraries run it as a dense transposed convolution (0.67 - 0.75 ms per
+// call at B = 32: a 3-column GEMM over K^2 * 64 with (1 - 1/S^2) of the taps structurally zero); here a thread owns one input
+// pixel, a block one residue class ((ih + pad) % S, (iw + pad) % S), so the live taps and their weights are block-uniform
+// (staged once per block in LDS, read as broadcasts) and consecutive lanes read consecutive dy elements, 8 independent loads in
+// flight per lane; a thread owns FOUR vertically adjacent pixels of its class, so a dy row is loaded once for the up to four
+// (pixel, tap) pairs it serves and an LDS weight read feeds up to four pixels (version 1, one pixel per thread, ran at the
+// library's speed: 0.41 / 0.54 ms — its LDS broadcasts and loads, not its FMAs, were the cost).  fp32 FMA chain in a fixed
+// (kw, dy row, n) order: deterministic.
+constexpr int IG_PX = 4;  // vertically adjacent pixels (of one residue class) per thread
+
+template <int S>
+__global__ __launch_bounds__(256) void conv_image_grad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int N, int Ho, int Wo, int C, int K, int pad,
+                                                              int Hi, int Wi, int tiles_w) {
+    // blockIdx.x = (tile of the class's pixel grid: 16 rows x 64 columns), blockIdx.y = residue class rh * S + rw, blockIdx.z = b
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // the class's weights: [tap u][tap t][n][4] (channel padded to 4)
+    const int rh = blockIdx.y / S, rw = blockIdx.y - rh * S;
+    const int nth = (K - rh + S - 1) / S, ntw = (K - rw + S - 1) / S;  // taps of the class along each axis (block-uniform)
+    for (int e = threadIdx.x; e < ntw * nth * N * 4; e += 256) {
+        const int c = e & 3, n = (e >> 2) % N, tap = (e >> 2) / N;
+        const int u = tap / nth, t = tap - u * nth;
+        wl[e] = c < C ? w[((size_t)(n * C + c) * K + (rh + S * t)) * K + (rw + S * u)] : 0.f;
+    }
+    __syncthreads();
+    const int ih0 = ((rh - pad) % S + S) % S, iw0 = ((rw - pad) % S + S) % S;  // first pixel of the class
+    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    const int i0 = (th * 4 + (threadIdx.x >> 6)) * IG_PX, j = tw * 64 + (threadIdx.x & 63);  // class coordinates of pixel 0
+    const int iw = iw0 + S * j;
+    const bool okw = iw < Wi;
+    // kh = rh + S t  ->  oh = (ih + pad) / S - t; pixel p of the thread: qh = qh0 + p
+    const int qh0 = (ih0 + S * i0 + pad) / S, qw = (iw + pad) / S;
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)Ho * Wo;
+    const float* dyb = dy + (size_t)b * N * plane;
+    float acc[IG_PX][3];
+#pragma unroll
+    for (int p = 0; p < IG_PX; ++p) acc[p][0] = acc[p][1] = acc[p][2] = 0.f;
+    float acc3[IG_PX] = {0.f, 0.f, 0.f, 0.f};  // fourth image channel (C == 4 only)
+    constexpr int U = 8;  // independent loads in flight per lane
+    // a dy row rr (oh = qh0 + IG_PX - 1 - rr... counted downwards from the top pixel's first tap) serves pixel p through tap
+    // t = p + (IG_PX - 1 - rr')...: written out below with oh as the loop variable
+    const int oh_lo = qh0 - (nth - 1), oh_hi = qh0 + IG_PX - 1;  // rows of dy any of the thread's pixels can touch
+    for (int u = 0; u < ntw; ++u) {
+        const int ow = qw - u;
+        const bool livew = okw && ow >= 0 && ow < Wo;
+        const float4* wu = reinterpret_cast<const float4*>(wl) + (size_t)u * nth * N;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const bool live = livew && oh >= 0 && oh < Ho;
+            const float* src = dyb + (live ? (size_t)oh * Wo + ow : 0);
+            for (int n0 = 0; n0 < N; n0 += U) {
+                float g[U];
+#pragma unroll
+                for (int v = 0; v < U; ++v) g[v] = (live && n0 + v < N) ? src[(size_t)(n0 + v) * plane] : 0.f;
+#pragma unroll
+                for (int p = 0; p < IG_PX; ++p) {
+                    const int t = qh0 + p - oh;  // the tap through which this dy row reaches pixel p (block- and wave-uniform)
+                    if (t >= 0 && t < nth) {
+                        const float4* wt = wu + (size_t)t * N;
+#pragma unroll
+                        for (int v = 0; v < U; ++v) {
+                            const float4 wv = wt[n0 + v < N ? n0 + v : 0];  // one address per wave: an LDS broadcast
+                            acc[p][0] = fmaf(g[v], wv.x, acc[p][0]);
+                            acc[p][1] = fmaf(g[v], wv.y, acc[p][1]);
+                            acc[p][2] = fmaf(g[v], wv.z, acc[p][2]);
+                            if (C == 4) acc3[p] = fmaf(g[v], wv.w, acc3[p]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < IG_PX; ++p) {
+        const int ih = ih0 + S * (i0 + p);
+        if (okw && ih < Hi) {
+            float* o = dx + ((size_t)b * C * Hi + ih) * Wi + iw;
+            o[0] = acc[p][0];
+            if (C > 1) o[(size_t)Hi * Wi] = acc[p][1];
+            if (C > 2) o[(size_t)2 * Hi * Wi] = acc[p][2];
+            if (C > 3) o[(size_t)3 * Hi * Wi] = acc3[p];
+        }
+    }
+}
+
+// 16 channel slices per block (1024 threads) when the launch has fewer than ~4 blocks of 4 waves per CU and enough channels
+inline bool lp_wide(unsigned blocks, int64_t B, int64_t C) { return (int64_t)blocks * B < 1024 && C >= 128; }
 
 inline unsigned grid_for(unsigned long n) {
     unsigned long b = (n + 255) / 256;
@@ -359,8 +591,12 @@ int stylex_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, flo
     if (!f0 || !f1 || !lin || !partial || B < 1 || B > 65535 || C < 1 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
     const unsigned blocks = (unsigned)((HW + LP_PIX - 1) / LP_PIX);
     if (partial_stride < (int64_t)blocks) return STYLEX_EINVAL;
-    hipLaunchKernelGGL(lpips_tap_fwd_kernel, dim3(blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0, f1, lin, partial, r0,
-                       r1, (int)C, (int)HW, (long)partial_stride);
+    if (lp_wide(blocks, B, C))
+        hipLaunchKernelGGL(lpips_tap_fwd_kernel<16>, dim3(blocks, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, f0, f1, lin, partial,
+                           r0, r1, (int)C, (int)HW, (long)partial_stride);
+    else
+        hipLaunchKernelGGL(lpips_tap_fwd_kernel<4>, dim3(blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0, f1, lin, partial, r0,
+                           r1, (int)C, (int)HW, (long)partial_stride);
     return (int)hipGetLastError();
 }
 
@@ -369,8 +605,62 @@ int stylex_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, con
     if (!f0 || !f1 || !lin || !r0 || !r1 || !gout || (!g0 && !g1) || B < 1 || B > 65535 || C < 1 || HW < 1 ||
         B * C * HW > 0x7fffffffLL)
         return STYLEX_EINVAL;
-    hipLaunchKernelGGL(lpips_tap_bwd_kernel, dim3((unsigned)((HW + LP_PIX - 1) / LP_PIX), (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0,
-                       f1, lin, r0, r1, gout, g0, g1, (int)C, (int)HW);
+    const unsigned blocks = (unsigned)((HW + LP_PIX - 1) / LP_PIX);
+    if (lp_wide(blocks, B, C))
+        hipLaunchKernelGGL(lpips_tap_bwd_kernel<16>, dim3(blocks, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, f0, f1, lin, r0, r1, gout,
+                           g0, g1, (int)C, (int)HW);
+    else
+        hipLaunchKernelGGL(lpips_tap_bwd_kernel<4>, dim3(blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, f0, f1, lin, r0, r1, gout,
+                           g0, g1, (int)C, (int)HW);
+    return (int)hipGetLastError();
+}
+
+int stylex_conv_image_grad(const float* dy, const float* w, float* dx, const int64_t* sh, void* stream) {
+    // sh = {B, N, Ho, Wo, C, K, stride, pad, Hi, Wi}
+    if (!dy || !w || !dx || !sh) return STYLEX_EINVAL;
+    const int64_t B = sh[0], N = sh[1], Ho = sh[2], Wo = sh[3], C = sh[4], K = sh[5], S = sh[6], pad = sh[7], Hi = sh[8], Wi = sh[9];
+    if (B < 1 || B > 65535 || N < 1 || C < 1 || C > 4 || K < 1 || K > 15 || pad < 0 || pad >= K || Hi < 1 || Wi < 1) return STYLEX_EINVAL;
+    if (S != 1 && S != 2 && S != 4) return STYLEX_EINVAL;
+    if (Ho != (Hi + 2 * pad - K) / S + 1 || Wo != (Wi + 2 * pad - K) / S + 1 || Ho < 1 || Wo < 1) return STYLEX_EINVAL;
+    if (B * N * Ho * Wo > 0x7fffffffLL || B * C * Hi * Wi > 0x7fffffffLL) return STYLEX_EINVAL;
+    const int ch = (int)((Hi + S - 1) / S), cw = (int)((Wi + S - 1) / S);  // pixels of a residue class along each axis (at most)
+    const int tiles_h = (ch + 4 * IG_PX - 1) / (4 * IG_PX), tiles_w = (cw + 63) / 64;
+    const dim3 grid((unsigned)(tiles_h * tiles_w), (unsigned)(S * S), (unsigned)B);
+    const int64_t max_taps = ((K + S - 1) / S) * ((K + S - 1) / S);
+    const size_t smem = (size_t)(max_taps * N * 4 * sizeof(float));  // the largest residue class's weights
+    if (smem > 64 * 1024) return STYLEX_EINVAL;
+#define STYLEX_IMG_GRAD(SS)                                                                                                        \
+    hipLaunchKernelGGL(conv_image_grad_kernel<SS>, grid, dim3(256), smem, (hipStream_t)stream, dy, w, dx, (int)N, (int)Ho, (int)Wo, \
+                       (int)C, (int)K, (int)pad, (int)Hi, (int)Wi, tiles_w)
+    if (S == 1) STYLEX_IMG_GRAD(1);
+    else if (S == 2) STYLEX_IMG_GRAD(2);
+    else STYLEX_IMG_GRAD(4);
+#undef STYLEX_IMG_GRAD
+    return (int)hipGetLastError();
+}
+
+int stylex_lpips_tap_nhwc_fwd(const void* f0, const void* f1, const float* lin, float* partial, float* r0, float* r1, int64_t B,
+                              int64_t C, int64_t HW, int64_t partial_stride, void* stream) {
+    if (!f0 || !f1 || !lin || !partial || B < 1 || B > 65535 || C < 8 || C % 8 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(f0) | reinterpret_cast<uintptr_t>(f1) | reinterpret_cast<uintptr_t>(lin)) & 15) return STYLEX_EINVAL;
+    const unsigned blocks = (unsigned)((HW + LPN_PIX - 1) / LPN_PIX);
+    if (partial_stride < (int64_t)blocks) return STYLEX_EINVAL;
+    hipLaunchKernelGGL(lpips_tap_nhwc_fwd_kernel, dim3(blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)f0,
+                       (const unsigned short*)f1, lin, partial, r0, r1, (int)C, (int)HW, (long)partial_stride);
+    return (int)hipGetLastError();
+}
+
+int stylex_lpips_tap_nhwc_bwd(const void* f0, const void* f1, const float* lin, const float* r0, const float* r1, const float* gout,
+                              void* g0, void* g1, int64_t B, int64_t C, int64_t HW, void* stream) {
+    if (!f0 || !f1 || !lin || !r0 || !r1 || !gout || (!g0 && !g1) || B < 1 || B > 65535 || C < 8 || C % 8 || HW < 1 ||
+        B * C * HW > 0x7fffffffLL)
+        return STYLEX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(f0) | reinterpret_cast<uintptr_t>(f1) | reinterpret_cast<uintptr_t>(lin) |
+         reinterpret_cast<uintptr_t>(g0) | reinterpret_cast<uintptr_t>(g1)) & 15)
+        return STYLEX_EINVAL;
+    hipLaunchKernelGGL(lpips_tap_nhwc_bwd_kernel, dim3((unsigned)((HW + LPN_PIX - 1) / LPN_PIX), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short*)f0, (const unsigned short*)f1, lin, r0, r1, gout, (unsigned short*)g0,
+                       (unsigned short*)g1, (int)C, (int)HW);
     return (int)hipGetLastError();
 }
 

@@ -107,7 +107,9 @@ bool conv_shape_ok(const int64_t* sh) {
     int64_t B = sh[0], Hi = sh[1], Wi = sh[2], C = sh[3], N = sh[4], KH = sh[5], KW = sh[6], st = sh[7], pad = sh[8],
             Ho = sh[9], Wo = sh[10];
     if (B < 1 || Hi < 1 || Wi < 1 || C < 1 || N < 1) return false;
-    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3))) return false;
+    // 1x1 and 3x3 are the StylEx layers; 5x5 (stride 1) is LPIPS-AlexNet's second layer (round 6: the generic implicit-GEMM
+    // kernel gathers any K x K window; every specialised kernel checks its own 3x3 / 1x1 premise)
+    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 5 && KW == 5 && st == 1))) return false;
     if (st != 1 && st != 2) return false;
     if (Ho != (Hi + 2 * pad - KH) / st + 1 || Wo != (Wi + 2 * pad - KW) / st + 1) return false;
     if (B * Ho * Wo > 0x7fffffff || B * Hi * Wi > 0x7fffffff) return false;

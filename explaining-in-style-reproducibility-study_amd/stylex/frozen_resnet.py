@@ -87,6 +87,40 @@ def _affine(bn):
     return scale, shift
 
 
+class _FirstConv(torch.autograd.Function):
+    """The stem of a frozen network over the image (ResNet conv1 7x7/2, LPIPS-AlexNet 11x11/4): forward = the library's
+    convolution, untouched; backward = csrc/frozen_ew.hip conv_image_grad_kernel instead of the library's dense transposed
+    convolution (round 6: 0.67-0.75 ms -> ~0.1 ms per call at B = 32; same fp32 arithmetic, fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        ctx.cfg = (stride, pad, tuple(x.shape[2:]))
+        ctx.save_for_backward(w)
+        return F.conv2d(x, w, bias, stride, pad)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        (w,) = ctx.saved_tensors
+        stride, pad, hw = ctx.cfg
+        return hb.conv_image_grad(gy, w, hw, stride, pad), None, None, None, None
+
+
+def first_conv(x, w, bias, stride, pad):
+    """conv2d of a frozen stem; the input gradient on the image-gradient kernel where it applies (GPU, fp32, <= 4 image
+    channels, stride 4, frozen weights).  STYLEX_IMAGE_GRAD=0: plain F.conv2d."""
+    import os
+
+    # stride 4 only by default (LPIPS-AlexNet's stem: 0.33 ms against the library's 0.47 at B = 32); at stride 2 (ResNet conv1) the
+    # kernel runs at the library's speed or below (0.58 vs 0.52 ms: profiles/r06_e_probe_first_conv.txt) — STYLEX_IMAGE_GRAD=2 takes both
+    mode = os.environ.get("STYLEX_IMAGE_GRAD", "1")
+    if (x.is_cuda and x.requires_grad and x.dtype == torch.float32 and x.shape[1] <= 4 and (stride == 4 or (mode == "2" and stride in (1, 2)))
+            and w.shape[2] == w.shape[3] <= 15 and pad < w.shape[2] and not w.requires_grad
+            and (bias is None or not bias.requires_grad) and mode != "0"):
+        return _FirstConv.apply(x, w, bias, stride, pad)
+    return F.conv2d(x, w, bias, stride, pad)
+
+
 class _AffineAct(torch.autograd.Function):
     """act(x * scale[c] + shift[c] (+ residual)): `bn -> relu` / `bn -> (+ identity) -> relu` of a BasicBlock
     (torchvision resnet.py BasicBlock.forward) in one pass; first-order backward to x and the residual."""
@@ -161,7 +195,12 @@ class FusedTailResNet(nn.Module):
         if self._stamp() != self.stamp:  # BatchNorm tensors were modified in place (a state dict loaded later)
             self._build()
         x = x.float().contiguous()
-        x = _AffineReluPool.apply(self._conv(x, m.conv1).contiguous(), *self.aff["bn1"])
+        c1 = m.conv1
+        if c1.groups == 1 and c1.dilation == (1, 1) and c1.stride[0] == c1.stride[1] and c1.padding[0] == c1.padding[1]:
+            stem = first_conv(x, c1.weight, c1.bias, c1.stride[0], c1.padding[0])
+        else:
+            stem = self._conv(x, c1)
+        x = _AffineReluPool.apply(stem.contiguous(), *self.aff["bn1"])
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(m, "layer%d" % li)):
                 pre = "layer%d.%d." % (li, bi)

@@ -112,6 +112,11 @@ SIGNATURES = {
                                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_affine_relu_maxpool_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_lpips_tap_nhwc_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_lpips_tap_nhwc_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_conv_image_grad": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_lpips_tap_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p]),
     "stylex_lpips_tap_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64,
@@ -256,13 +261,14 @@ class RawGrad:
     tensor still exists (the engine may have replaced it by an out-of-place sum with another node's gradient): `alive()`
     must be checked right before use; the address is read from the live tensor then.  Accepted as accumulate_into /
     accumulate_bias_into of conv2d_bwd_weight / conv2d_bwd_weight_s2d (ops._gacc_*)."""
-    __slots__ = ("ref", "ptr", "shape")
+    __slots__ = ("ref", "ptr", "shape", "stream", "seq")
 
     def __init__(self, t):
         import weakref
 
         assert t.dtype == torch.float32 and t.is_contiguous()
         self.ref, self.ptr, self.shape = weakref.ref(t), t.data_ptr(), tuple(t.shape)
+        self.stream = torch.cuda.current_stream() if t.is_cuda else None  # the HIP stream the tensor was produced on
 
     def alive(self):
         t = self.ref()
@@ -1018,6 +1024,20 @@ def affine_relu_maxpool_bwd(gy, idx, scale, in_hw):
     return gx
 
 
+def conv_image_grad(gy, w, in_hw, stride, pad):
+    """Input gradient of a K x K / stride-S convolution over a <= 4-channel image (the stems of the frozen classifier and of
+    LPIPS-AlexNet), dense fp32 NCHW: gy [B, N, Ho, Wo], w [N, C, K, K] -> [B, C, Hi, Wi] (stylex_conv_image_grad)."""
+    lib = _ensure_device(gy)
+    gy, w = gy.contiguous(), w.detach().contiguous()
+    assert gy.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[2] == w.shape[3] and gy.shape[1] == w.shape[0]
+    b, n, ho, wo = gy.shape
+    c, k = int(w.shape[1]), int(w.shape[2])
+    dx = _empty((b, c, int(in_hw[0]), int(in_hw[1])), dtype=torch.float32, device=gy.device)
+    _check(lib.stylex_conv_image_grad(_ptr(gy), _ptr(w), _ptr(dx), _shape(b, n, ho, wo, c, k, int(stride), int(pad), int(in_hw[0]),
+                                                                         int(in_hw[1])), _stream()), "stylex_conv_image_grad")
+    return dx
+
+
 def lpips_taps_fwd(f0s, f1s, lins, keep_norms):
     """sum over the taps of mean_p sum_c lin[c] (n0 - n1)^2  ->  ([B] distances, saved per-pixel norms)."""
     lib = _ensure_device(f0s[0])
@@ -1035,6 +1055,35 @@ def lpips_taps_fwd(f0s, f1s, lins, keep_norms):
         norms.append((r0, r1))
         off += nb
     return partial.sum(dim=1), norms
+
+
+def lpips_taps_nhwc_fwd(f0s, f1s, lins, keep_norms):
+    """lpips_taps_fwd for bf16 channels_last feature maps (the taps of the bf16 LPIPS path)."""
+    lib = _ensure_device(f0s[0])
+    b = f0s[0].shape[0]
+    blocks = [(f.shape[2] * f.shape[3] + 31) // 32 for f in f0s]
+    partial = torch.empty((b, sum(blocks)), dtype=torch.float32, device=f0s[0].device)
+    norms, off = [], 0
+    for f0, f1, lin, nb in zip(f0s, f1s, lins, blocks):
+        _, c, h, w = f0.shape
+        assert f1.shape == f0.shape and lin.numel() == c and is_cl(f0) and is_cl(f1) and f0.dtype == f1.dtype == torch.bfloat16
+        r0 = torch.empty((b, h * w), dtype=torch.float32, device=f0.device) if keep_norms else None
+        r1 = torch.empty_like(r0) if keep_norms else None
+        _check(lib.stylex_lpips_tap_nhwc_fwd(_ptr(f0), _ptr(f1), _ptr(lin), ctypes.c_void_p(partial.data_ptr() + 4 * off), _ptr(r0),
+                                             _ptr(r1), b, c, h * w, partial.shape[1], _stream()), "stylex_lpips_tap_nhwc_fwd")
+        norms.append((r0, r1))
+        off += nb
+    return partial.sum(dim=1), norms
+
+
+def lpips_tap_nhwc_bwd(f0, f1, lin, r0, r1, gout, want0, want1):
+    lib = _ensure_device(f0)
+    b, c, h, w = f0.shape
+    g0 = torch.empty_like(f0) if want0 else None  # (preserves channels_last)
+    g1 = torch.empty_like(f1) if want1 else None
+    _check(lib.stylex_lpips_tap_nhwc_bwd(_ptr(f0), _ptr(f1), _ptr(lin), _ptr(r0), _ptr(r1), _ptr(gout), _ptr(g0), _ptr(g1), b, c, h * w,
+                                         _stream()), "stylex_lpips_tap_nhwc_bwd")
+    return g0, g1
 
 
 def lpips_tap_bwd(f0, f1, lin, r0, r1, gout, want0, want1):

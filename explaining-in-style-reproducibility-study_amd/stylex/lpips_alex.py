@@ -52,11 +52,53 @@ class LPIPS(nn.Module):
         for i, (_, _, _, s, p, mp, _) in enumerate(_ALEX):
             if mp:
                 x = F.max_pool2d(x, 3, 2)
-            x = F.relu(F.conv2d(x, self.cw[i], self.cb[i], stride=s, padding=p))
+            if i == 0 and x.is_cuda:  # the stem: its input gradient on the image-gradient kernel (frozen_resnet.first_conv)
+                from frozen_resnet import first_conv
+
+                x = F.relu(first_conv(x, self.cw[i], self.cb[i], s, p))
+            else:
+                x = F.relu(F.conv2d(x, self.cw[i], self.cb[i], stride=s, padding=p))
             out.append(x)
         return out
 
+    def _taps_bf16(self, x):
+        """The five taps in the bf16 speed mode (round 6): the stem stays on the library's fp32 convolution (forward) with its
+        input gradient on csrc/frozen_ew.hip's image-gradient kernel; its ReLU output is cast once to bf16 channels_last and the
+        other four layers (5x5, then three 3x3, each + bias + ReLU in the conv epilogue) run on this library's bf16 MFMA kernels,
+        first-order backward included (ops.conv2d fast path).  Returns bf16 channels_last feature maps."""
+        import ops
+        from frozen_resnet import first_conv
+
+        t = F.relu(first_conv(x, self.cw[0], self.cb[0], _ALEX[0][3], _ALEX[0][4]))
+        t = t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        out = [t]
+        prev = ops.set_fast(True)  # first-order gradients only ever flow through the frozen loss network
+        try:
+            for i in range(1, len(_ALEX)):
+                _, _, _, s, p, mp, _ = _ALEX[i]
+                if mp:
+                    t = F.max_pool2d(t, 3, 2)
+                t = ops.conv2d(t, self.cw[i], self.cb[i], stride=s, padding=p, lrelu="relu")
+                out.append(t)
+        finally:
+            ops.set_fast(prev)
+        return out
+
+    @staticmethod
+    def _bf16_path(x):
+        """bf16 speed mode on the GPU with the HIP implementation installed (STYLEX_LPIPS_BF16=0: the fp32 library path)."""
+        if not x.is_cuda or os.environ.get("STYLEX_LPIPS_BF16", "1") == "0":
+            return False
+        import ops
+
+        return ops.get_precision() == "bf16" and ops.impl() is ops.HipOps
+
     def forward(self, in0, in1):
+        if self._bf16_path(in0):
+            f0 = self._taps_bf16((in0 - self.shift) / self.scale)
+            f1 = self._taps_bf16((in1 - self.shift) / self.scale)
+            lins = [w.reshape(-1) for w in self.lin]
+            return _LpipsDistanceNHWC.apply(len(f0), *lins, *f0, *f1).view(-1, 1, 1, 1)
         f0 = self._taps((in0 - self.shift) / self.scale)
         f1 = self._taps((in1 - self.shift) / self.scale)
         if in0.is_cuda and f0[0].dtype == torch.float32 and os.environ.get("STYLEX_LPIPS_FUSE", "1") != "0":
@@ -100,6 +142,41 @@ class _LpipsDistance(torch.autograd.Function):
             w0, w1 = ctx.needs_input_grad[1 + n + i], ctx.needs_input_grad[1 + 2 * n + i]
             g0, g1 = (None, None) if not (w0 or w1) else hb.lpips_tap_bwd(f0s[i], f1s[i], lins[i], rs[2 * i], rs[2 * i + 1],
                                                                           gout, w0, w1)
+            g0s.append(g0)
+            g1s.append(g1)
+        return (None,) + (None,) * n + tuple(g0s) + tuple(g1s)
+
+
+class _LpipsDistanceNHWC(torch.autograd.Function):
+    """_LpipsDistance on bf16 channels_last feature maps (stylex_lpips_tap_nhwc_fwd / _bwd): the channel reductions are
+    contiguous 16-byte loads instead of strided sweeps; gradients come back as bf16 channels_last, the layout the conv
+    kernels' backward takes."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        import hip_backend as hb
+
+        lins, f0s, f1s = args[:n], list(args[n:2 * n]), list(args[2 * n:])
+        need = any(t.requires_grad for t in args[n:])
+        out, norms = hb.lpips_taps_nhwc_fwd(f0s, f1s, lins, keep_norms=need)
+        ctx.n = n
+        if need:
+            ctx.save_for_backward(*lins, *f0s, *f1s, *[r for pair in norms for r in pair])
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        import hip_backend as hb
+
+        n, sv = ctx.n, ctx.saved_tensors
+        lins, f0s, f1s, rs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:]
+        gout = gout.contiguous().float()
+        g0s, g1s = [], []
+        for i in range(n):
+            w0, w1 = ctx.needs_input_grad[1 + n + i], ctx.needs_input_grad[1 + 2 * n + i]
+            g0, g1 = (None, None) if not (w0 or w1) else hb.lpips_tap_nhwc_bwd(f0s[i], f1s[i], lins[i], rs[2 * i], rs[2 * i + 1],
+                                                                               gout, w0, w1)
             g0s.append(g0)
             g1s.append(g1)
         return (None,) + (None,) * n + tuple(g0s) + tuple(g1s)

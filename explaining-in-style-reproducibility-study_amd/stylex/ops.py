@@ -1005,9 +1005,29 @@ class _DBlockFast(torch.autograd.Function):
 # (stylex_conv2d_bwd_weight_ex, accumulate) and returns None.  The engine keeps the first tensor alive, unmodified, until
 # the parameter's AccumulateGrad node runs — after every use, by its dependency count.  Same two rounded fp32 operations as
 # the engine's add: bit-identical gradients (tests/test_hip_parity.py::test_twice_used_block_accumulates_in_the_reduce_launch).
+#
+# Stream ordering (round 6, ADVICE medium).  The engine knows nothing of the later node's write, so the two orderings it would
+# have provided are made explicit: (1) a node running on ANOTHER HIP stream than the tensor's producer (E(x) on the caller's
+# stream, E(G(x)) on a Trainer._fork side stream) first makes its stream wait for the producer's; (2) the stream it added on
+# is joined into the stream backward() was called from by an engine callback at the end of the pass (what the engine's own
+# leaf-stream sync does for gradients it knows of), and GradSync's in-backward bucket launches wait for it as well
+# (parallel.py::_launch reads _GACC_STREAMS).  tests/test_hip_parity.py::test_twice_used_block_on_two_streams.
 _GACC = {}
 _GACC_TASK = [-2]
 _GACC_ON = os.environ.get("STYLEX_GRAD_ACC", "1") != "0"
+_GACC_STREAMS = set()  # streams that added into a gradient produced on another stream, during the current backward pass
+_GACC_WAITED = {}  # (waiting stream, producer stream) -> production number up to which the wait already holds
+_GACC_SEQ = [0]
+
+
+def _gacc_join():
+    """End of the backward pass (engine callback, on the thread and stream that called backward())."""
+    if _GACC_STREAMS:
+        cur = torch.cuda.current_stream()
+        for st in _GACC_STREAMS:
+            if st != cur:
+                cur.wait_stream(st)
+        _GACC_STREAMS.clear()
 
 
 def _gacc_get(w, tag=""):
@@ -1019,17 +1039,33 @@ def _gacc_get(w, tag=""):
         return None
     if task != _GACC_TASK[0]:
         _GACC.clear()
+        _GACC_STREAMS.clear()
+        _GACC_WAITED.clear()
         _GACC_TASK[0] = task
     slot = _GACC.get((w.data_ptr(), tag))
     if slot is not None and not slot.alive():  # the engine no longer holds that tensor (replaced by an out-of-place sum)
         del _GACC[(w.data_ptr(), tag)]
         return None
+    if slot is not None:
+        cur = torch.cuda.current_stream()
+        if slot.stream != cur:
+            # the tensor's producer ran on another stream: its kernel must have finished.  One wait covers every tensor that
+            # stream had produced by then (slots are numbered in production order), so a whole encoder costs one event
+            key = (cur, slot.stream)
+            if _GACC_WAITED.get(key, 0) <= slot.seq:
+                cur.wait_stream(slot.stream)
+                _GACC_WAITED[key] = _GACC_SEQ[0]
+            if not _GACC_STREAMS:
+                torch.autograd.Variable._execution_engine.queue_callback(_gacc_join)
+            _GACC_STREAMS.add(cur)
     return slot
 
 
 def _gacc_put(w, g, tag=""):
     if _GACC_ON and g is not None and w.is_cuda and torch._C._current_graph_task_id() == _GACC_TASK[0] and g.is_contiguous():
-        _GACC[(w.data_ptr(), tag)] = hb.RawGrad(g)
+        slot = _GACC[(w.data_ptr(), tag)] = hb.RawGrad(g)
+        slot.seq = _GACC_SEQ[0]
+        _GACC_SEQ[0] += 1
 
 
 def _channel_sum(t, scale=1.0):

@@ -283,6 +283,16 @@ int stylex_affine_relu_maxpool_fwd(const float* x, const float* scale, const flo
 int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, const float* scale, float* gx, int64_t B, int64_t C,
                                    int64_t H, int64_t W, void* stream);
 
+/* ---- input gradient of a frozen network's first convolution (round 6) ---------------------------
+ * The K x K / stride-S stem over the 3-channel image of the frozen classifier (torchvision ResNet conv1: 7 x 7 / 2 / pad 3,
+ * reference stylex/resnet_classifier.py:19, 56-71) and of LPIPS-AlexNet (11 x 11 / 4 / pad 2, reference stylex_train.py:404):
+ *   dx[b][c][ih][iw] = sum_n sum_{kh,kw} dy[b][n][(ih + pad - kh) / S][(iw + pad - kw) / S] * w[n][c][kh][kw]
+ * (terms whose divisions are exact and land inside dy) — the gradient torch.nn.grad.conv2d_input defines.  Dense fp32
+ * NCHW: dy [B][N][Ho][Wo], w [N][C][K][K], dx [B][C][Hi][Wi]; sh = {B, N, Ho, Wo, C, K, S, pad, Hi, Wi}; C <= 4,
+ * K <= 15, S in {1, 2, 4}.  Replaces the library's dense transposed convolution in the backward of the two stems
+ * (frozen_resnet.py / lpips_alex.py `_FirstConv`); fixed summation order. */
+int stylex_conv_image_grad(const float* dy, const float* w, float* dx, const int64_t* sh, void* stream);
+
 /* ---- LPIPS distance of one feature tap -----------------------------------------------------------
  * reconstruction_loss (reference stylex_train.py:404-438) calls lpips.LPIPS(net='alex') (lpips 0.1.4): per tap
  *   n = f / (sqrt(sum_c f^2) + 1e-10),  d[b][p] = sum_c lin[c] * (n0 - n1)^2,  out[b] = mean_p d[b][p].
@@ -294,6 +304,14 @@ int stylex_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, flo
                          int64_t C, int64_t HW, int64_t partial_stride, void* stream);
 int stylex_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* r0, const float* r1, const float* gout,
                          float* g0, float* g1, int64_t B, int64_t C, int64_t HW, void* stream);
+
+/* The same tap on bf16 NHWC features f[b][p][c] (round 6: LPIPS-AlexNet on this library's bf16 convolution kernels in the speed
+ * mode, stylex/lpips_alex.py): C % 8 == 0, 16-byte aligned pointers; per-block sums of d / HW over blocks of 32 pixels,
+ * block = 0 .. ceil(HW / 32) - 1; norms r0 / r1 fp32 [B][HW]; bwd writes g0 / g1 as bf16 NHWC. */
+int stylex_lpips_tap_nhwc_fwd(const void* f0, const void* f1, const float* lin, float* partial, float* r0, float* r1, int64_t B,
+                              int64_t C, int64_t HW, int64_t partial_stride, void* stream);
+int stylex_lpips_tap_nhwc_bwd(const void* f0, const void* f1, const float* lin, const float* r0, const float* r1, const float* gout,
+                              void* g0, void* g1, int64_t B, int64_t C, int64_t HW, void* stream);
 
 /* ---- modulated-conv coefficients (SURVEY §8(b) `demod_coeff` / `bwd_style`) --------------------
  * Conv2DMod.forward (reference stylex_train.py:650-656) in the batched form:

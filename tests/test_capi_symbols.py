@@ -46,7 +46,7 @@ def test_binding_table_matches_header():
 def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device."""
     lib = hip_backend.load_library()
-    sh = (ctypes.c_int64 * 11)(1, 4, 4, 4, 4, 5, 5, 1, 2, 4, 4)  # 5x5 kernel: unsupported
+    sh = (ctypes.c_int64 * 11)(1, 4, 4, 4, 4, 7, 7, 1, 3, 4, 4)  # 7x7 kernel: unsupported
     assert lib.stylex_conv2d_bwd_weight_workspace_bytes(sh) == -1
     assert lib.stylex_conv2d_fwd(None, None, None, sh, 0, None, 0, None, 0, None) == -1
     assert lib.stylex_timing_report(7, None, None, None, None) == -1
