@@ -1655,6 +1655,53 @@ def test_frozen_classifier_fused_tails_match_plain_module():
     close(after_plain, after_fused, 2e-5, "logits after an in-place BatchNorm update")
 
 
+@pytest.mark.parametrize("size", [224, 96])
+def test_frozen_classifier_bf16_data_gradient(size, monkeypatch):
+    """Round 6: the frozen ResNet-18 in the bf16 speed mode, a pass whose input gradient is wanted (the classifier on generated
+    images, reference stylex_train.py:1390, 421-438): the forward stays on the library's fp32 convolutions — the logits of
+    the fp32 path — and the data gradient runs on this library's bf16 kernels gated by the signs of the fp32 activations
+    (frozen_resnet._ResNetBodyHybrid).  Against the all-fp32 backward (STYLEX_FROZEN_BWD_BF16=0) on the same input: relative L2
+    error of the image gradient below 3e-2, cosine above 0.999 (17 chained bf16 data gradients, no gate flips)."""
+    from frozen_resnet import FusedTailResNet
+    from tv_models import ResNet18
+
+    torch.manual_seed(5)
+    net = ResNet18()
+    net.fc = torch.nn.Linear(512, 2)
+    with torch.no_grad():
+        for mod in net.modules():  # non-trivial BatchNorm statistics
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    net = net.to(DEV).eval()
+    for p in net.parameters():
+        p.requires_grad = False
+    fused = FusedTailResNet(net)
+    g = torch.Generator(device=DEV).manual_seed(59)
+    x0 = torch.randn(4, 3, size, size, device=DEV, generator=g)
+    r = torch.randn(4, 2, device=DEV, generator=g)
+    res = {}
+    ops.set_precision("bf16")
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("STYLEX_FROZEN_BWD_BF16", mode)
+            x = x0.clone().requires_grad_()
+            y = fused(x)
+            (y * r).sum().backward()
+            res[mode] = (y.detach().clone(), x.grad.detach().double())
+    finally:
+        ops.set_precision("fp32")
+    # the same library convolutions in both modes (the library's own run-to-run noise is ~1e-7: atomics in its algorithms)
+    close(res["0"][0], res["1"][0], 1e-5, "the forward must not change")
+    g32, g16 = res["0"][1], res["1"][1]
+    rel = float((g16 - g32).norm() / g32.norm())
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    print("frozen classifier @%d: bf16 data gradient vs fp32: rel L2 %.3e, cosine %.6f" % (size, rel, cos))
+    assert rel < 3e-2 and cos > 0.999, (rel, cos)
+
+
 def test_resnet_wrapper_vs_reference_golden_on_hip(tmp_path):
     """A16 on the GPU: ResNet.classify_images (the classifier of the headline benchmark configuration) against what
     the REFERENCE's own wrapper class produced (tests/golden/resnet_wrapper.npz from stylex/resnet_classifier.py:29-71
