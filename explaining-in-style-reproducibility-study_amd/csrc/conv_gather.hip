@@ -16,9 +16,9 @@
 // partials [ksplit][M][N] and the existing deterministic split-K epilogue kernel (conv_igemm.hip) applies the fused
 // epilogue (scales, bias, noise, residual, gate, activation) and the bf16 rounding.
 //
-// Round 5: conv_gather_line_kernel (below) is the kernel that runs — same tile, split-K plan and partial layout, operand rows
-// staged as whole 128-byte lines on 8 waves and, above all, a DMA issue path without branches, 64-bit pointer arithmetic or
-// kernel-argument reloads inside the loop; conv_gather_kernel stays behind STYLEX_GATHER_LINE=0 for A/B runs.
+// Round 5: conv_gather_line_kernel (below) — same tile, split-K plan and partial layout as the round-2 kernel it replaced, operand
+// rows staged as whole 128-byte lines on 8 waves and, above all, a DMA issue path without branches, 64-bit pointer arithmetic or
+// kernel-argument reloads inside the loop.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,17 +30,10 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-__device__ uint4 g_zero_page_g[4];
-
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef __attribute__((address_space(1))) const void* gl_void_ptr;
 
-constexpr int GBM = 128, GBN = 128, ROW = 32;
-constexpr int GROUP_BYTES = (GBM + GBN) * ROW;   // 8 KiB: one 16-channel group of A and W rows
-constexpr int STAGE_BYTES = 4 * GROUP_BYTES;     // 32 KiB: 64 channels
+constexpr int GBM = 128, GBN = 128;
 constexpr int RING = 4;
-constexpr int PIECES_PER_WAVE = 8;               // 32 pieces of 1 KiB per stage, 4 waves
-constexpr int SMEM_BYTES = RING * STAGE_BYTES;   // 128 KiB -> one block per CU
 
 struct GatherParams {
     const unsigned short* x;   // [B][H][W][C] bf16
@@ -62,166 +55,8 @@ __device__ __forceinline__ unsigned short f2bf_rne(float f) {  // v_cvt_pk_bf16_
     return (unsigned short)(*reinterpret_cast<unsigned*>(&r) & 0xffffu);
 }
 
-__global__ __launch_bounds__(256, 1) void conv_gather_kernel(GatherParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_tiles = (p.N + GBN - 1) / GBN;
-    const int n0 = (int)(blockIdx.x % n_tiles) * GBN;
-    int mt = (int)(blockIdx.x / n_tiles);
-    // Stride-2 data gradient: rows are grouped by the parity class (py, px) of the output pixel, so that a tile shares
-    // its live taps — kh = 1 for even oh, kh in {0, 2} for odd oh (same along w): 1, 2 or 4 taps instead of 9 with
-    // three quarters of the gathered rows zero.  Row r of a class = (b, qh, qw) over the SOURCE grid; output pixel
-    // (2 qh + py, 2 qw + px).
-    const bool phased = p.sign < 0 && p.stride == 2;
-    int py = 0, px = 0;
-    if (phased) {
-        const int tpp = p.m_tiles >> 2;
-        const int ph = mt / tpp;
-        mt -= ph * tpp;
-        py = ph >> 1;
-        px = ph & 1;
-    }
-    const int m0 = mt * GBM;
-    const int rows = phased ? p.B * p.Hs * p.Ws : p.M;  // rows of this tile's index space
-    const int cpt = p.C >> 6;  // stages per tap
-    const int ks = blockIdx.y;
-    const int s_begin = ks * p.stages_per_split;
-    const int s_end = min(s_begin + p.stages_per_split, phased ? (1 + py) * (1 + px) * cpt : p.stages);
-    const int nst = max(s_end - s_begin, 0);
-    const int T = p.KH * p.KH, K = T * p.C;
-    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page_g);
-
-    // this lane's rows: DMA piece q of a group = rows q*32 + lr of the A panel (q < 4) or of the W panel (q >= 4)
-    const int lr = lane >> 1, pslot = lane & 1;
-    const int slot = pslot ^ ((lr >> 3) & 1);  // logical 8-channel half this lane fetches
-    // a wave issues pieces (wave + 4*it): it even -> group (it/2)... piece index pi = wave + 4*it in [0, 32): group = pi >> 3,
-    // q = pi & 7.  For a fixed wave, q takes the two values wave and wave + 4: one A panel slice and one W panel slice.
-    const int a_rowl = wave * 32 + lr;          // A row (0..127) this lane stages
-    const int w_rowl = wave * 32 + lr;          // W row (0..127) this lane stages
-    // pixel of the A row
-    const int m = m0 + a_rowl;
-    const bool m_ok = m < rows;
-    const int gw = phased ? p.Ws : p.W;                  // grid the row index runs over
-    const int hw = phased ? p.Hs * p.Ws : p.H * p.W;
-    const int b = m_ok ? m / hw : 0;
-    const int q_ = m_ok ? m - b * hw : 0;
-    const int oh = q_ / gw, ow = q_ - oh * gw;           // phased: (qh, qw)
-    const long img_base = (long)b * p.Hs * p.Ws * p.C;
-    const int n_row = n0 + w_rowl;
-    const bool n_ok = n_row < p.N;
-    const long w_base = (long)n_row * K;
-
-    // source pointers of one stage (computed once per stage), and the two DMA instructions of one 16-channel group
-    const unsigned short *asrc = zero, *wsrc = zero;
-    bool a_ok = false;
-    auto stage_setup = [&](int s) {
-        int tap = s / cpt;
-        const int c0 = (s - tap * cpt) << 6;
-        int ih, iw;
-        if (phased) {  // tap = index into the class's live taps; (2q + py + 1 - kh) / 2 = q + (py && kh == 0)
-            const int nkw = 1 + px;
-            const int a = tap / nkw, bq = tap - a * nkw;
-            const int kh = py ? 2 * a : 1, kw = px ? 2 * bq : 1;
-            ih = oh + (py && kh == 0);
-            iw = ow + (px && kw == 0);
-            tap = kh * 3 + kw;
-        } else {
-            const int kh = tap / p.KH, kw = tap - kh * p.KH;
-            ih = p.sign > 0 ? oh * p.stride + kh - p.pad : oh + p.pad - kh;
-            iw = p.sign > 0 ? ow * p.stride + kw - p.pad : ow + p.pad - kw;
-        }
-        a_ok = m_ok && ih >= 0 && ih < p.Hs && iw >= 0 && iw < p.Ws;
-        asrc = p.x + img_base + ((long)ih * p.Ws + iw) * p.C + c0 + slot * 8;
-        wsrc = p.w + w_base + (long)tap * p.C + c0 + slot * 8;
-    };
-    auto issue_group = [&](int rs, int g) {
-        char* base = smem + rs * STAGE_BYTES;
-        __builtin_amdgcn_global_load_lds((gl_void_ptr)(a_ok ? asrc + g * 16 : zero),
-                                         (lds_void_ptr)(base + g * GROUP_BYTES + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gl_void_ptr)(n_ok ? wsrc + g * 16 : zero),
-                                         (lds_void_ptr)(base + g * GROUP_BYTES + GBM * ROW + wave * 1024), 16, 0, 0);
-    };
-    auto issue_stage = [&](int s, int rs) {
-        stage_setup(s);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) issue_group(rs, g);
-    };
-
-    // MFMA operand rows: wave (wm, wn) owns rows wm*64 .. +63 of A and wn*64 .. +63 of W
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lk = lane >> 5;
-    const int swz = (((li >> 3) ^ lk) & 1) << 4;
-    const int a_off = (wm * 64 + li) * ROW + swz;              // + i*32*ROW + g*GROUP_BYTES
-    const int b_off = GBM * ROW + (wn * 64 + li) * ROW + swz;  // + j*32*ROW + g*GROUP_BYTES
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // prologue: three stages in flight
-    for (int s = 0; s < 3 && s < nst; ++s) issue_stage(s_begin + s, s);
-    for (int s = 0; s < nst; ++s) {
-        // stage s must have landed; loads complete in order, so allowing the 8 DMA instructions of each younger stage
-        // in flight proves it
-        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES_PER_WAVE) : "memory");
-        else if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // everyone's pieces of stage s are visible; everyone is done with ring slot (s + 3) % RING.  A RAW barrier:
-        // __syncthreads() carries an s_waitcnt vmcnt(0), which drained the three stages in flight at every stage (round 5:
-        // found in the ISA; the kernel ran one DMA round trip per stage, 1.9 us, for 0.25 us of MFMA work)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const bool more = s + 3 < nst;
-        if (more) stage_setup(s_begin + s + 3);
-        const char* base = smem + (s % RING) * STAGE_BYTES;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // the 8 DMA instructions of stage s+3 go out two per group, in the shadow of this group's 4 MFMAs (a burst at
-            // the top of the stage leaves the matrix pipe idle while it is issued)
-            if (more) issue_group((s + 3) % RING, g);
-            bf16x8 av[2], bv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(base + g * GROUP_BYTES + a_off + i * 32 * ROW);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(base + g * GROUP_BYTES + b_off + j * 32 * ROW);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // raw fp32 partials: D[row = m][col = n], col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* out = p.partial + (long)ks * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int mm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const bool ok = mm < rows && n < p.N;
-                if (phased && ok) {  // class row -> natural (b, oh, ow) order of the partial buffer
-                    const int bb = mm / hw, qq = mm - bb * hw;
-                    const int qh = qq / p.Ws, qw = qq - qh * p.Ws;
-                    mm = (bb * p.H + 2 * qh + py) * p.W + 2 * qw + px;
-                }
-                if (ok && p.y) p.y[(long)mm * p.N + n] = f2bf_rne(acc[i][j][r]);
-                else if (ok) out[(long)mm * p.N + n] = acc[i][j][r];
-            }
-        }
-}
-
-
-// ---- round 5: the same GEMM with WHOLE-LINE staging on 8 waves.  The kernel above stages 16-channel groups: every DMA
-// instruction fetches 32 bytes from each of 32 rows, a request shape the vector-memory path serves at 15-17 B/clk/CU whatever
+// ---- WHOLE-LINE staging on 8 waves (round 5).  The round-2 kernel (deleted in round 6; git history, profiles/design_history_r1_r4.md)
+// staged 16-channel groups: every DMA instruction fetched 32 bytes from each of 32 rows, a request shape the vector-memory path serves at 15-17 B/clk/CU whatever
 // is in flight (tools/l2_feed_probe.hip), and with the ring no longer drained at every barrier that rate IS its stage time
 // (32 KiB per stage = 1.0 us for 0.25 us of MFMA work).  Here a K stage is the same 64 channels of one tap, but an operand row
 // is ONE 128-byte line in global memory and in LDS: a DMA instruction fetches 8 complete lines (33-37 B/clk/CU with 8 waves
@@ -469,18 +304,15 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
     gather_plan(p, &ks, &per);
     if (workspace_bytes < (int64_t)ks * p.M * p.N * (int64_t)sizeof(float)) return STYLEX_NOT_APPLICABLE;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) return STYLEX_NOT_APPLICABLE;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_line_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, RING * LSTAGE);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
+    // 0 = not asked yet, 1 = granted, -1 = refused (a device with less LDS): the generic kernel behind this one serves the launch
+    static int attr_state = 0;
+    if (attr_state == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gather_line_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, RING * LSTAGE);
+        attr_state = e == hipSuccess ? 1 : -1;
+        if (e != hipSuccess) (void)hipGetLastError();
     }
-    const char* le = getenv("STYLEX_GATHER_LINE");  // read per launch: A/B tests toggle it in-process
-    const bool line = !(le && le[0] == '0');
+    if (attr_state < 0) return STYLEX_NOT_APPLICABLE;
     GatherParams g;
     g.x = reinterpret_cast<const unsigned short*>(p.a);
     g.w = reinterpret_cast<const unsigned short*>(p.w);
@@ -505,9 +337,8 @@ int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_byte
     g.ksplit = ks;
     g.stages_per_split = per;
     const long tiles = (long)g.m_tiles * ((p.N + GBN - 1) / GBN);
-    stylex_note_kernel(line ? "conv_gather_line_kernel" : "conv_gather_kernel");
-    if (line) hipLaunchKernelGGL(conv_gather_line_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(512), RING * LSTAGE, s, g);
-    else hipLaunchKernelGGL(conv_gather_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), SMEM_BYTES, s, g);
+    stylex_note_kernel("conv_gather_line_kernel");
+    hipLaunchKernelGGL(conv_gather_line_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(512), RING * LSTAGE, s, g);
     p.ksplit = direct ? 0 : ks;  // 0: output complete, the caller skips the split-K epilogue
     p.kt_per_split = per;
     p.partial = (float*)workspace;

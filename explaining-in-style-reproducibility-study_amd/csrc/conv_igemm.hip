@@ -1203,20 +1203,6 @@ int stylex_launch_wgrad(ConvKParams p, float* partial, float* dw_oihw, int preci
         }
         p.bias_partial = nullptr;
     }
-    if (precision == STYLEX_BF16 && stylex_wgrad_halo_applicable(p)) {
-        int hs = 0, bias_done = 0;
-        if (db) {  // the bias partials live behind the weight-gradient partials of this plan
-            int ps, tps;
-            stylex_wgrad_halo_plan(p, &ps, &tps);
-            p.bias_partial = partial + (long)ps * p.N * 9 * p.Ck;
-        }
-        int rc = stylex_launch_wgrad_halo(p, partial, s, &hs, &bias_done);
-        if (rc) return rc;
-        const bool with_db = db && bias_done;
-        launch_wgrad_reduce(partial, dw_oihw, p.N, p.Ck, 9, hs, s, wg_out_of(p), with_db ? p.bias_partial : nullptr, with_db ? db : nullptr);
-        if (with_db && db_done) *db_done = 1;
-        return (int)hipGetLastError();
-    }
     if (precision == STYLEX_BF16 && stylex_wgrad_tr_applicable(p)) {
         int ts = 0;
         int rc = stylex_launch_wgrad_tr(p, partial, s, &ts);

@@ -446,20 +446,6 @@ int64_t stylex_conv2d_bwd_weight_workspace_bytes(const int64_t* sh) {
     int tn, tc, splits;
     long len;
     stylex_wgrad_plan(p, &tn, &tc, &splits, &len);
-    if (p.KH == 3 && p.stride == 1 && p.pad == 1 && p.Wo >= 16 && p.Ho >= 8) {  // halo plans may use more splits
-        // the plan depends on the activation type and on whether x carries a per-sample scale (LDS-DMA kernel: splits
-        // never cross a sample then); the query knows neither, so it covers every combination
-        static const float dummy_scale[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int abf = 0; abf < 2; ++abf)
-            for (int sc = 0; sc < 2; ++sc) {
-                ConvKParams q = p;
-                q.act_bf16 = abf;
-                q.a_scale = sc ? dummy_scale : nullptr;
-                int hs, tps;
-                stylex_wgrad_halo_plan(q, &hs, &tps);
-                if (hs > splits) splits = hs;
-            }
-    }
     {  // pipelined LDS-DMA plan (bf16 activations; with / without a per-sample x scale)
         static const float dummy_scale[4] = {0.f, 0.f, 0.f, 0.f};
         for (int sc = 0; sc < 2; ++sc) {

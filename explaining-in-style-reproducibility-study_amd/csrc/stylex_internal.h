@@ -28,7 +28,7 @@ struct ConvKParams {
     int phase_major;  // rows ordered by (oh&1, ow&1) first (transposed stride-2 only)
     int act_bf16;     // activation tensors (a, a2, y, residual) are bf16 instead of fp32 (STYLEX_BF16_ACT)
     int s2d_c;        // >0: the conv is a 3x3/s2 conv in space-to-depth form: source channels = 4 sub-positions x s2d_c,
-                      //     structurally-zero (tap, sub-position) pairs are skipped (conv_halo / conv_wgrad_halo)
+                      //     structurally-zero (tap, sub-position) pairs are skipped (conv_halo)
     int flip_taps;    // halo kernel: read weight tap 8-t for compute tap t (data gradient of a 3x3/s1/p1 conv)
     int M;            // B*Ho*Wo
     int flags;
@@ -101,11 +101,6 @@ int stylex_launch_s2d_fwd(const ConvKParams& p, hipStream_t s);
 // for the split-K epilogue kernel
 int stylex_launch_gather(ConvKParams& p, void* workspace, int64_t workspace_bytes, hipStream_t s);
 int64_t stylex_gather_workspace_bytes(const ConvKParams& p);
-
-// 3x3/s1/p1 bf16 weight gradient with resident halo + LDS transpose reads (conv_wgrad_halo.hip)
-bool stylex_wgrad_halo_applicable(const ConvKParams& p);
-void stylex_wgrad_halo_plan(const ConvKParams& p, int* splits, int* tiles_per_split);
-int stylex_launch_wgrad_halo(ConvKParams p, float* partial, hipStream_t s, int* splits_out, int* bias_done = nullptr);
 
 // round 5: pipelined LDS-DMA weight gradient of the 3x3/s1/p1 bf16 layers with whole 64-channel tiles (conv_wgrad_pipe.hip)
 bool stylex_wgrad_pipe_applicable(const ConvKParams& p);

@@ -24,7 +24,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
                              "conv3x3_wgrad_pipe_kernelILi1ELi32ELb1", "conv3x3_wgrad_pipe_kernelILi2ELi16ELb1",
                              "conv3x3_wgrad_pipe_kernelILi1ELi16ELb0"]),
     ("conv_wgrad_tr.hip", ["conv_wgrad_tr_dma_kernel", "conv_wgrad_tr_kernelILi2ELi2ELb0"]),
-    ("conv_gather.hip", ["conv_gather_line_kernel", "conv_gather_kernel"]),
+    ("conv_gather.hip", ["conv_gather_line_kernel"]),
     ("conv_s2d_dgrad.hip", ["conv_s2d_dgrad_kernelILi32ELi4", "conv_s2d_dgrad_kernelILi16ELi4", "conv_s2d_dgrad_kernelILi32ELi8",
                             "conv_s2d_dgrad_kernelILi16ELi8"]),
     ("conv_s2d_fwd.hip", ["conv_s2d_fwd_kernelILi32ELi128ELi4ELi4", "conv_s2d_fwd_kernelILi16ELi128ELi4ELi4",

@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WGRAD = ("conv3x3_wgrad_pipe_kernel", "conv3x3_wgrad_halo_kernel", "conv3x3_wgrad_halo_dma_kernel", "conv_wgrad_tr_kernel", "conv_wgrad_tr_dma_kernel", "conv_wgrad_kernel")
+WGRAD = ("conv3x3_wgrad_pipe_kernel", "conv_wgrad_tr_kernel", "conv_wgrad_tr_dma_kernel", "conv_wgrad_kernel")
 WGRAD_AUX = ("wgrad_reduce_kernel", "wgrad_reduce_small_kernel", "fold_weight_s2d_kernel")
 FWD = ("conv3x3_halo_bf16_kernel", "conv3x3_halo_dma_kernel", "conv_igemm_kernel", "conv_gather_kernel", "conv3x3_pipe_kernel", "conv3x3_line64_kernel", "conv3x3_rgb_kernel", "conv_s2d_dgrad_kernel", "conv_s2d_fwd_kernel", "conv_gather_line_kernel")  # forward and data gradient share these kernels
 FWD_AUX = ("splitk_epilogue_kernel", "pack_weight_kernel", "pack_weight_s2d_kernel")
