@@ -15,6 +15,7 @@
 // 3x3 nn.Conv2d of DiscriminatorBlock (:724-731), plus their input gradients.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "stylex_internal.h"
 
@@ -452,7 +453,10 @@ int launch_halo(const ConvKParams& p, hipStream_t s) {
 int stylex_launch_halo(const ConvKParams& p, hipStream_t s) {
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return STYLEX_NOT_APPLICABLE;
     if (p.Hi != p.Ho || p.Wi != p.Wo) return STYLEX_NOT_APPLICABLE;
-    if (p.Ck % 8 != 0 || p.Wo < 16 || p.Ho < 8 || (long)p.Ho * p.Wo < 256) return STYLEX_NOT_APPLICABLE;
+    // images below 16 x 16: 12-15 pixel wide ones (the frozen networks' 14 x 14 / 15 x 15 layers, round 6) run here as one partial
+    // 16 x 16 tile per image — the generic kernel served them at 100-200 TF/s; <= 8 x 8 belongs to the gather kernel
+    static const int min_w = getenv("STYLEX_HALO_MIN_W") ? atoi(getenv("STYLEX_HALO_MIN_W")) : 12;
+    if (p.Ck % 8 != 0 || p.Wo < min_w || p.Ho < 8 || (long)p.Ho * p.Wo < (long)min_w * min_w) return STYLEX_NOT_APPLICABLE;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)) return STYLEX_NOT_APPLICABLE;
     if (p.a_scale && (reinterpret_cast<uintptr_t>(p.a_scale) & 15)) return STYLEX_NOT_APPLICABLE;
     {

@@ -436,6 +436,137 @@ __global__ __launch_bounds__(256) void lpips_tap_nhwc_bwd_kernel(const unsigned 
 }
 
 
+// ---- layout bridges between the library's fp32 NCHW tensors and this library's bf16 NHWC ones (round 6) ------------------------
+// The frozen networks keep their forward (classifier) or their stem (LPIPS) on the library's fp32 NCHW convolutions while their
+// gradient path / remaining layers run on the bf16 NHWC kernels.  ATen's strided copy did the conversion at 45 us per ResNet
+// activation (16 per classifier call: 0.73 ms); a 64-channel x 64-pixel tile through LDS reads and writes whole lines.
+//   fwd: y[b][p][c] = bf16( relu ? max(x[b][c][p], 0) : x[b][c][p] )
+//   bwd: gx[b][c][p] = float(g[b][p][c]) * (gate == nullptr || gate[b][p][c] > 0)
+constexpr int LB_T = 64;
+
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int C,
+                                                                    int HW, int relu) {
+    __shared__ float tile[LB_T][LB_T + 1];
+    const int b = blockIdx.z, c0 = blockIdx.y * LB_T, p0 = blockIdx.x * LB_T, tid = threadIdx.x;
+    const float* xb = x + (size_t)b * C * HW;
+#pragma unroll
+    for (int i = 0; i < LB_T / 4; ++i) {
+        const int c = i * 4 + (tid >> 6), p = tid & 63;
+        float v = 0.f;
+        if (c0 + c < C && p0 + p < HW) v = xb[(size_t)(c0 + c) * HW + p0 + p];
+        tile[c][p] = relu ? fmaxf(v, 0.f) : v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int pix = (tid >> 3) + 32 * k, slot = tid & 7;
+        if (p0 + pix < HW && c0 + slot * 8 < C) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[slot * 8 + e][pix];
+            *reinterpret_cast<uint4*>(y + ((size_t)b * HW + p0 + pix) * C + c0 + slot * 8) =
+                make_uint4(lp_pack2(v[0], v[1]), lp_pack2(v[2], v[3]), lp_pack2(v[4], v[5]), lp_pack2(v[6], v[7]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ g,
+                                                                    const unsigned short* __restrict__ gate, float* __restrict__ gx,
+                                                                    int C, int HW) {
+    __shared__ float tile[LB_T][LB_T + 1];
+    const int b = blockIdx.z, c0 = blockIdx.y * LB_T, p0 = blockIdx.x * LB_T, tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int pix = (tid >> 3) + 32 * k, slot = tid & 7;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p0 + pix < HW && c0 + slot * 8 < C) {
+            const size_t o = ((size_t)b * HW + p0 + pix) * C + c0 + slot * 8;
+            lp_unpack8(*reinterpret_cast<const uint4*>(g + o), v);
+            if (gate) {
+                float q[8];
+                lp_unpack8(*reinterpret_cast<const uint4*>(gate + o), q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = q[e] > 0.f ? v[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[slot * 8 + e][pix] = v[e];
+    }
+    __syncthreads();
+    float* gb = gx + (size_t)b * C * HW;
+#pragma unroll
+    for (int i = 0; i < LB_T / 4; ++i) {
+        const int c = i * 4 + (tid >> 6), p = tid & 63;
+        if (c0 + c < C && p0 + p < HW) gb[(size_t)(c0 + c) * HW + p0 + p] = tile[c][p];
+    }
+}
+
+// ---- classifier input: bilinear resize (align_corners = false, no antialias) + per-channel normalisation (round 6) --------------
+// ResNet.classify_images (reference stylex/resnet_classifier.py:56-71): torchvision's tensor resize to 224 x 224 ==
+// F.interpolate(mode='bilinear', align_corners=False), then (x - mean[c]) / std[c].  ATen's upsample kernel takes 140-160 us per
+// call for the 32 x 3 x 224 x 224 output (and as long again backward), plus the sub / div passes and a layout copy of the generated
+// batch in front; one pass each way here.  Index arithmetic as ATen's (area_pixel_compute_source_index): src = in / out * (dst + 0.5)
+// - 0.5, clamped at 0; i0 = (int)src, i1 = i0 + (i0 < in - 1), lambda1 = src - i0.  The input is read through its four strides (the
+// generator's channels_last output needs no dense copy).  Backward = the exact adjoint as a gather: an input pixel collects from
+// the outputs whose i0 / i1 name it (fixed order: deterministic).
+struct RsIdx { int i0, i1; float l0, l1; };
+__device__ __forceinline__ RsIdx rs_index(int dst, float ratio, int in) {
+    float src = ratio * (dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    RsIdx r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void resize_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ mean, const float* __restrict__ stdv, int C,
+                                                              int Hi, int Wi, int Ho, int Wo, long sb, long sc, long sh, long sw,
+                                                              unsigned total) {
+    const float rh = (float)Hi / Ho, rw = (float)Wi / Wo;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int ox = i % Wo, oy = (i / Wo) % Ho, c = (i / (Wo * Ho)) % C, b = i / (Wo * Ho * C);
+        const RsIdx h = rs_index(oy, rh, Hi), w = rs_index(ox, rw, Wi);
+        const float* p = x + b * sb + c * sc;
+        const float v = h.l0 * (w.l0 * p[h.i0 * sh + w.i0 * sw] + w.l1 * p[h.i0 * sh + w.i1 * sw]) +
+                        h.l1 * (w.l0 * p[h.i1 * sh + w.i0 * sw] + w.l1 * p[h.i1 * sh + w.i1 * sw]);
+        y[i] = mean ? (v - mean[c]) / stdv[c] : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_norm_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                              const float* __restrict__ stdv, int C, int Hi, int Wi, int Ho, int Wo,
+                                                              unsigned total) {
+    const float rh = (float)Hi / Ho, rw = (float)Wi / Wo;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int ix = i % Wi, iy = (i / Wi) % Hi, c = (i / (Wi * Hi)) % C, b = i / (Wi * Hi * C);
+        // outputs whose source coordinate lies within (i - 1, i + 1), one more on either side for the float arithmetic
+        int oy0 = (int)floorf((iy - 0.5f) / rh - 0.5f) - 1, oy1 = (int)ceilf((iy + 1.5f) / rh - 0.5f) + 1;
+        int ox0 = (int)floorf((ix - 0.5f) / rw - 0.5f) - 1, ox1 = (int)ceilf((ix + 1.5f) / rw - 0.5f) + 1;
+        oy0 = oy0 < 0 ? 0 : oy0;
+        ox0 = ox0 < 0 ? 0 : ox0;
+        oy1 = oy1 > Ho - 1 ? Ho - 1 : oy1;
+        ox1 = ox1 > Wo - 1 ? Wo - 1 : ox1;
+        const float* g = gy + ((size_t)b * C + c) * Ho * Wo;
+        float acc = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const RsIdx h = rs_index(oy, rh, Hi);
+            const float wy = (h.i0 == iy ? h.l0 : 0.f) + (h.i1 == iy ? h.l1 : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const RsIdx w = rs_index(ox, rw, Wi);
+                const float wx = (w.i0 == ix ? w.l0 : 0.f) + (w.i1 == ix ? w.l1 : 0.f);
+                row = fmaf(wx, g[oy * Wo + ox], row);
+            }
+            acc = fmaf(wy, row, acc);
+        }
+        gx[i] = stdv ? acc / stdv[c] : acc;
+    }
+}
+
 // ---- input gradient of a frozen network's FIRST convolution (round 6) -------------------------------------------------------
 // dx[b][c][ih][iw] = sum_n sum_{kh,kw} dy[b][n][(ih + pad - kh) / S][(iw + pad - kw) / S] * w[n][c][kh][kw]   (exact divisions only)
 // for the K x K / stride-S stems whose input is the 3-channel image: ResNet conv1 (7 x 7, stride 2, pad 3; torchvision
@@ -661,6 +792,49 @@ int stylex_lpips_tap_nhwc_bwd(const void* f0, const void* f1, const float* lin, 
     hipLaunchKernelGGL(lpips_tap_nhwc_bwd_kernel, dim3((unsigned)((HW + LPN_PIX - 1) / LPN_PIX), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, (const unsigned short*)f0, (const unsigned short*)f1, lin, r0, r1, gout, (unsigned short*)g0,
                        (unsigned short*)g1, (int)C, (int)HW);
+    return (int)hipGetLastError();
+}
+
+int stylex_nchw_f32_to_nhwc_bf16(const float* x, void* y, int64_t B, int64_t C, int64_t HW, int relu, void* stream) {
+    if (!x || !y || B < 1 || B > 65535 || C < 8 || C % 8 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
+    if (reinterpret_cast<uintptr_t>(y) & 15) return STYLEX_EINVAL;
+    const dim3 grid((unsigned)((HW + LB_T - 1) / LB_T), (unsigned)((C + LB_T - 1) / LB_T), (unsigned)B);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, (int)C, (int)HW, relu);
+    return (int)hipGetLastError();
+}
+
+int stylex_nhwc_bf16_to_nchw_f32(const void* g, const void* gate, float* gx, int64_t B, int64_t C, int64_t HW, void* stream) {
+    if (!g || !gx || B < 1 || B > 65535 || C < 8 || C % 8 || HW < 1 || B * C * HW > 0x7fffffffLL) return STYLEX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gate)) & 15) return STYLEX_EINVAL;
+    const dim3 grid((unsigned)((HW + LB_T - 1) / LB_T), (unsigned)((C + LB_T - 1) / LB_T), (unsigned)B);
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g,
+                       (const unsigned short*)gate, gx, (int)C, (int)HW);
+    return (int)hipGetLastError();
+}
+
+int stylex_resize_norm_fwd(const float* x, float* y, const float* mean, const float* stdv, const int64_t* sh, const int64_t* strides,
+                           void* stream) {
+    // sh = {B, C, Hi, Wi, Ho, Wo}; strides = element strides of x (b, c, h, w); y dense NCHW
+    if (!x || !y || !sh || !strides || (mean && !stdv) || (!mean && stdv)) return STYLEX_EINVAL;
+    for (int k = 0; k < 6; ++k)
+        if (sh[k] < 1) return STYLEX_EINVAL;
+    const int64_t total = sh[0] * sh[1] * sh[4] * sh[5];
+    if (total > 0x7fffffffLL || sh[0] * sh[1] * sh[2] * sh[3] > 0x7fffffffLL) return STYLEX_EINVAL;
+    hipLaunchKernelGGL(resize_norm_fwd_kernel, dim3(grid_for((unsigned long)total)), dim3(256), 0, (hipStream_t)stream, x, y, mean, stdv,
+                       (int)sh[1], (int)sh[2], (int)sh[3], (int)sh[4], (int)sh[5], (long)strides[0], (long)strides[1], (long)strides[2],
+                       (long)strides[3], (unsigned)total);
+    return (int)hipGetLastError();
+}
+
+int stylex_resize_norm_bwd(const float* gy, float* gx, const float* stdv, const int64_t* sh, void* stream) {
+    // gy dense [B][C][Ho][Wo] -> gx dense [B][C][Hi][Wi]; stdv NULL = no normalisation
+    if (!gy || !gx || !sh) return STYLEX_EINVAL;
+    for (int k = 0; k < 6; ++k)
+        if (sh[k] < 1) return STYLEX_EINVAL;
+    const int64_t total = sh[0] * sh[1] * sh[2] * sh[3];
+    if (total > 0x7fffffffLL || sh[0] * sh[1] * sh[4] * sh[5] > 0x7fffffffLL) return STYLEX_EINVAL;
+    hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3(grid_for((unsigned long)total)), dim3(256), 0, (hipStream_t)stream, gy, gx, stdv,
+                       (int)sh[1], (int)sh[2], (int)sh[3], (int)sh[4], (int)sh[5], (unsigned)total);
     return (int)hipGetLastError();
 }
 

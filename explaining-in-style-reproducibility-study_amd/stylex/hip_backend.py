@@ -116,6 +116,11 @@ SIGNATURES = {
                                                  ctypes.c_int64, ctypes.c_void_p]),
     "stylex_lpips_tap_nhwc_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_nchw_f32_to_nhwc_bf16": (ctypes.c_int, [_c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                                    ctypes.c_void_p]),
+    "stylex_nhwc_bf16_to_nchw_f32": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_resize_norm_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, _i64p, ctypes.c_void_p]),
+    "stylex_resize_norm_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_conv_image_grad": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_lpips_tap_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p]),
@@ -1024,6 +1029,47 @@ def affine_relu_maxpool_bwd(gy, idx, scale, in_hw):
     return gx
 
 
+def resize_norm_fwd(x, size, mean=None, std=None):
+    """bilinear resize (align_corners=False) of a [B, C, H, W] fp32 tensor of ANY layout to `size`, then (. - mean[c]) / std[c]
+    (both or neither given): dense NCHW fp32 result (stylex_resize_norm_fwd)."""
+    lib = _ensure_device(x)
+    assert x.dtype == torch.float32 and x.dim() == 4
+    b, c, h, w = x.shape
+    y = torch.empty((b, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+    _check(lib.stylex_resize_norm_fwd(_ptr(x), _ptr(y), _ptr(mean), _ptr(std), _shape(b, c, h, w, int(size[0]), int(size[1])),
+                                      _shape(*x.stride()), _stream()), "stylex_resize_norm_fwd")
+    return y
+
+
+def resize_norm_bwd(gy, in_hw, std=None):
+    lib = _ensure_device(gy)
+    gy = _dense_f32(gy.contiguous())
+    b, c, ho, wo = gy.shape
+    gx = torch.empty((b, c, int(in_hw[0]), int(in_hw[1])), dtype=torch.float32, device=gy.device)
+    _check(lib.stylex_resize_norm_bwd(_ptr(gy), _ptr(gx), _ptr(std), _shape(b, c, int(in_hw[0]), int(in_hw[1]), ho, wo), _stream()),
+           "stylex_resize_norm_bwd")
+    return gx
+
+
+def nchw_to_cl_bf16(x, relu=False):
+    """Dense fp32 NCHW -> bf16 channels_last (optionally through a ReLU) in one pass (stylex_nchw_f32_to_nhwc_bf16)."""
+    lib = _ensure_device(x)
+    b, c, h, w = _dense_f32(x).shape
+    y = torch.empty((b, c, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _check(lib.stylex_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(y), b, c, h * w, int(relu), _stream()), "stylex_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def cl_bf16_to_nchw(g, gate=None):
+    """bf16 channels_last -> dense fp32 NCHW, optionally gated by (gate > 0) (stylex_nhwc_bf16_to_nchw_f32)."""
+    lib = _ensure_device(g)
+    assert is_cl(g) and g.dtype == torch.bfloat16 and (gate is None or (is_cl(gate) and gate.dtype == torch.bfloat16 and gate.shape == g.shape))
+    b, c, h, w = g.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=g.device)
+    _check(lib.stylex_nhwc_bf16_to_nchw_f32(_ptr(g), _ptr(gate), _ptr(out), b, c, h * w, _stream()), "stylex_nhwc_bf16_to_nchw_f32")
+    return out
+
+
 def conv_image_grad(gy, w, in_hw, stride, pad):
     """Input gradient of a K x K / stride-S convolution over a <= 4-channel image (the stems of the frozen classifier and of
     LPIPS-AlexNet), dense fp32 NCHW: gy [B, N, Ho, Wo], w [N, C, K, K] -> [B, C, Hi, Wi] (stylex_conv_image_grad)."""
@@ -1498,8 +1544,15 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True, per_sam
     lib = _ensure_device(dy)
     assert is_cl(dy) and (y is None or (is_cl(y) and y.dtype == dy.dtype))
     b, c, h, w = dy.shape
+    if not per_sample and b > 1:
+        # sums over the samples as well: the NHWC tensor is ONE list of b*h*w pixels, cut into <= 512 block ranges (two blocks
+        # per CU) — the second stage then adds 512 rows instead of b * chunks = 2048 (round 6: 21 -> ~8 us per bias gradient,
+        # 39 of them per step); fixed ranges, fixed order
+        h, b = b * h, 1
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
+    if not per_sample:
+        nch = min(nch, 512)
     partial = _empty((b, nch, c), dtype=torch.float32, device=dy.device)
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
     _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)),

@@ -67,10 +67,9 @@ class LPIPS(nn.Module):
         other four layers (5x5, then three 3x3, each + bias + ReLU in the conv epilogue) run on this library's bf16 MFMA kernels,
         first-order backward included (ops.conv2d fast path).  Returns bf16 channels_last feature maps."""
         import ops
-        from frozen_resnet import first_conv
+        from frozen_resnet import _ReluToCLBf16, first_conv
 
-        t = F.relu(first_conv(x, self.cw[0], self.cb[0], _ALEX[0][3], _ALEX[0][4]))
-        t = t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        t = _ReluToCLBf16.apply(first_conv(x, self.cw[0], self.cb[0], _ALEX[0][3], _ALEX[0][4]))  # relu + cast + layout: one pass
         out = [t]
         prev = ops.set_fast(True)  # first-order gradients only ever flow through the frozen loss network
         try:

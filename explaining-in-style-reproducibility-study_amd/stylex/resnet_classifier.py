@@ -35,7 +35,29 @@ def load_resnet_classifier(model_name, cuda_rank, output_size=2, seed=1234):
     return model.to(_device(cuda_rank))
 
 
+class _ResizeNormalize(torch.autograd.Function):
+    """resize to `size` (bilinear, align_corners=False) + (x - mean) / std as one kernel each way (csrc/frozen_ew.hip,
+    stylex_resize_norm_fwd / _bwd; round 6) — ATen's upsample kernel alone took 140-160 us per call and direction at B = 32.
+    The input is read through its strides: the generator's channels_last batch needs no dense copy first."""
+
+    @staticmethod
+    def forward(ctx, x, size, mean, std):
+        import hip_backend as hb
+
+        ctx.hw, ctx.std = tuple(x.shape[2:]), std
+        return hb.resize_norm_fwd(x, size, mean, std)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        import hip_backend as hb
+
+        return hb.resize_norm_bwd(gy, ctx.hw, ctx.std), None, None, None
+
+
 class ResNet:
+    accepts_any_layout = True  # classify_images reads its input through strides on the GPU (Trainer._classify skips the dense copy)
+
     def __init__(self, model_name, cuda_rank, output_size=2, image_size=32, normalize=True):
         self.model = load_resnet_classifier(model_name, cuda_rank, output_size)
         self.resnet_dim = 224
@@ -50,7 +72,12 @@ class ResNet:
 
     def classify_images(self, images):
         # torchvision 0.11 resize on tensors == bilinear, align_corners=False, no antialias (:61)
-        x = F.interpolate(images, size=[self.resnet_dim, self.resnet_dim], mode="bilinear", align_corners=False)
+        if (images.is_cuda and images.dtype == torch.float32 and images.dim() == 4
+                and os.environ.get("STYLEX_RESIZE_FUSE", "1") != "0"):
+            mean, std = (self._mean.reshape(-1), self._std.reshape(-1)) if self.normalize else (None, None)
+            x = _ResizeNormalize.apply(images, (self.resnet_dim, self.resnet_dim), mean, std)
+            return self._net(x)(x)
+        x = F.interpolate(images.contiguous(), size=[self.resnet_dim, self.resnet_dim], mode="bilinear", align_corners=False)
         if self.normalize:
             x = (x - self._mean) / self._std
         return self._net(x)(x)

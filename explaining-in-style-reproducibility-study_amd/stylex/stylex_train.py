@@ -909,6 +909,8 @@ class Trainer:
         return outs
 
     def _classify(self, images):
+        if images.is_cuda and getattr(self.classifier, "accepts_any_layout", False) and os.environ.get("STYLEX_RESIZE_FUSE", "1") != "0":
+            return self.classifier.classify_images(images)  # the fused resize kernel reads any layout: no dense copy
         return self.classifier.classify_images(_frozen_layout(images))
 
     def _styles_from_encoder(self, batch):

@@ -283,6 +283,25 @@ int stylex_affine_relu_maxpool_fwd(const float* x, const float* scale, const flo
 int stylex_affine_relu_maxpool_bwd(const float* gy, const unsigned char* idx, const float* scale, float* gx, int64_t B, int64_t C,
                                    int64_t H, int64_t W, void* stream);
 
+/* ---- classifier input: bilinear resize + normalisation (round 6) --------------------------------------------------------
+ * ResNet.classify_images (reference stylex/resnet_classifier.py:56-71): torchvision's tensor resize to 224 x 224
+ * (== F.interpolate(mode='bilinear', align_corners=False), no antialias) followed by (x - mean[c]) / std[c], one pass.
+ * sh = {B, C, Hi, Wi, Ho, Wo}; x fp32 read through its element strides {b, c, h, w} (any layout); y dense fp32 NCHW;
+ * mean / stdv [C] or both NULL.  bwd: the exact adjoint (gy dense [B][C][Ho][Wo] -> gx dense [B][C][Hi][Wi], divided by
+ * stdv[c] when given), a gather in fixed order.  Index rule: src = in / out * (dst + 0.5) - 0.5 clamped at 0,
+ * i0 = (int)src, i1 = i0 + (i0 < in - 1), weights (1 - frac, frac). */
+int stylex_resize_norm_fwd(const float* x, float* y, const float* mean, const float* stdv, const int64_t* sh, const int64_t* strides,
+                           void* stream);
+int stylex_resize_norm_bwd(const float* gy, float* gx, const float* stdv, const int64_t* sh, void* stream);
+
+/* ---- layout bridges: the library's dense fp32 NCHW tensors <-> this library's bf16 NHWC tensors (round 6) -------------
+ * Where a frozen network keeps part of its path on the library's fp32 convolutions (the classifier forward, north_star; the
+ * LPIPS stem) and the rest runs on the bf16 kernels: frozen_resnet._ResNetBodyHybrid, lpips_alex._taps_bf16.  C % 8 == 0.
+ *   stylex_nchw_f32_to_nhwc_bf16:  y[b][p][c] = bf16(relu ? max(x[b][c][p], 0) : x[b][c][p])
+ *   stylex_nhwc_bf16_to_nchw_f32:  gx[b][c][p] = float(g[b][p][c]) * (gate == NULL || gate[b][p][c] > 0)   (gate: bf16 NHWC) */
+int stylex_nchw_f32_to_nhwc_bf16(const float* x, void* y, int64_t B, int64_t C, int64_t HW, int relu, void* stream);
+int stylex_nhwc_bf16_to_nchw_f32(const void* g, const void* gate, float* gx, int64_t B, int64_t C, int64_t HW, void* stream);
+
 /* ---- input gradient of a frozen network's first convolution (round 6) ---------------------------
  * The K x K / stride-S stem over the 3-channel image of the frozen classifier (torchvision ResNet conv1: 7 x 7 / 2 / pad 3,
  * reference stylex/resnet_classifier.py:19, 56-71) and of LPIPS-AlexNet (11 x 11 / 4 / pad 2, reference stylex_train.py:404):

@@ -80,6 +80,9 @@ CONV_CASES = [
     (1, 128, 64, 16, 40, 3, 1, 1),    # bf16: 64-channel tiles, 8 chunks, ragged columns (the 128->64 data gradient)
     (2, 64, 192, 31, 31, 5, 1, 2),    # round 6: 5x5 (LPIPS-AlexNet's second layer, bf16 speed mode) on the generic kernel
     (1, 8, 12, 9, 7, 5, 1, 2),        # 5x5, odd sizes, one 8-channel slot
+    (3, 192, 384, 15, 15, 3, 1, 1),   # round 6: 15 x 15 (LPIPS-AlexNet taps) as one partial 16 x 16 tile of the LDS-halo kernel
+    (2, 256, 256, 14, 14, 3, 1, 1),   # 14 x 14 (ResNet-18 layer3)
+    (2, 64, 64, 12, 13, 3, 1, 1),     # the smallest image the halo kernel takes
 ]
 
 
@@ -1702,6 +1705,36 @@ def test_frozen_classifier_bf16_data_gradient(size, monkeypatch):
     assert rel < 3e-2 and cos > 0.999, (rel, cos)
 
 
+@pytest.mark.parametrize("case", [(4, 3, 256, 256, 224, 224, "nchw"), (4, 3, 256, 256, 224, 224, "nhwc"), (2, 3, 32, 32, 224, 224, "nchw"),
+                                  (2, 3, 64, 64, 224, 224, "nhwc"), (2, 4, 40, 56, 33, 97, "nchw"), (1, 3, 224, 224, 224, 224, "nchw"),
+                                  (3, 1, 7, 5, 3, 11, "slice")])
+def test_resize_normalize_kernels_vs_aten(case):
+    """stylex_resize_norm_fwd / _bwd (round 6: the classifier's input path, reference resnet_classifier.py:56-71) against
+    F.interpolate(mode='bilinear', align_corners=False) + (x - mean) / std and their autograd backward: down- and up-scaling,
+    non-square, identity, dense / channels_last / sliced inputs (read through strides).  Same index rule and the same fp32
+    products as ATen's kernel: 1e-6 of the largest element forward, 1e-5 backward (ATen's backward scatters with atomics in
+    another order); a second backward call is bit-identical."""
+    B, C, H, W, Ho, Wo, layout = case
+    g = torch.Generator(device=DEV).manual_seed(61)
+    x = torch.randn(B, C + (2 if layout == "slice" else 0), H, W, device=DEV, generator=g)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    if layout == "slice":
+        x = x[:, 1:1 + C]
+    mean = torch.randn(C, device=DEV, generator=g)
+    std = torch.rand(C, device=DEV, generator=g) + 0.5
+    gy = torch.randn(B, C, Ho, Wo, device=DEV, generator=g)
+    xr = x.detach().clone().requires_grad_()
+    want = (F.interpolate(xr, size=[Ho, Wo], mode="bilinear", align_corners=False) - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
+    (want * gy).sum().backward()
+    got = hb.resize_norm_fwd(x, (Ho, Wo), mean, std)
+    close(want, got, 1e-6, "resize + normalise")
+    gx = hb.resize_norm_bwd(gy, (H, W), std)
+    close(xr.grad, gx, 1e-5, "adjoint")
+    assert torch.equal(gx, hb.resize_norm_bwd(gy, (H, W), std))
+    close(F.interpolate(x, size=[Ho, Wo], mode="bilinear", align_corners=False), hb.resize_norm_fwd(x, (Ho, Wo)), 1e-6, "resize only")
+
+
 def test_resnet_wrapper_vs_reference_golden_on_hip(tmp_path):
     """A16 on the GPU: ResNet.classify_images (the classifier of the headline benchmark configuration) against what
     the REFERENCE's own wrapper class produced (tests/golden/resnet_wrapper.npz from stylex/resnet_classifier.py:29-71
@@ -1797,6 +1830,25 @@ def test_lpips_nhwc_tap_kernels_vs_published_formula(shape):
     assert torch.equal(got, again)
     only1 = hb.lpips_tap_nhwc_bwd(f0, f1, lin, norms[0][0], norms[0][1], gout, False, True)
     assert only1[0] is None and torch.equal(only1[1], g1)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 63, 63), (3, 192, 15, 15), (1, 8, 1, 1), (2, 72, 7, 7), (4, 512, 7, 7), (2, 64, 56, 56)])
+def test_layout_bridge_kernels(shape):
+    """stylex_nchw_f32_to_nhwc_bf16 / stylex_nhwc_bf16_to_nchw_f32 (round 6: the hand-over between the library's fp32 NCHW
+    tensors and this library's bf16 channels_last ones) against the ATen conversions they replace — exact (one rounding to
+    bf16, RNE, as Tensor.to does), with and without the fused ReLU / gate, ragged pixel and channel tiles."""
+    B, C, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(60)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    for relu in (False, True):
+        y = hb.nchw_to_cl_bf16(x, relu=relu)
+        want = (x.relu() if relu else x).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        assert y.dtype == torch.bfloat16 and hb.is_cl(y) and torch.equal(y, want), relu
+    gy = cl(torch.randn(B, C, H, W, device=DEV, generator=g).bfloat16())
+    gate = hb.nchw_to_cl_bf16(x, relu=True)
+    assert torch.equal(hb.cl_bf16_to_nchw(gy), gy.float().contiguous())
+    got = hb.cl_bf16_to_nchw(gy, gate=gate)
+    assert got.is_contiguous() and torch.equal(got, (gy.float() * (x > 0)).contiguous())
 
 
 def test_lpips_bf16_path_tracks_the_fp32_library_path():
