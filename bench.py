@@ -577,7 +577,10 @@ def main(argv=None, backend="nccl", device=None):
                        "rng": ("latents / noise planes drawn on the GPU generator (as every rank of the data-parallel path; "
                                "--device-rng 0 = the reference's CPU draws + upload: -3 %, profiles/r06_d_ab_imagegrad_devrng.txt)")
                               if args.device_rng else "CPU generator draws + upload (reference order)",
-                       "frozen_nets": "stock MIOpen fp32, immediate mode (reference cli.py:38; what a cli.py run uses)"
+                       "frozen_nets": ("classifier forward: stock MIOpen fp32, immediate mode (north_star; reference cli.py:38); in the bf16 "
+                                       "mode its data gradient and LPIPS-AlexNet's layers 2-5 run on this library's bf16 kernels "
+                                       "(frozen_resnet._ResNetBodyHybrid, lpips_alex._taps_bf16; STYLEX_FROZEN_BWD_BF16=0 / "
+                                       "STYLEX_LPIPS_BF16=0: all on MIOpen fp32), outside the roofline classes")
                                       if not args.miopen_find else "stock MIOpen fp32, algorithms searched during the warm-up"},
             "algorithmic_conv_gflop_per_image": round(gf, 1),
             "step_conv_tflops": round(gf * value / 1e3, 2),

