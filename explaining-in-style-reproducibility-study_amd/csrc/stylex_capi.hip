@@ -110,8 +110,10 @@ bool conv_shape_ok(const int64_t* sh) {
     if (B < 1 || Hi < 1 || Wi < 1 || C < 1 || N < 1) return false;
     // 1x1 and 3x3 are the StylEx layers; 5x5 (stride 1) is LPIPS-AlexNet's second layer (round 6: the generic implicit-GEMM
     // kernel gathers any K x K window; every specialised kernel checks its own 3x3 / 1x1 premise)
-    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 5 && KW == 5 && st == 1))) return false;
-    if (st != 1 && st != 2) return false;
+    // ... and 11x11 / stride 4 is its first layer (FORWARD only: the generic kernel's transposed gather knows strides 1 and 2;
+    // stylex_conv_image_grad is that layer's data gradient)
+    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 5 && KW == 5 && st == 1) || (KH == 11 && KW == 11 && st == 4))) return false;
+    if (st != 1 && st != 2 && !(st == 4 && KH == 11)) return false;
     if (Ho != (Hi + 2 * pad - KH) / st + 1 || Wo != (Wi + 2 * pad - KW) / st + 1) return false;
     if (B * Ho * Wo > 0x7fffffff || B * Hi * Wi > 0x7fffffff) return false;
     return true;
@@ -379,7 +381,7 @@ int stylex_conv2d_s2d_res_fwd(const void* x_s2d, const void* w_fwd_s2d, const vo
 int stylex_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, const int64_t* sh, int flags,
                            const stylex_conv_epilogue* epi, int precision, void* workspace, int64_t workspace_bytes,
                            void* stream) {
-    if (!dy || !w_bwd || !dx || !conv_shape_ok(sh)) return STYLEX_EINVAL;
+    if (!dy || !w_bwd || !dx || !conv_shape_ok(sh) || sh[7] > 2) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
     if (flags & ~(STYLEX_EPI_OSCALE | STYLEX_EPI_GATE | STYLEX_EPI_GATE_MASK)) return STYLEX_EINVAL;
     if ((flags & STYLEX_EPI_GATE) && (!epi || !epi->residual)) return STYLEX_EINVAL;
@@ -502,7 +504,7 @@ int stylex_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw, float*
                                 int s2d_c, float out_scale, int accumulate, int precision, void* stream) {
     if (db_written) *db_written = 0;
     if (db && !db_written) return STYLEX_EINVAL;
-    if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh)) return STYLEX_EINVAL;
+    if (!x || !dy || !dw || !workspace || !conv_shape_ok(sh) || sh[7] > 2) return STYLEX_EINVAL;
     if (precision != STYLEX_F32 && precision != STYLEX_BF16 && precision != STYLEX_BF16_ACT) return STYLEX_EINVAL;
     if (workspace_bytes < stylex_conv2d_bwd_weight_workspace_bytes(sh)) return STYLEX_EWORKSPACE;
     ConvKParams p;

@@ -138,6 +138,35 @@ class _ReluToCLBf16(torch.autograd.Function):
         return hb.cl_bf16_to_nchw(gy.contiguous(memory_format=torch.channels_last), gate=y)
 
 
+class _StemBf16(torch.autograd.Function):
+    """relu(conv2d(x, w, b, stride, pad)) of a frozen stem over the 3-channel image in the bf16 speed mode, bf16 channels_last
+    out (round 6, LPIPS-AlexNet's 11x11 / 4 layer): the image is cast + padded to one 16-byte channel slot (stylex_pad_rgb8)
+    and the layer runs on the generic implicit-GEMM kernel with tap-major K (121 taps x 8 channels), bias + ReLU in its epilogue;
+    backward = bridge kernel (bf16 NHWC -> fp32 NCHW, gated by the output's sign) + stylex_conv_image_grad.  Why not the
+    library: its immediate mode serves this layer with an NHWC implicit-GEMM kernel on some boxes (90 us per 32 images) and with a
+    per-image im2col + GEMM on others (64 launches, 1.9 ms per step: profiles/r06_p_steady_state_kernels.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        P = hb.BF16_ACT
+        xp = hb.pad_rgb8(x)
+        wp = hb.pad_in_channels(w, 8 - w.shape[1])
+        owner = w if isinstance(w, torch.nn.Parameter) else None
+        packed = hb.pack_weight(wp, True, False, P, owner=owner)[0]
+        y = hb.conv2d_fwd(xp, wp, stride, pad, P, bias=bias, lrelu="relu", packed=packed, w_shape=tuple(wp.shape))
+        ctx.save_for_backward(y, w)
+        ctx.cfg = (stride, pad, tuple(x.shape[2:]))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        y, w = ctx.saved_tensors
+        stride, pad, hw = ctx.cfg
+        g = hb.cl_bf16_to_nchw(gy.contiguous(memory_format=torch.channels_last), gate=y)
+        return hb.conv_image_grad(g, w, hw, stride, pad), None, None, None, None
+
+
 class _AffineAct(torch.autograd.Function):
     """act(x * scale[c] + shift[c] (+ residual)): `bn -> relu` / `bn -> (+ identity) -> relu` of a BasicBlock
     (torchvision resnet.py BasicBlock.forward) in one pass; first-order backward to x and the residual."""

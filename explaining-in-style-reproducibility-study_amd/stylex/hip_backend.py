@@ -1545,15 +1545,18 @@ def act_bwd_reduce(dy, y, lrelu, scale=1.0, want_dx=True, want_sum=True, per_sam
     lib = _ensure_device(dy)
     assert is_cl(dy) and (y is None or (is_cl(y) and y.dtype == dy.dtype))
     b, c, h, w = dy.shape
-    if not per_sample and b > 1:
-        # sums over the samples as well: the NHWC tensor is ONE list of b*h*w pixels, cut into <= 512 block ranges (two blocks
-        # per CU) — the second stage then adds 512 rows instead of b * chunks = 2048 (round 6: 21 -> ~8 us per bias gradient,
-        # 39 of them per step); fixed ranges, fixed order
+    flat = not per_sample and b > 1
+    if flat:
+        # sums over the samples as well: the NHWC tensor is ONE list of b*h*w pixels cut into block ranges of >= 64 KB —
+        # 2048 ranges for the 256^2 tensors (the pass is HBM-bound: it needs the blocks), as few as 64 for the small ones, whose
+        # second stage then adds 64 rows instead of b * chunks (round 6; a flat cap of 512 ranges made the large passes 1.7x
+        # slower: profiles/r06_p_steady_state_kernels.txt); fixed ranges, fixed order
+        nbytes = b * h * w * c * dy.element_size()
         h, b = b * h, 1
     shp = _shape(b, h, w, c)
     nch = lib.stylex_reduce_chunks(shp)
-    if not per_sample:
-        nch = min(nch, 512)
+    if flat:
+        nch = max(1, min(nch, max(64, -(-nbytes // (64 * 1024)))))
     partial = _empty((b, nch, c), dtype=torch.float32, device=dy.device)
     dx = empty_cl(tuple(dy.shape), dy) if want_dx else None
     _check(lib.stylex_act_bwd_reduce(_ptr(dy), _ptr(y), _ptr(dx), _ptr(partial), shp, nch, 2 if lrelu == "relu" else int(bool(lrelu)),

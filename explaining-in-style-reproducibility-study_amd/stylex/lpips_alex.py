@@ -62,15 +62,19 @@ class LPIPS(nn.Module):
         return out
 
     def _taps_bf16(self, x):
-        """The five taps in the bf16 speed mode (round 6): the stem stays on the library's fp32 convolution (forward) with its
-        input gradient on csrc/frozen_ew.hip's image-gradient kernel; its ReLU output is cast once to bf16 channels_last and the
-        other four layers (5x5, then three 3x3, each + bias + ReLU in the conv epilogue) run on this library's bf16 MFMA kernels,
+        """The five taps in the bf16 speed mode (round 6): the stem on the generic implicit-GEMM kernel over the image padded to
+        8 channels (its input gradient: csrc/frozen_ew.hip's image-gradient kernel; STYLEX_LPIPS_STEM=0: the library's fp32
+        forward + one bridge kernel), the other four layers (5x5, then three 3x3, each + bias + ReLU in the conv epilogue) run on this library's bf16 MFMA kernels,
         first-order backward included (ops.conv2d fast path).  Returns bf16 channels_last feature maps."""
         import hip_backend as hb
         import ops
-        from frozen_resnet import _ReluToCLBf16, first_conv
+        from frozen_resnet import _ReluToCLBf16, _StemBf16, first_conv
 
-        t = _ReluToCLBf16.apply(first_conv(x, self.cw[0], self.cb[0], _ALEX[0][3], _ALEX[0][4]))  # relu + cast + layout: one pass
+        if os.environ.get("STYLEX_LPIPS_STEM", "1") != "0":  # the stem on the generic bf16 kernel (see _StemBf16: why)
+            with hb.timing_pause():
+                t = _StemBf16.apply(x, self.cw[0], self.cb[0], _ALEX[0][3], _ALEX[0][4])
+        else:  # library forward; relu + cast + layout in one pass
+            t = _ReluToCLBf16.apply(first_conv(x, self.cw[0], self.cb[0], _ALEX[0][3], _ALEX[0][4]))
         out = [t]
         prev = ops.set_fast(True)  # first-order gradients only ever flow through the frozen loss network
         try:

@@ -1883,6 +1883,34 @@ def test_timing_pause_keeps_frozen_network_launches_out_of_the_classes():
         ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("case", [(4, 64, 11, 4, 2, 256, 256), (2, 64, 11, 4, 2, 97, 130), (3, 24, 11, 4, 2, 64, 64)])
+def test_bf16_stem_on_the_generic_kernel(case):
+    """frozen_resnet._StemBf16 (round 6: LPIPS-AlexNet's 11x11 / stride-4 layer in the bf16 mode on the generic implicit-GEMM
+    kernel, image padded to one 8-channel slot, bias + ReLU epilogue) against relu(conv2d) in float64 on the same bf16-rounded
+    image and weights (1e-2: fp32 accumulation of 363 products + one bf16 rounding of the output), and its input gradient
+    (bridge kernel + stylex_conv_image_grad) against autograd through the fp64 definition gated by the kernel's own output."""
+    from frozen_resnet import _StemBf16
+
+    B, N, K, S, pad, H, W = case
+    ops.set_precision("bf16")
+    g = torch.Generator(device=DEV).manual_seed(63)
+    x = torch.randn(B, 3, H, W, device=DEV, generator=g)
+    w = torch.randn(N, 3, K, K, device=DEV, generator=g) / (3 * K * K) ** 0.5
+    b = torch.randn(N, device=DEV, generator=g) * 0.1
+    xa = x.clone().requires_grad_()
+    y = _StemBf16.apply(xa, w, b, S, pad)
+    assert y.dtype == torch.bfloat16 and hb.is_cl(y)
+    xr = x.to(torch.bfloat16).double().requires_grad_()
+    yr = F.relu(F.conv2d(xr, w.to(torch.bfloat16).double(), b.double(), S, pad))
+    close(yr, y, 1e-2, "stem forward")
+    gy = cl(torch.randn(*y.shape, device=DEV, generator=g).bfloat16())
+    y.backward(gy)
+    # the reference gradient with the gate of the KERNEL's output (a pre-activation within rounding of zero may differ in sign)
+    z = F.conv2d(xr, w.double(), b.double(), S, pad)  # fp32 weights in the data gradient, as stylex_conv_image_grad uses them
+    (z * (gy.double() * (y.double() > 0))).sum().backward()
+    close(xr.grad, xa.grad, 2e-5, "stem input gradient")
+
+
 def test_lpips_bf16_path_tracks_the_fp32_library_path():
     """LPIPS-AlexNet in the bf16 speed mode (round 6, stylex/lpips_alex.py::_taps_bf16: stem on the library + image-gradient
     kernel, the 5x5 and the three 3x3 layers on this library's bf16 conv kernels, taps as bf16 channels_last) against the
