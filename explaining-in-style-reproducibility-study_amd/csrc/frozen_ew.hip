@@ -567,6 +567,25 @@ __global__ __launch_bounds__(256) void resize_norm_bwd_kernel(const float* __res
     }
 }
 
+// out = (y > 0) ? a + b : 0 on bf16 NHWC tensors (b may be NULL): the ReLU gate of a BasicBlock's output applied to the sum of the
+// two gradients that reach it (conv path + identity path) — one pass instead of an add and a gating pass (round 6)
+__global__ __launch_bounds__(256) void relu_gate_add_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                            const uint4* __restrict__ y, uint4* __restrict__ out, unsigned total) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        float va[8], vb[8], vy[8];
+        lp_unpack8(a[i], va);
+        lp_unpack8(y[i], vy);
+        if (b) {
+            lp_unpack8(b[i], vb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) va[e] += vb[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) va[e] = vy[e] > 0.f ? va[e] : 0.f;
+        out[i] = make_uint4(lp_pack2(va[0], va[1]), lp_pack2(va[2], va[3]), lp_pack2(va[4], va[5]), lp_pack2(va[6], va[7]));
+    }
+}
+
 // ---- input gradient of a frozen network's FIRST convolution (round 6) -------------------------------------------------------
 // dx[b][c][ih][iw] = sum_n sum_{kh,kw} dy[b][n][(ih + pad - kh) / S][(iw + pad - kw) / S] * w[n][c][kh][kw]   (exact divisions only)
 // for the K x K / stride-S stems whose input is the 3-channel image: ResNet conv1 (7 x 7, stride 2, pad 3; torchvision
@@ -651,6 +670,90 @@ __global__ __launch_bounds__(256) void conv_image_grad_kernel(const float* __res
             if (C > 1) o[(size_t)Hi * Wi] = acc[p][1];
             if (C > 2) o[(size_t)2 * Hi * Wi] = acc[p][2];
             if (C > 3) o[(size_t)3 * Hi * Wi] = acc3[p];
+        }
+    }
+}
+
+// Register-tiled version (round 6, fourth): per (tap column u, 4 output channels) a thread holds the NT + 3 dy rows its four pixels
+// can touch and the NT tap weights of those channels in registers — 4 pixels x NT taps x 4 channels x 3 image channels = 144-192 FMAs
+// per 24-28 global loads and 12-16 LDS broadcasts (version 3 re-read a weight from LDS for every 3 FMAs, which was its whole cost).
+// NT = ceil(K / S) taps per axis at most (<= 4: 11 x 11 / 4 -> 3, 7 x 7 / 2 -> 4); a residue class with fewer taps has zero weights
+// in the LDS image for the missing ones.
+template <int S, int NT>
+__global__ __launch_bounds__(256) void conv_image_grad_rt_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int N, int Ho, int Wo, int C, int K, int pad,
+                                                                 int Hi, int Wi, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [tap u][tap t < NT][n (padded to 4)][4]
+    const int rh = blockIdx.y / S, rw = blockIdx.y - rh * S;
+    const int nth = (K - rh + S - 1) / S, ntw = (K - rw + S - 1) / S;
+    const int N4 = (N + 3) & ~3;
+    for (int e = threadIdx.x; e < ntw * NT * N4 * 4; e += 256) {
+        const int c = e & 3, n = (e >> 2) % N4, tap = (e >> 2) / N4;
+        const int u = tap / NT, t = tap - u * NT;
+        wl[e] = (c < C && n < N && t < nth) ? w[((size_t)(n * C + c) * K + (rh + S * t)) * K + (rw + S * u)] : 0.f;
+    }
+    __syncthreads();
+    const int ih0 = ((rh - pad) % S + S) % S, iw0 = ((rw - pad) % S + S) % S;
+    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    const int i0 = (th * 4 + (threadIdx.x >> 6)) * IG_PX, j = tw * 64 + (threadIdx.x & 63);
+    const int iw = iw0 + S * j;
+    const bool okw = iw < Wi;
+    const int qh0 = (ih0 + S * i0 + pad) / S, qw = (iw + pad) / S;
+    const int b = blockIdx.z;
+    const size_t plane = (size_t)Ho * Wo;
+    const float* dyb = dy + (size_t)b * N * plane;
+    constexpr int ROWS = NT + IG_PX - 1;
+    float acc[IG_PX][4];
+#pragma unroll
+    for (int p = 0; p < IG_PX; ++p) acc[p][0] = acc[p][1] = acc[p][2] = acc[p][3] = 0.f;
+    // row r of the window is dy row oh = qh0 - (NT - 1) + r; it reaches pixel p through tap t = p + NT - 1 - r
+    long roff[ROWS];
+    bool rok[ROWS];
+    for (int u = 0; u < ntw; ++u) {
+        const int ow = qw - u;
+        const bool livew = okw && ow >= 0 && ow < Wo;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int oh = qh0 - (NT - 1) + r;
+            rok[r] = livew && oh >= 0 && oh < Ho;
+            roff[r] = rok[r] ? (long)oh * Wo + ow : 0;
+        }
+        const float4* wu = reinterpret_cast<const float4*>(wl) + (size_t)u * NT * N4;
+        for (int n0 = 0; n0 < N4; n0 += 4) {
+            float g[ROWS][4];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) g[r][v] = (rok[r] && n0 + v < N) ? dyb[(size_t)(n0 + v) * plane + roff[r]] : 0.f;
+            float4 wv[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) wv[t][v] = wu[(size_t)t * N4 + n0 + v];  // one address per wave: LDS broadcasts
+#pragma unroll
+            for (int p = 0; p < IG_PX; ++p)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int r = p + NT - 1 - t;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        acc[p][0] = fmaf(g[r][v], wv[t][v].x, acc[p][0]);
+                        acc[p][1] = fmaf(g[r][v], wv[t][v].y, acc[p][1]);
+                        acc[p][2] = fmaf(g[r][v], wv[t][v].z, acc[p][2]);
+                        acc[p][3] = fmaf(g[r][v], wv[t][v].w, acc[p][3]);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < IG_PX; ++p) {
+        const int ih = ih0 + S * (i0 + p);
+        if (okw && ih < Hi) {
+            float* o = dx + ((size_t)b * C * Hi + ih) * Wi + iw;
+            o[0] = acc[p][0];
+            if (C > 1) o[(size_t)Hi * Wi] = acc[p][1];
+            if (C > 2) o[(size_t)2 * Hi * Wi] = acc[p][2];
+            if (C > 3) o[(size_t)3 * Hi * Wi] = acc[p][3];
         }
     }
 }
@@ -757,9 +860,23 @@ int stylex_conv_image_grad(const float* dy, const float* w, float* dx, const int
     const int ch = (int)((Hi + S - 1) / S), cw = (int)((Wi + S - 1) / S);  // pixels of a residue class along each axis (at most)
     const int tiles_h = (ch + 4 * IG_PX - 1) / (4 * IG_PX), tiles_w = (cw + 63) / 64;
     const dim3 grid((unsigned)(tiles_h * tiles_w), (unsigned)(S * S), (unsigned)B);
-    const int64_t max_taps = ((K + S - 1) / S) * ((K + S - 1) / S);
-    const size_t smem = (size_t)(max_taps * N * 4 * sizeof(float));  // the largest residue class's weights
+    const int64_t nt = (K + S - 1) / S, max_taps = nt * nt;
+    const size_t smem = (size_t)(max_taps * ((N + 3) & ~3) * 4 * sizeof(float));  // the largest residue class's weights
     if (smem > 64 * 1024) return STYLEX_EINVAL;
+    if (nt <= 4 && nt >= 2) {  // register-tiled kernel (the two frozen stems: 11 x 11 / 4 -> 3 taps per axis, 7 x 7 / 2 -> 4)
+        const size_t smem_rt = (size_t)(nt * 4 * ((N + 3) & ~3) * 4 * sizeof(float));  // [<= nt tap columns][NT <= 4][N4][4]
+#define STYLEX_IMG_GRAD_RT(SS, NTT)                                                                                              \
+    hipLaunchKernelGGL((conv_image_grad_rt_kernel<SS, NTT>), grid, dim3(256), smem_rt, (hipStream_t)stream, dy, w, dx, (int)N, (int)Ho, \
+                       (int)Wo, (int)C, (int)K, (int)pad, (int)Hi, (int)Wi, tiles_w)
+        if (S == 4 && nt == 3) STYLEX_IMG_GRAD_RT(4, 3);
+        else if (S == 4) STYLEX_IMG_GRAD_RT(4, 4);
+        else if (S == 2 && nt == 4) STYLEX_IMG_GRAD_RT(2, 4);
+        else if (S == 2) STYLEX_IMG_GRAD_RT(2, 3);
+        else if (S == 1 && nt == 3) STYLEX_IMG_GRAD_RT(1, 3);
+        else STYLEX_IMG_GRAD_RT(1, 4);
+#undef STYLEX_IMG_GRAD_RT
+        return (int)hipGetLastError();
+    }
 #define STYLEX_IMG_GRAD(SS)                                                                                                        \
     hipLaunchKernelGGL(conv_image_grad_kernel<SS>, grid, dim3(256), smem, (hipStream_t)stream, dy, w, dx, (int)N, (int)Ho, (int)Wo, \
                        (int)C, (int)K, (int)pad, (int)Hi, (int)Wi, tiles_w)
@@ -835,6 +952,16 @@ int stylex_resize_norm_bwd(const float* gy, float* gx, const float* stdv, const 
     if (total > 0x7fffffffLL || sh[0] * sh[1] * sh[4] * sh[5] > 0x7fffffffLL) return STYLEX_EINVAL;
     hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3(grid_for((unsigned long)total)), dim3(256), 0, (hipStream_t)stream, gy, gx, stdv,
                        (int)sh[1], (int)sh[2], (int)sh[3], (int)sh[4], (int)sh[5], (unsigned)total);
+    return (int)hipGetLastError();
+}
+
+int stylex_relu_gate_add(const void* a, const void* b, const void* y, void* out, int64_t numel, void* stream) {
+    if (!a || !y || !out || numel < 8 || numel % 8 || numel > 0x7fffffffLL * 8) return STYLEX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15)
+        return STYLEX_EINVAL;
+    const unsigned total = (unsigned)(numel / 8);
+    hipLaunchKernelGGL(relu_gate_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
+                       (const uint4*)y, (uint4*)out, total);
     return (int)hipGetLastError();
 }
 

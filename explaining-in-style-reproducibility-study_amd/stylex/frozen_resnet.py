@@ -90,7 +90,7 @@ def _affine(bn):
 class _FirstConv(torch.autograd.Function):
     """The stem of a frozen network over the image (ResNet conv1 7x7/2, LPIPS-AlexNet 11x11/4): forward = the library's
     convolution, untouched; backward = csrc/frozen_ew.hip conv_image_grad_kernel instead of the library's dense transposed
-    convolution (round 6: 0.67-0.75 ms -> ~0.1 ms per call at B = 32; same fp32 arithmetic, fixed order)."""
+    convolution (round 6: 0.47 / 0.52 ms -> 0.25 / 0.38 ms per call at B = 32; same fp32 arithmetic, fixed order)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad):
@@ -108,13 +108,13 @@ class _FirstConv(torch.autograd.Function):
 
 def first_conv(x, w, bias, stride, pad):
     """conv2d of a frozen stem; the input gradient on the image-gradient kernel where it applies (GPU, fp32, <= 4 image
-    channels, stride 4, frozen weights).  STYLEX_IMAGE_GRAD=0: plain F.conv2d."""
+    channels, stride 1 / 2 / 4, frozen weights).  STYLEX_IMAGE_GRAD=0: plain F.conv2d."""
     import os
 
-    # stride 4 only by default (LPIPS-AlexNet's stem: 0.33 ms against the library's 0.47 at B = 32); at stride 2 (ResNet conv1) the
-    # kernel runs at the library's speed or below (0.58 vs 0.52 ms: profiles/r06_e_probe_first_conv.txt) — STYLEX_IMAGE_GRAD=2 takes both
+    # (register-tiled kernel, alone on the GPU at B = 32: 0.25 ms against the library's 0.47 at stride 4, 0.38 against 0.52 at stride 2:
+    # profiles/r06_s_probe_first_conv.txt; the first three versions ran at 1.2, 0.5 and 0.33 / 0.58 ms)
     mode = os.environ.get("STYLEX_IMAGE_GRAD", "1")
-    if (x.is_cuda and x.requires_grad and x.dtype == torch.float32 and x.shape[1] <= 4 and (stride == 4 or (mode == "2" and stride in (1, 2)))
+    if (x.is_cuda and x.requires_grad and x.dtype == torch.float32 and x.shape[1] <= 4 and stride in (1, 2, 4)
             and w.shape[2] == w.shape[3] <= 15 and pad < w.shape[2] and not w.requires_grad
             and (bias is None or not bias.requires_grad) and mode != "0"):
         return _FirstConv.apply(x, w, bias, stride, pad)
@@ -339,16 +339,16 @@ class _ResNetBodyHybrid(torch.autograd.Function):
 
     @staticmethod
     def _chain(ctx, plan, saved, g, P):
+        ga, gb = g, None  # the gradients reaching a block's output: through the next block's conv path / its identity path
         for k in range(len(plan) - 1, -1, -1):
             e, h, out = plan[k], saved[2 * k], saved[2 * k + 1]
             x_shape, h_shape = ctx.shapes[k]
-            gz = hb.act_bwd_reduce(g, out, "relu", 1.0, want_dx=True, want_sum=False)[0]  # d relu(. + identity)
+            gz = hb.relu_gate_add(ga, gb, out)  # d relu(. + identity) of the sum of both, one pass
             if "wd" in e:  # 1x1 / stride-2 projection: a 1x1 / stride-1 data gradient over the even pixels, zero-inserted
                 half = (x_shape[0], x_shape[1], gz.shape[2], gz.shape[3])
                 g_idt = hb.subsample2_bwd(hb.conv2d_bwd_data(gz, e["wd"], half, 1, 0, P), (x_shape[2], x_shape[3]))
             else:
                 g_idt = gz
             gh = hb.conv2d_bwd_data(gz, e["w2"], h_shape, 1, 1, P, gate=h, gate_slope=0.0)  # + d relu of conv1's output
-            gx = hb.conv2d_bwd_data(gh, e["w1"], x_shape, e["stride"], 1, P)
-            g = gx + g_idt
-        return g
+            ga, gb = hb.conv2d_bwd_data(gh, e["w1"], x_shape, e["stride"], 1, P), g_idt
+        return ga + gb

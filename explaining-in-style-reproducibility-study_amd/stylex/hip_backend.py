@@ -121,6 +121,7 @@ SIGNATURES = {
     "stylex_nhwc_bf16_to_nchw_f32": (ctypes.c_int, [_c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_resize_norm_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, _i64p, ctypes.c_void_p]),
     "stylex_resize_norm_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_relu_gate_add": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_void_p]),
     "stylex_conv_image_grad": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_lpips_tap_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p]),
@@ -1050,6 +1051,16 @@ def resize_norm_bwd(gy, in_hw, std=None):
     _check(lib.stylex_resize_norm_bwd(_ptr(gy), _ptr(gx), _ptr(std), _shape(b, c, int(in_hw[0]), int(in_hw[1]), ho, wo), _stream()),
            "stylex_resize_norm_bwd")
     return gx
+
+
+def relu_gate_add(a, b, y):
+    """(y > 0) ? a + b : 0 for bf16 channels_last tensors of one shape (b may be None), one pass (stylex_relu_gate_add)."""
+    lib = _ensure_device(a)
+    assert a.dtype == torch.bfloat16 and is_cl(a) and is_cl(y) and y.shape == a.shape and y.dtype == a.dtype
+    assert b is None or (is_cl(b) and b.shape == a.shape and b.dtype == a.dtype)
+    out = torch.empty_like(a)
+    _check(lib.stylex_relu_gate_add(_ptr(a), _ptr(b), _ptr(y), _ptr(out), a.numel(), _stream()), "stylex_relu_gate_add")
+    return out
 
 
 def nchw_to_cl_bf16(x, relu=False):

@@ -194,16 +194,29 @@ class GeneratorBlock(nn.Module):  # reference :670-718
         way instead of mutating `to_style*.bias` in place as the reference notebook does."""
         if exists(self.upsample):
             x = self.upsample(x)
-        style1, style2 = styles if styles is not None else (self.to_style1(istyle), self.to_style2(istyle))
+        coords = None
+        self._rgb_style = None
+        if styles is None:
+            # the block's three affine style maps as one GEMM (ops._StyleAffines); the first two column blocks ARE the
+            # block's style coordinates (reference :716: cat(style1, style2)), the third is handed to to_rgb
+            fused = ops.style_affines(istyle, self.to_style1, self.to_style2, self.to_rgb.to_style, self.__dict__.setdefault("_aff_cache", {}))
+            if fused is not None:
+                c1, c2 = self.input_channels, self.filters
+                style1, style2, coords = fused[:, :c1], fused[:, c1:c1 + c2], fused[:, :c1 + c2]
+                self._rgb_style = fused[:, c1 + c2:]
+            else:
+                style1, style2 = self.to_style1(istyle), self.to_style2(istyle)
+        else:
+            style1, style2 = styles
         x = ops.modconv_noise_act(x, style1, self.conv1.weight, inoise, self.to_noise1.weight[:, 0],
                                   self.to_noise1.bias, demod=self.conv1.demod, eps=self.conv1.eps)
         x = ops.modconv_noise_act(x, style2, self.conv2.weight, inoise, self.to_noise2.weight[:, 0],
                                   self.to_noise2.bias, demod=self.conv2.demod, eps=self.conv2.eps)
-        return x, torch.cat([style1, style2], dim=-1)
+        return x, (coords if coords is not None else torch.cat([style1, style2], dim=-1))
 
     def forward(self, x, prev_rgb, istyle, inoise):
         x, coords = self.forward_main(x, istyle, inoise)
-        rgb = self.to_rgb(x, prev_rgb, istyle)
+        rgb = self.to_rgb(x, prev_rgb, istyle, style=self.__dict__.pop("_rgb_style", None))
         return x, rgb, coords
 
 
@@ -296,7 +309,7 @@ class Generator(nn.Module):  # reference :747-825
             for li, block in enumerate(self.blocks):
                 x, sc = block.forward_main(x, per_layer[li], input_noise)
                 coords.append(sc)
-                rgb = block.to_rgb(x, rgb, per_layer[li], padded=True)
+                rgb = block.to_rgb(x, rgb, per_layer[li], style=block.__dict__.pop("_rgb_style", None), padded=True)
         else:
             main = torch.cuda.current_stream()
             # (measured and dropped: evaluating all blocks' style affines / demod coefficients ahead on a second
@@ -304,7 +317,9 @@ class Generator(nn.Module):  # reference :747-825
             for li, block in enumerate(self.blocks):
                 x, sc = block.forward_main(x, styles[:, li], input_noise)
                 coords.append(sc)
-                rgb_style = block.to_rgb.to_style(styles[:, li])  # the GEMMs stay on `main` (see below)
+                rgb_style = block.__dict__.pop("_rgb_style", None)
+                if rgb_style is None:
+                    rgb_style = block.to_rgb.to_style(styles[:, li])  # the GEMMs stay on `main` (see below)
                 side.wait_stream(main)  # x is ready
                 x.record_stream(side)
                 rgb_style.record_stream(side)

@@ -1293,6 +1293,55 @@ def equal_linear(x, weight, bias, lr_mul, slope=None):
     return y if slope is None else F.leaky_relu(y, slope)
 
 
+class _StyleAffines(torch.autograd.Function):
+    """The three affine style maps of a GeneratorBlock on ONE input — to_style1, to_style2 and to_rgb.to_style (reference
+    :682-688, :609: three nn.Linear(latent, C) applied to the block's style vector) — as one GEMM each way over the
+    concatenated weights (round 6).  Separately they are 3 addmm forward and, backward, 3 data-gradient GEMMs whose results
+    the engine sums with two add_ launches, 3 weight-gradient GEMMs and 3 bias sums: 14 launches per block and pass, all on
+    the generator's serial chain; here 1 forward (the concatenated weight is cached per parameter stamp) and 4 backward.
+    The parameters stay the reference's three modules (state dict, AttFind's in-place bias edits)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, cache):
+        stamp = tuple(hb._gen(t) for t in (w1, b1, w2, b2, w3, b3))
+        hit = cache.get("cat")
+        if hit is None or hit[0] != stamp or hit[1].device != x.device:
+            hit = (stamp, torch.cat((w1.detach(), w2.detach(), w3.detach()), dim=0), torch.cat((b1.detach(), b2.detach(), b3.detach())))
+            cache["cat"] = hit
+        wcat, bcat = hit[1], hit[2]
+        y = torch.addmm(bcat, x, wcat.t())
+        ctx.save_for_backward(x, wcat)
+        ctx.sizes = (w1.shape[0], w2.shape[0], w3.shape[0])
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, wcat = ctx.saved_tensors
+        n1, n2, n3 = ctx.sizes
+        need = ctx.needs_input_grad
+        gy = gy.contiguous()
+        gx = gy @ wcat if need[0] else None
+        gws = gbs = (None, None, None)
+        if any(need[1:7]):
+            gws = (gy.t() @ x).split((n1, n2, n3), dim=0)  # row blocks of one matrix: contiguous tensors
+            gbs = gy.sum(dim=0).split((n1, n2, n3))
+        return (gx, gws[0] if need[1] else None, gbs[0] if need[2] else None, gws[1] if need[3] else None,
+                gbs[1] if need[4] else None, gws[2] if need[5] else None, gbs[2] if need[6] else None, None)
+
+
+def style_affines(istyle, lin1, lin2, lin3, cache):
+    """[to_style1(w) | to_style2(w) | to_rgb.to_style(w)] as one [B, C1 + C2 + C3] tensor (the fused node above), or None
+    when the composable path must run (CPU double, double backward, non-fp32 / non-2D input)."""
+    if not (_IMPL is HipOps and istyle.is_cuda and istyle.dim() == 2 and fast_enabled() and istyle.dtype == torch.float32
+            and os.environ.get("STYLEX_STYLE_FUSE", "1") != "0"):
+        return None
+    for lin in (lin1, lin2, lin3):
+        if lin.bias is None or lin.weight.dtype != torch.float32:
+            return None
+    return _StyleAffines.apply(istyle, lin1.weight, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias, cache)
+
+
 class _ModCoeffs(torch.autograd.Function):
     """(style + 1, demodulation coefficient) of a modulated conv as ONE launch (csrc/style_coeffs.hip; `wsq`, the
     weight-only factor, is cached per parameter version) with a two-launch first-order backward — the ATen composition

@@ -299,6 +299,9 @@ int stylex_resize_norm_bwd(const float* gy, float* gx, const float* stdv, const 
  * LPIPS stem) and the rest runs on the bf16 kernels: frozen_resnet._ResNetBodyHybrid, lpips_alex._taps_bf16.  C % 8 == 0.
  *   stylex_nchw_f32_to_nhwc_bf16:  y[b][p][c] = bf16(relu ? max(x[b][c][p], 0) : x[b][c][p])
  *   stylex_nhwc_bf16_to_nchw_f32:  gx[b][c][p] = float(g[b][p][c]) * (gate == NULL || gate[b][p][c] > 0)   (gate: bf16 NHWC) */
+/* out = (y > 0) ? a + b : 0, bf16 tensors of `numel` elements in the same (any) layout, numel % 8 == 0, b may be NULL: the ReLU
+ * gate of a residual block's output applied to the sum of the gradients of its two consumers (frozen_resnet._ResNetBodyHybrid). */
+int stylex_relu_gate_add(const void* a, const void* b, const void* y, void* out, int64_t numel, void* stream);
 int stylex_nchw_f32_to_nhwc_bf16(const float* x, void* y, int64_t B, int64_t C, int64_t HW, int relu, void* stream);
 int stylex_nhwc_bf16_to_nchw_f32(const void* g, const void* gate, float* gx, int64_t B, int64_t C, int64_t HW, void* stream);
 

@@ -1472,6 +1472,52 @@ def test_modcoeff_kernels_vs_torch_composition(shape):
     close(r1, sd2.grad, 1e-6, "grad style via s1 only")
 
 
+def test_style_affines_fused_node_vs_three_linears():
+    """ops._StyleAffines (round 6): to_style1 / to_style2 / to_rgb.to_style of a GeneratorBlock as one GEMM each way against the
+    three nn.Linear modules (reference stylex_train.py:682-688, :609) — outputs, the gradient to the style vector and all six
+    parameter gradients in fp32 (only the summation order of the style-vector gradient changes: 1e-6); the concatenated weight
+    is rebuilt after an in-place edit of a bias (AttFind's procedure) and after an optimiser-style stamp."""
+    torch.manual_seed(21)
+    blk = st.GeneratorBlock(514, 64, 32).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(64)
+    w = torch.randn(6, 514, device=DEV, generator=g)
+    r = torch.randn(6, 64 + 32 + 32, device=DEV, generator=g)
+    lins = (blk.to_style1, blk.to_style2, blk.to_rgb.to_style)
+
+    def fused():
+        wa = w.clone().requires_grad_()
+        prev = ops.set_fast(True)
+        try:
+            y = ops.style_affines(wa, *lins, blk.__dict__.setdefault("_aff_cache", {}))
+        finally:
+            ops.set_fast(prev)
+        assert y is not None
+        blk.zero_grad()
+        (y * r).sum().backward()
+        return y.detach(), wa.grad, [p.grad.clone() for lin in lins for p in (lin.weight, lin.bias)]
+
+    def plain():
+        wb = w.clone().requires_grad_()
+        y = torch.cat([lin(wb) for lin in lins], dim=1)
+        blk.zero_grad()
+        (y * r).sum().backward()
+        return y.detach(), wb.grad, [p.grad.clone() for lin in lins for p in (lin.weight, lin.bias)]
+
+    for edit in (None, "bias", "stamp"):
+        if edit == "bias":
+            with torch.no_grad():
+                blk.to_style2.bias[3] += 1.5
+        if edit == "stamp":
+            with torch.no_grad():
+                blk.to_style1.weight.data.mul_(1.01)  # a raw-kernel style update: no version bump ...
+            hb.mark_updated([blk.to_style1.weight])  # ... but the stamp the Trainer sets after every optimiser step
+        (ya, ga, pa), (yb, gb, pb) = fused(), plain()
+        close(yb, ya, 1e-6, "outputs (%s)" % edit)
+        close(gb, ga, 1e-6, "style-vector gradient (%s)" % edit)
+        for a, b_ in zip(pa, pb):
+            close(b_, a, 1e-6, "parameter gradient (%s)" % edit)
+
+
 def test_mapping_network_fused_node_vs_reference_composition():
     """StyleVectorizer (reference :590-601) on the fused EqualLinear+LeakyReLU node with cached scaled parameters, and
     latent_to_w mapping the two latents of a style-mixing step in one pass: values and all parameter / input gradients
@@ -1849,6 +1895,11 @@ def test_layout_bridge_kernels(shape):
     assert torch.equal(hb.cl_bf16_to_nchw(gy), gy.float().contiguous())
     got = hb.cl_bf16_to_nchw(gy, gate=gate)
     assert got.is_contiguous() and torch.equal(got, (gy.float() * (x > 0)).contiguous())
+    # relu_gate_add: (y > 0) ? a + b : 0 with ONE rounding of the fp32 sum
+    gb = cl(torch.randn(B, C, H, W, device=DEV, generator=g).bfloat16())
+    want = ((gy.float() + gb.float()) * (gate.float() > 0)).to(torch.bfloat16)
+    assert torch.equal(hb.relu_gate_add(gy, gb, gate), want)
+    assert torch.equal(hb.relu_gate_add(gy, None, gate), (gy.float() * (gate.float() > 0)).to(torch.bfloat16))
 
 
 def test_timing_pause_keeps_frozen_network_launches_out_of_the_classes():

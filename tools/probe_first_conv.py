@@ -42,7 +42,7 @@ for name, (N, K, S, P, H) in {"LPIPS-AlexNet conv1 11x11/4": (64, 11, 4, 2, 256)
     print("==", name)
     print("   forward, no grad (plain F.conv2d):")
     kernels(lambda: F.conv2d(x, w, b, S, P))
-    for mode in ("0", "1"):
+    for mode in ("0", "2"):
         os.environ["STYLEX_IMAGE_GRAD"] = mode
         xr = x.clone().requires_grad_()
         print("   forward + input gradient, STYLEX_IMAGE_GRAD=%s:" % mode)
