@@ -201,9 +201,7 @@ class GeneratorBlock(nn.Module):  # reference :670-718
             # block's style coordinates (reference :716: cat(style1, style2)), the third is handed to to_rgb
             fused = ops.style_affines(istyle, self.to_style1, self.to_style2, self.to_rgb.to_style, self.__dict__.setdefault("_aff_cache", {}))
             if fused is not None:
-                c1, c2 = self.input_channels, self.filters
-                style1, style2, coords = fused[:, :c1], fused[:, c1:c1 + c2], fused[:, :c1 + c2]
-                self._rgb_style = fused[:, c1 + c2:]
+                style1, style2, self._rgb_style, coords = fused
             else:
                 style1, style2 = self.to_style1(istyle), self.to_style2(istyle)
         else:

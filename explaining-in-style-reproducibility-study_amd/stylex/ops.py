@@ -1311,16 +1311,21 @@ class _StyleAffines(torch.autograd.Function):
         wcat, bcat = hit[1], hit[2]
         y = torch.addmm(bcat, x, wcat.t())
         ctx.save_for_backward(x, wcat)
-        ctx.sizes = (w1.shape[0], w2.shape[0], w3.shape[0])
-        return y
+        n1, n2, n3 = ctx.sizes = (w1.shape[0], w2.shape[0], w3.shape[0])
+        # four views of ONE result: style1, style2, the to-RGB style, and [style1 | style2] = the block's style coordinates.
+        # (Slicing the result outside the node cost a zero-filled full-width tensor + an add_ per slice in the backward.)
+        return y[:, :n1], y[:, n1:n1 + n2], y[:, n1 + n2:], y[:, :n1 + n2]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, g1, g2, g3, gc):
         x, wcat = ctx.saved_tensors
         n1, n2, n3 = ctx.sizes
         need = ctx.needs_input_grad
-        gy = gy.contiguous()
+        z = lambda n: x.new_zeros(x.shape[0], n)  # noqa: E731  (a style nobody used)
+        gy = torch.cat((g1 if g1 is not None else z(n1), g2 if g2 is not None else z(n2), g3 if g3 is not None else z(n3)), dim=1)
+        if gc is not None:  # a consumer of the style coordinates (get_style_coords=True under autograd)
+            gy[:, :n1 + n2] += gc
         gx = gy @ wcat if need[0] else None
         gws = gbs = (None, None, None)
         if any(need[1:7]):
@@ -1331,8 +1336,8 @@ class _StyleAffines(torch.autograd.Function):
 
 
 def style_affines(istyle, lin1, lin2, lin3, cache):
-    """[to_style1(w) | to_style2(w) | to_rgb.to_style(w)] as one [B, C1 + C2 + C3] tensor (the fused node above), or None
-    when the composable path must run (CPU double, double backward, non-fp32 / non-2D input)."""
+    """(to_style1(w), to_style2(w), to_rgb.to_style(w), [style1 | style2]) as four views of one GEMM result (the fused node
+    above), or None when the composable path must run (CPU double, double backward, non-fp32 / non-2D input)."""
     if not (_IMPL is HipOps and istyle.is_cuda and istyle.dim() == 2 and fast_enabled() and istyle.dtype == torch.float32
             and os.environ.get("STYLEX_STYLE_FUSE", "1") != "0"):
         return None

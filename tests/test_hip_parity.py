@@ -1491,16 +1491,17 @@ def test_style_affines_fused_node_vs_three_linears():
             y = ops.style_affines(wa, *lins, blk.__dict__.setdefault("_aff_cache", {}))
         finally:
             ops.set_fast(prev)
-        assert y is not None
+        assert y is not None and len(y) == 4 and torch.equal(y[3], torch.cat(y[:2], dim=1))
+        coords, y = y[3], torch.cat(y[:3], dim=1)
         blk.zero_grad()
-        (y * r).sum().backward()
+        ((y * r).sum() + 0.5 * (coords * r[:, :96]).sum()).backward()  # the style coordinates have a consumer as well
         return y.detach(), wa.grad, [p.grad.clone() for lin in lins for p in (lin.weight, lin.bias)]
 
     def plain():
         wb = w.clone().requires_grad_()
         y = torch.cat([lin(wb) for lin in lins], dim=1)
         blk.zero_grad()
-        (y * r).sum().backward()
+        ((y * r).sum() + 0.5 * (y[:, :96] * r[:, :96]).sum()).backward()
         return y.detach(), wb.grad, [p.grad.clone() for lin in lins for p in (lin.weight, lin.bias)]
 
     for edit in (None, "bias", "stamp"):
