@@ -256,8 +256,10 @@ class FusedTailResNet(nn.Module):
             c1 = m.conv1
             stem = first_conv(x, c1.weight, c1.bias, c1.stride[0], c1.padding[0]) if c1.groups == 1 else self._conv(x, c1)
             p0 = _AffineReluPool.apply(stem.contiguous(), *self.aff["bn1"])
-            if getattr(self, "_hyb", None) is None:
+            pstamp = tuple(p._version for p in m.parameters())  # (a state dict loaded into the classifier later: refold)
+            if getattr(self, "_hyb", None) is None or self._hyb.stamp != pstamp:
                 self._hyb = _HybridPlan(self)
+                self._hyb.stamp = pstamp
             y = _ResNetBodyHybrid.apply(p0, self)
             return m.fc(torch.flatten(m.avgpool(y), 1))
         c1 = m.conv1

@@ -1732,17 +1732,21 @@ def test_frozen_classifier_bf16_data_gradient(size, monkeypatch):
     g = torch.Generator(device=DEV).manual_seed(59)
     x0 = torch.randn(4, 3, size, size, device=DEV, generator=g)
     r = torch.randn(4, 2, device=DEV, generator=g)
-    res = {}
-    ops.set_precision("bf16")
-    try:
-        for mode in ("0", "1"):
-            monkeypatch.setenv("STYLEX_FROZEN_BWD_BF16", mode)
-            x = x0.clone().requires_grad_()
-            y = fused(x)
-            (y * r).sum().backward()
-            res[mode] = (y.detach().clone(), x.grad.detach().double())
-    finally:
-        ops.set_precision("fp32")
+    def both():
+        res = {}
+        ops.set_precision("bf16")
+        try:
+            for mode in ("0", "1"):
+                monkeypatch.setenv("STYLEX_FROZEN_BWD_BF16", mode)
+                x = x0.clone().requires_grad_()
+                y = fused(x)
+                (y * r).sum().backward()
+                res[mode] = (y.detach().clone(), x.grad.detach().double())
+        finally:
+            ops.set_precision("fp32")
+        return res
+
+    res = both()
     # the same library convolutions in both modes (the library's own run-to-run noise is ~1e-7: atomics in its algorithms)
     close(res["0"][0], res["1"][0], 1e-5, "the forward must not change")
     g32, g16 = res["0"][1], res["1"][1]
@@ -1750,6 +1754,14 @@ def test_frozen_classifier_bf16_data_gradient(size, monkeypatch):
     cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
     print("frozen classifier @%d: bf16 data gradient vs fp32: rel L2 %.3e, cosine %.6f" % (size, rel, cos))
     assert rel < 3e-2 and cos > 0.999, (rel, cos)
+    # a checkpoint loaded into the classifier LATER must reach the folded bf16 weights of the backward as well
+    with torch.no_grad():
+        net.layer2[0].conv1.weight.mul_(1.7)
+        net.layer3[1].conv2.weight.neg_()
+    res = both()
+    g32, g16 = res["0"][1], res["1"][1]
+    rel2 = float((g16 - g32).norm() / g32.norm())
+    assert rel2 < 3e-2, ("stale folded weights after an in-place change of the classifier's parameters", rel2)
 
 
 @pytest.mark.parametrize("case", [(4, 3, 256, 256, 224, 224, "nchw"), (4, 3, 256, 256, 224, 224, "nhwc"), (2, 3, 32, 32, 224, 224, "nchw"),
