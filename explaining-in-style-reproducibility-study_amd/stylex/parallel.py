@@ -12,6 +12,8 @@ every rank — the path the gloo tests (2 and 4 ranks), the 1-rank RCCL identity
 appears.  ``STYLEX_DDP_OVERLAP=0`` / ``GradSync(overlap=False)``: 128 MB buckets issued AFTER the
 backward.  Non-final micro-steps never communicate (== ``no_sync``, :274-285).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -89,6 +91,12 @@ class GradSync:
                 off += (p.numel() + 3) & ~3
             self.flats.append(flat)
         self._armed = False
+        # First-use self-check of the in-backward launch path (round 6, ADVICE): no >= 2-GPU RCCL run of it exists, so the
+        # first `checks` overlapped all_reduce() calls verify what MUST hold afterwards on any correct run — every rank
+        # holds the SAME averaged buckets — with two tiny collectives (MAX and MIN of a per-bucket checksum vector).  A
+        # mismatch (a bucket reduced before its gradients were complete on some rank, buckets launched in different orders)
+        # falls back to the post-backward path with a warning instead of training on corrupt gradients.
+        self._selfcheck_left = int(os.environ.get("STYLEX_DDP_SELFCHECK", "2")) if self.overlap else 0
         self._reset()
         with torch.no_grad():
             for p in self.params:  # adopt gradients that already exist, then bind every .grad to its view
@@ -194,6 +202,7 @@ class GradSync:
     def all_reduce(self):
         if not is_dist():
             return
+        armed_run = self._armed
         if not self._armed:
             self._reset()
         self._armed = False
@@ -204,6 +213,9 @@ class GradSync:
             work.wait()
             if not flat.is_cuda:
                 flat.div_(world)
+        if self._selfcheck_left > 0 and self.overlap and world > 1 and armed_run:
+            self._selfcheck_left -= 1
+            self._selfcheck()
         # A parameter without a gradient in this phase has none on ANY rank (every rank runs the same schedule: same
         # phase, same micro-steps, same alternating / encoder switches), so its reduced "gradient" is exactly zero.
         # Leave .grad = None as the single-GPU path and the reference's DDP do — Adam then skips the parameter instead
@@ -211,6 +223,27 @@ class GradSync:
         for p in self._nograd:
             p.grad = None
         self._reset()
+
+
+def _gradsync_selfcheck(self):
+    """Every rank must hold identical buckets after the averaging collectives: compare a checksum per bucket across
+    the ranks (MAX == MIN).  One host sync, on the first overlapped steps only."""
+    import warnings
+
+    sums = torch.stack([f.double().sum() + f.double().abs().sum() * 1e-3 for f in self.flats])
+    hi, lo = sums.clone(), sums.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    scale = hi.abs().clamp_min(1e-30)
+    bad = ((hi - lo).abs() / scale > 1e-6) | ~torch.isfinite(hi - lo)
+    if bool(bad.any()):
+        self.overlap = False
+        warnings.warn("GradSync: the ranks disagree on %d of %d averaged gradient buckets after the in-backward launch path; "
+                      "falling back to the post-backward all-reduce (STYLEX_DDP_OVERLAP=0)" % (int(bad.sum()), len(self.flats)))
+    return not bool(bad.any())
+
+
+GradSync._selfcheck = _gradsync_selfcheck
 
 
 def all_reduce_max_(t):

@@ -140,6 +140,17 @@ def _gradsync_worker(rank, world, port, q):
             assert all(p.grad is None for p in unused.parameters())
             got = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
             results[mode] = (float((got - want).abs().max()), launched_before if mode == "armed" else None)
+            if mode == "armed":
+                results["selfcheck_ran"] = (sync._selfcheck_left, sync.overlap)  # one of the two first-use checks is spent
+        # round 6: the first-use self-check of the in-backward path — ranks that disagree on an averaged bucket fall back
+        import warnings
+
+        if rank == 1:
+            sync.flats[0][0] += 1.0  # what a bucket reduced before its gradients were complete would look like
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            ok = sync._selfcheck()
+        results["selfcheck_mismatch"] = (ok, sync.overlap, len(wl))
         q.put((rank, results))
     finally:
         dist.destroy_process_group()
@@ -163,6 +174,8 @@ def test_gradsync_overlapped_matches_manual_average():
     for rank, results in res:
         assert results["armed"][0] < 1e-6 and results["plain"][0] < 1e-6, results
         assert results["armed"][1] >= 2, "no bucket was launched during the backward: %r" % (results,)
+        assert results["selfcheck_ran"] == (1, True), results  # ran once, passed, the overlap path stays on
+        assert results["selfcheck_mismatch"] == (False, False, 1), results  # EVERY rank sees the mismatch, falls back, warns once
 
 
 def _uneven_worker(rank, world, port, q):
