@@ -829,7 +829,8 @@ class _DBlockFast(torch.autograd.Function):
                 wf2, _ = hb.pack_weight_s2d(w3)
                 if fold_res:
                     wm = hb._bf16_matrix(wrp if cin == 3 else w_res, owner=w_res if cin == 3 else None)
-                    out = hb.conv2d_s2d_res_fwd(xb, wf2, xs, wm, b3.detach().float() + b_res.detach().float(), w3.shape[0], n, c)
+                    bsum = hb.cached_vector("sum32", lambda a, b: a.float() + b.float(), b3, b_res)
+                    out = hb.conv2d_s2d_res_fwd(xb, wf2, xs, wm, bsum, w3.shape[0], n, c)
                 else:
                     out = hb.conv2d_fwd(xb, None, 1, 1, _PRECISION, bias=b3, residual=res, res_scale=c, packed=wf2,
                                         w_shape=(w3.shape[0], 4 * n, 3, 3), s2d_c=n)
