@@ -287,44 +287,16 @@ class Generator(nn.Module):  # reference :747-825
         batch = styles.shape[0]
         x = self.initial_conv(self.initial_block.expand(batch, -1, -1, -1))
         rgb, coords = None, []
-        # The toRGB chain (1x1 modulated conv to 3 channels, skip add, bilinear x2, blur: memory-bound kernels on
-        # 3-channel tensors) only feeds the NEXT toRGB, never the feature path, so it CAN run one block behind on a
-        # side HIP stream under the MFMA-bound convs of the next block (STYLEX_G_SIDE=1).  Off by default since the
-        # streaming to-RGB kernels (csrc/torgb.hip) made the chain cheap: the overlap is worth 0.8 % (645 vs 650
-        # images/s), and with the short chain on a side stream the full-size determinism check (tools/
-        # determinism_check.py) stopped being bit-identical run to run — single pixels of the gradient handed from
-        # the side chain to the feature path differ (profiles/probes/race_locator.py; the kernels themselves are
-        # reproducible under concurrency, profiles/probes/torgb_concurrency_probe.py, and the autograd engine's
-        # cross-stream hand-off checks out in isolation, profiles/probes/engine_stream_probe.py).  Root cause not found;
-        # until it is, the chain stays on the caller's stream.
-        g_side = os.environ.get("STYLEX_G_SIDE", "0")  # 1: always; 2 / 3 (probes): only without / only with autograd recording
-        use_side = g_side == "1" or (g_side == "2" and not torch.is_grad_enabled()) or (g_side == "3" and torch.is_grad_enabled())
-        side = _side_stream(x) if use_side else None
-        if side is None:
-            # one UnbindBackward (a stack) instead of num_layers SelectBackwards (a zero-filled [B, L, D] tensor each,
-            # summed pairwise by the engine): ~20 fewer launches per generator backward
-            per_layer = styles.unbind(1)
-            for li, block in enumerate(self.blocks):
-                x, sc = block.forward_main(x, per_layer[li], input_noise)
-                coords.append(sc)
-                rgb = block.to_rgb(x, rgb, per_layer[li], style=block.__dict__.pop("_rgb_style", None), padded=True)
-        else:
-            main = torch.cuda.current_stream()
-            # (measured and dropped: evaluating all blocks' style affines / demod coefficients ahead on a second
-            # companion stream changed nothing: 597 vs 600 images/s)
-            for li, block in enumerate(self.blocks):
-                x, sc = block.forward_main(x, styles[:, li], input_noise)
-                coords.append(sc)
-                rgb_style = block.__dict__.pop("_rgb_style", None)
-                if rgb_style is None:
-                    rgb_style = block.to_rgb.to_style(styles[:, li])  # the GEMMs stay on `main` (see below)
-                side.wait_stream(main)  # x is ready
-                x.record_stream(side)
-                rgb_style.record_stream(side)
-                with torch.cuda.stream(side):
-                    rgb = block.to_rgb(x, rgb, None, style=rgb_style, padded=True)
-            main.wait_stream(side)
-            rgb.record_stream(main)
+        # The toRGB chain runs on the caller's stream.  (Rounds 1-5 kept an opt-in variant that ran it one block behind on a
+        # side HIP stream — +0.8 % — which produced run-to-run differences whose cause was never found: deleted in round 6;
+        # profiles/design_history_r5.md "Open issue — toRGB chain on a side stream".)
+        # One UnbindBackward (a stack) instead of num_layers SelectBackwards (a zero-filled [B, L, D] tensor each, summed
+        # pairwise by the engine): ~20 fewer launches per generator backward.
+        per_layer = styles.unbind(1)
+        for li, block in enumerate(self.blocks):
+            x, sc = block.forward_main(x, per_layer[li], input_noise)
+            coords.append(sc)
+            rgb = block.to_rgb(x, rgb, per_layer[li], style=block.__dict__.pop("_rgb_style", None), padded=True)
         if rgb.shape[1] == 4 and self.blocks[0].to_rgb.conv.filters == 3:
             rgb = rgb[:, :3]  # fused RGB path: 4-channel storage, channel 3 is zero
         rgb = rgb.float()  # activations may be stored in bf16; the module API returns fp32 images

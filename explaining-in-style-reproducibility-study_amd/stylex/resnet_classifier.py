@@ -83,29 +83,16 @@ class ResNet:
         return self._net(x)(x)
 
     def _net(self, x):
-        """Stock PyTorch fp32 module by default (north_star: the frozen classifier stays on stock PyTorch).
-        STYLEX_FROZEN_HIP=1 runs the BasicBlocks on the HIP conv kernels with BatchNorm folded
-        (frozen_resnet.py; exact in 'fp32' mode, +2.8 % step throughput in 'bf16' mode — but a bf16 ReLU network's
-        INPUT GRADIENT was measured 20 % off in the L2 sense (D's own LeakyReLU chain: 1.5 %), too noisy a
-        classifier signal to be the default)."""
-        if not x.is_cuda:
+        """The stock PyTorch fp32 module (north_star: the frozen classifier's forward stays on stock PyTorch): on the GPU its
+        library convolutions with everything between them (eval BatchNorm, ReLU, residual add, max-pool) on the fused fp32
+        kernels of csrc/frozen_ew.hip, and — bf16 speed mode, a pass whose input gradient is wanted — the data gradient on
+        this library's bf16 kernels gated by the fp32 activations' signs (frozen_resnet.FusedTailResNet).
+        STYLEX_FROZEN_FUSE=0 = the plain nn.Module.  (A bf16 FORWARD of the classifier — the opt-in of rounds 1-5 — was
+        deleted in round 6: its flipped ReLU gates put 20 % of L2 error on the input gradient.)"""
+        if not x.is_cuda or os.environ.get("STYLEX_FROZEN_FUSE", "1") == "0":
             return self.model
-        mode = os.environ.get("STYLEX_FROZEN_HIP", "0")
-        # "nograd" (opt-in, round 4): the HIP kernels only where no gradient is asked of the classifier — the logits of
-        # REAL images (conditioning + KL target: 2 of its 3 forward passes per encoder micro-step); the pass on generated
-        # images, whose input gradient trains G, stays on the library's fp32 convolutions
-        if not (mode == "1" or (mode == "nograd" and not x.requires_grad)):
-            # default: the library's fp32 convolutions, everything between them (eval BatchNorm, ReLU, residual add,
-            # max-pool) on the fused fp32 kernels of csrc/frozen_ew.hip; STYLEX_FROZEN_FUSE=0 = the plain nn.Module
-            if os.environ.get("STYLEX_FROZEN_FUSE", "1") == "0":
-                return self.model
-            if getattr(self, "_fused", None) is None:
-                from frozen_resnet import FusedTailResNet
+        if getattr(self, "_fused", None) is None:
+            from frozen_resnet import FusedTailResNet
 
-                self._fused = FusedTailResNet(self.model) if FusedTailResNet.supports(self.model) else self.model
-            return self._fused
-        if getattr(self, "_hip", None) is None:
-            from frozen_resnet import HipFrozenResNet
-
-            self._hip = HipFrozenResNet(self.model) if HipFrozenResNet.supports(self.model) else self.model
-        return self._hip
+            self._fused = FusedTailResNet(self.model) if FusedTailResNet.supports(self.model) else self.model
+        return self._fused

@@ -358,15 +358,10 @@ def get_lpips(device):
 
 
 def _frozen_layout(images):
-    """Memory layout handed to the frozen library networks (classifier, LPIPS): dense NCHW — MIOpen's fp32
-    Winograd kernels beat its NHWC implicit-GEMM ones on these shapes (measured: +2 % on the whole step), and the
-    generator output arrives channels_last.  STYLEX_FROZEN_LAYOUT=nhwc|keep overrides for experiments."""
-    mode = os.environ.get("STYLEX_FROZEN_LAYOUT", "nchw")
-    if mode == "nchw":
-        return images.contiguous()
-    if mode == "nhwc":
-        return images.contiguous(memory_format=torch.channels_last)
-    return images
+    """Memory layout handed to the frozen library networks (classifier, LPIPS): dense NCHW — MIOpen's fp32 Winograd kernels
+    beat its NHWC implicit-GEMM ones on these shapes (measured: +2 % on the whole step), and the generator output arrives
+    channels_last."""
+    return images.contiguous()
 
 
 def perceptual_loss(encoder_batch, generated_images, lpips_fn=None):

@@ -598,45 +598,6 @@ def test_bf16_strip_blur_vs_oracle():
         ops.set_precision("fp32")
 
 
-def test_frozen_resnet_on_hip_kernels_matches_torch_module():
-    """Opt-in path (STYLEX_FROZEN_HIP=1): the frozen ResNet-18 BasicBlocks on the HIP conv kernels (BatchNorm
-    folded, ReLU and the identity merge in the epilogue).  fp32 mode must reproduce the stock module (logits and
-    input gradient); bf16 mode must reproduce the logits (its input gradient is bf16-noisy by nature, DESIGN)."""
-    import frozen_resnet
-    import tv_models
-
-    torch.manual_seed(3)
-    model = tv_models.ResNet18()
-    model.fc = torch.nn.Linear(512, 2)
-    for m in model.modules():  # non-trivial BatchNorm statistics
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.running_mean.normal_(0, 0.2)
-            m.running_var.uniform_(0.5, 1.5)
-            m.weight.data.uniform_(0.5, 1.5)
-            m.bias.data.normal_(0, 0.2)
-    model = model.to(DEV).eval()
-    for p in model.parameters():
-        p.requires_grad = False
-    assert frozen_resnet.HipFrozenResNet.supports(model)
-    x = torch.randn(4, 3, 96, 96, device=DEV)
-    head = torch.tensor([[1.0, -2.0]], device=DEV)
-    xr = x.clone().requires_grad_()
-    yr = model(xr)
-    (yr * head).sum().backward()
-    try:
-        for prec in ("fp32", "bf16"):
-            ops.set_precision(prec)
-            hip = frozen_resnet.HipFrozenResNet(model)
-            xh = x.clone().requires_grad_()
-            yh = hip(xh)
-            (yh * head).sum().backward()
-            close(yr, yh, 1e-4 if prec == "fp32" else 4e-2, "frozen resnet logits " + prec)
-            rel = float((xr.grad.double() - xh.grad.double()).norm() / xr.grad.double().norm())
-            assert rel <= (1e-4 if prec == "fp32" else 0.5), "input gradient %s: relative L2 error %.3e" % (prec, rel)
-    finally:
-        ops.set_precision("fp32")
-
-
 def test_resampling_exact_index_rules():
     g = load_golden("ops")
     x = torch.from_numpy(g["up/x"])
