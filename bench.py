@@ -38,13 +38,13 @@ PEAK_HBM_GBS = 8000.0  # HBM3E spec peak (same guide; 6.29 TB/s is the best meas
 
 
 def csrc_sha16():
-    """Hash of the kernel sources + C-ABI header: a PMC traffic file is only quoted for the code it was measured on."""
+    """Hash of the kernel sources, their build flags and the C-ABI header: a PMC traffic file is only quoted for the code it was measured on."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h"))
-                    + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+                    + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(PKG, "csrc", "Makefile")]):  # (+ build flags)
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -39,6 +39,12 @@ def broadcast_parameters(module, src=0):
     hb.mark_updated(ts)
 
 
+def _backend_averages():
+    """ReduceOp.AVG exists on RCCL only; over gloo (the CPU tests, and the two-ranks-on-one-GPU test that runs the HIP
+    kernels under a real two-rank exchange) the buckets are summed and divided by the world size afterwards."""
+    return dist.get_backend() == "nccl"
+
+
 class GradSync:
     """Bucketed gradient all-reduce on persistent flat buffers, overlapped with the backward pass.
 
@@ -177,7 +183,7 @@ class GradSync:
                     #                      stream has enqueued so far, the bucket's gradients included
         self._pack(bi)
         flat = self.flats[bi]
-        avg = flat.is_cuda  # RCCL averages inside the collective; gloo (CPU tests) has no AVG
+        avg = _backend_averages()  # RCCL averages inside the collective; gloo has no AVG (sum, then divide in all_reduce())
         self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True))
         self._next += 1
 
@@ -209,9 +215,10 @@ class GradSync:
         world = dist.get_world_size()
         while self._next < len(self.buckets):
             self._launch(self._next)
+        avg = _backend_averages()
         for flat, work in zip(self.flats, self._works):
             work.wait()
-            if not flat.is_cuda:
+            if not avg:
                 flat.div_(world)
         if self._selfcheck_left > 0 and self.overlap and world > 1 and armed_run:
             self._selfcheck_left -= 1

@@ -728,12 +728,15 @@ class Trainer:
         self._draw_worker, self._next_d = None, None
         self.lpips_fn = lpips_fn
         self.num_classes = num_classes
+        # the classifier wrappers keep the reference's `cuda_rank` argument (it passes the process rank, :1157-1160, which
+        # is the GPU index only on one node with one rank per GPU in order); the Trainer hands them the index of ITS device
+        dev_index = self.device.index if (self.device.type == "cuda" and self.device.index is not None) else rank
         if classifier is not None:
             self.classifier = classifier
         elif str(classifier_name).lower() == "resnet":
-            self.classifier = ResNet(classifier_path, cuda_rank=rank, output_size=num_classes, image_size=image_size)
+            self.classifier = ResNet(classifier_path, cuda_rank=dev_index, output_size=num_classes, image_size=image_size)
         else:
-            self.classifier = MobileNet(classifier_path, cuda_rank=rank, output_size=num_classes, image_size=image_size)
+            self.classifier = MobileNet(classifier_path, cuda_rank=dev_index, output_size=num_classes, image_size=image_size)
         self.tb_writer = None
         if exists(tensorboard_dir):
             try:

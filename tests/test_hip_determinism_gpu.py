@@ -56,3 +56,34 @@ def test_two_runs_are_bit_identical_at_the_benchmark_size():
         os.chdir(cwd)
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert runs[0][1] == runs[1][1]
+
+
+@pytest.mark.timeout(900)
+def test_two_processes_sharing_the_gpu_stay_bit_identical():
+    """Round 6: with a SECOND process on the same GPU identically seeded Trainers used to differ run to run (one in two to
+    ten): the to-RGB data gradient lost a product in lanes 48-63 of some waves — a packed fp32 multiply with crossed operand
+    halves that only the SLP-vectorised torgb.hip contained; never in isolation, never with the GPU to itself
+    (profiles/r06_torgb_contention.txt; csrc/Makefile builds that file without the vectoriser now).  Two determinism
+    checks at once, three Trainers each after the throw-away one, two train() calls at the benchmark size: all six
+    parameter checksums and every loss scalar agree."""
+    import subprocess
+
+    tool = os.path.join(ROOT, "tools", "determinism_check.py")
+    env = dict(os.environ, DET_TRAINERS="3")
+    procs = [subprocess.Popen([sys.executable, tool, "2", "256", "32"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=800))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sums = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+        line = [ln for ln in so.splitlines() if ln.startswith("all parameter checksums")][-1]
+        sums += [float(v) for v in line.split("[", 1)[1].rstrip("] \n").split(",")]
+        assert "bit-identical: True" in so, so[-2000:]  # (the first two Trainers of the process, losses included)
+    assert len(sums) == 6 and len(set(sums)) == 1, sums

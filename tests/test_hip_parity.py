@@ -2562,6 +2562,57 @@ def test_gradsync_on_one_rank_rccl_is_bit_identical_to_single_gpu():
     assert rep["n_params"] > 100
 
 
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_exchange_gradients_over_gloo():
+    """The N > 1 path as close to hardware as a 1-GPU box allows (tools/ddp_two_ranks_one_gpu.py): two processes, both on
+    cuda:0 with the real HIP kernels at config 2's network sizes (ResNet-18 classifier, LPIPS-AlexNet, batch 8 per rank),
+    gradients exchanged by a REAL two-rank all-reduce (gloo: RCCL refuses two ranks on one device) from the same hooks /
+    launch order / stream joins as the RCCL path.  The trained networks of the replicas are bit-identical after every call
+    in both exchange modes, the in-backward bucket launch (4 + 7 buckets) ends with the same bits as the post-backward
+    exchange on both ranks — a bucket reduced before one of its gradients was complete would not —, the first-use
+    self-check ran and passed, and the exchange really mixed the ranks' gradients.  (This test found the round's to-RGB
+    kernel defect: profiles/r06_torgb_contention.txt.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29553
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TWO_BATCH="8")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tools", "ddp_two_ranks_one_gpu.py"), "3"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=800))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    rep = json.loads(line)
+    out_dir = os.path.join(root, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "two_ranks_one_gpu.json"), "w") as f:
+        f.write(line + "\n")
+    assert rep["world"] == 2 and len(rep["ranks"]) == 2
+    for r in rep["ranks"]:
+        assert r["replicas_identical"] == {"post": [True] * 3, "overlap": [True] * 3}, r
+        assert r["overlap_equals_post"], r
+        assert r["exchange_changed_the_update"], r
+        assert r["finite"], r
+        assert r["selfcheck"]["still_overlapped"] == [True, True], r
+        assert min(r["selfcheck"]["ran"]) >= 1, r
+        assert min(r["buckets"]["overlap"]) >= 2, r  # several in-backward launches per phase
+        assert r["n_param_values"] > 50_000_000
+    assert rep["ranks"][0]["scalars_overlap"] != rep["ranks"][1]["scalars_overlap"]  # the ranks saw different data
+
+
 def test_adam_pack_step_matches_torch_fused_adam_and_the_pack_kernels():
     """csrc/adam_pack.hip (round 4): ONE launch = the Adam update of torch._fused_adam_ on the optimiser's own state
     tensors + every cached operand copy of the stepped weights rewritten from the updated values.  Against two reference

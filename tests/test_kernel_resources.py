@@ -49,3 +49,66 @@ def test_hot_kernels_use_no_scratch(tmp_path, source, kernels):
         assert hits, (k, sorted(seen))
         for n, (scratch, spill) in hits.items():
             assert scratch == 0 and spill == 0, (n, "scratch bytes/lane", scratch, "spilled VGPRs", spill)
+
+
+def _makefile_flags(stem):
+    """The per-file extra flags of csrc/Makefile (CXXFLAGS_<stem> = ...)."""
+    for line in open(os.path.join(CSRC, "Makefile")):
+        m = re.match(r"CXXFLAGS_%s\s*=\s*(.*)" % re.escape(stem), line)
+        if m:
+            return m.group(1).split()
+    return []
+
+
+def _crossed_packed_fp32(asm_path):
+    """(kernel, instruction) of every packed fp32 instruction with a CROSSED source: op_sel = 1 and op_sel_hi = 0 for the
+    same operand, i.e. the low result reads the high register of the pair and the high result the low one."""
+    hits, cur = [], None
+    for line in open(asm_path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+        if not re.match(r"\s*v_pk_\w+_f32\s", line):
+            continue
+        a = re.search(r"op_sel:\[([01,]+)\]", line)
+        b = re.search(r"op_sel_hi:\[([01,]+)\]", line)
+        osel = [int(v) for v in a.group(1).split(",")] if a else [0, 0, 0]
+        ohi = [int(v) for v in b.group(1).split(",")] if b else [1, 1, 1]
+        if any(osel[i] == 1 and ohi[i] == 0 for i in range(min(len(osel), len(ohi)))):
+            hits.append((cur, line.strip()))
+    return hits
+
+
+@pytest.mark.skipif(not os.path.isfile(HIPCC), reason="needs hipcc")
+def test_no_crossed_packed_fp32_operands(tmp_path):
+    """Round 6 (profiles/r06_torgb_contention.txt): `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` — what hipcc's SLP
+    vectoriser made of the to-RGB data gradient — lost the low product in lanes 48-63 whenever waves of another process (or
+    stream) shared the GPU.  torgb.hip is built without the SLP vectoriser since; this test compiles EVERY translation unit
+    with the Makefile's flags and fails on any packed fp32 instruction with a crossed source outside the two kernels below
+    (a crossed `v_pk_fma_f32` addend / multiplicand; the first is not launched by the training step, the second — three
+    launches per step — never differed in ~100 contended Trainers of tools/contention_probe.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    known = {"rgb_up_blur_add_fwd_kernelILi8E": 4, "resize_norm_fwd_kernel": 1}
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+    def compile_one(src):
+        out = str(tmp_path / (src + ".s"))
+        r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function"]
+                           + _makefile_flags(src[:-4]) + ["-S", "--cuda-device-only", "-c", os.path.join(CSRC, src), "-o", out],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return src, _crossed_packed_fp32(out)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        found = dict(pool.map(compile_one, srcs))
+    assert found["torgb.hip"] == [], found["torgb.hip"]
+    assert "-fno-slp-vectorize" in _makefile_flags("torgb")
+    seen = {}
+    for src, hits in found.items():
+        for kernel, ins in hits:
+            key = next((k for k in known if k in (kernel or "")), None)
+            assert key is not None, "new crossed packed-fp32 operand in %s, kernel %s: %s" % (src, kernel, ins)
+            seen[key] = seen.get(key, 0) + 1
+    for key, n in seen.items():
+        assert n <= known[key], (key, n)
