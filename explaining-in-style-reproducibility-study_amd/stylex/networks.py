@@ -288,8 +288,8 @@ class Generator(nn.Module):  # reference :747-825
         x = self.initial_conv(self.initial_block.expand(batch, -1, -1, -1))
         rgb, coords = None, []
         # The toRGB chain runs on the caller's stream.  (Rounds 1-5 kept an opt-in variant that ran it one block behind on a
-        # side HIP stream — +0.8 % — which produced run-to-run differences whose cause was never found: deleted in round 6;
-        # profiles/design_history_r5.md "Open issue — toRGB chain on a side stream".)
+        # side HIP stream — +0.8 % — which produced run-to-run differences: deleted in round 6.  Their very likely cause was
+        # found later that round: the to-RGB data-gradient kernel itself, whenever other waves shared the GPU)
         # One UnbindBackward (a stack) instead of num_layers SelectBackwards (a zero-filled [B, L, D] tensor each, summed
         # pairwise by the engine): ~20 fewer launches per generator backward.
         per_layer = styles.unbind(1)
