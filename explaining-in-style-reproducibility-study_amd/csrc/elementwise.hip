@@ -592,10 +592,9 @@ int stylex_rgb_up_blur_add_fwd(const void* rgb, const void* prev, void* y, EW_AR
     EW_UNPACK
     if (!rgb || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return STYLEX_EINVAL;
     const void* al = prev ? prev : rgb;
-    if (bf && (C % 8 == 0) && vec_ok(C, rgb, y) && vec_ok(C, al, y))
-        hipLaunchKernelGGL(rgb_up_blur_add_fwd_kernel<8>, dim3(grid_for((long)B * 4 * H * W * C / 8)), dim3(256), 0, s, rgb, prev,
-                           y, B, H, W, C, bf);
-    else if (vec_ok(C, rgb, y) && vec_ok(C, al, y))
+    // (no 8-channel instantiation: the RGB path has 4 channels per pixel, and the SLP vectoriser gave that variant packed fp32
+    // fmas with a crossed operand — the form DESIGN §7a keeps out of every translation unit)
+    if (vec_ok(C, rgb, y) && vec_ok(C, al, y))
         hipLaunchKernelGGL(rgb_up_blur_add_fwd_kernel<4>, dim3(grid_for((long)B * 4 * H * W * C / 4)), dim3(256), 0, s, rgb, prev,
                            y, B, H, W, C, bf);
     else

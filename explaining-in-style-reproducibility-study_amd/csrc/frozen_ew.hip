@@ -530,8 +530,14 @@ __global__ __launch_bounds__(256) void resize_norm_fwd_kernel(const float* __res
         const int ox = i % Wo, oy = (i / Wo) % Ho, c = (i / (Wo * Ho)) % C, b = i / (Wo * Ho * C);
         const RsIdx h = rs_index(oy, rh, Hi), w = rs_index(ox, rw, Wi);
         const float* p = x + b * sb + c * sc;
-        const float v = h.l0 * (w.l0 * p[h.i0 * sh + w.i0 * sw] + w.l1 * p[h.i0 * sh + w.i1 * sw]) +
-                        h.l1 * (w.l0 * p[h.i1 * sh + w.i0 * sw] + w.l1 * p[h.i1 * sh + w.i1 * sw]);
+        // the two rows as SCALAR fmas, one strictly after the other: hipcc's SLP vectoriser paired them into a packed fp32
+        // fma with a crossed operand — the operand form whose low half went missing in torgb.hip when other waves shared
+        // the GPU (tests/test_kernel_resources.py keeps every translation unit free of it)
+        float p10 = p[h.i1 * sh + w.i0 * sw], p11 = p[h.i1 * sh + w.i1 * sw];
+        float r0 = w.l0 * p[h.i0 * sh + w.i0 * sw] + w.l1 * p[h.i0 * sh + w.i1 * sw];
+        asm volatile("" : "+v"(r0), "+v"(p10), "+v"(p11));
+        const float r1 = w.l0 * p10 + w.l1 * p11;
+        const float v = h.l0 * r0 + h.l1 * r1;
         y[i] = mean ? (v - mean[c]) / stdv[c] : v;
     }
 }

@@ -84,12 +84,12 @@ def test_no_crossed_packed_fp32_operands(tmp_path):
     """Round 6 (profiles/r06_torgb_contention.txt): `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` — what hipcc's SLP
     vectoriser made of the to-RGB data gradient — lost the low product in lanes 48-63 whenever waves of another process (or
     stream) shared the GPU.  torgb.hip is built without the SLP vectoriser since; this test compiles EVERY translation unit
-    with the Makefile's flags and fails on any packed fp32 instruction with a crossed source outside the two kernels below
-    (a crossed `v_pk_fma_f32` addend / multiplicand; the first is not launched by the training step, the second — three
-    launches per step — never differed in ~100 contended Trainers of tools/contention_probe.py)."""
+    with the Makefile's flags and fails on any packed fp32 instruction with a crossed source.  (Two more kernels had one — a
+    crossed `v_pk_fma_f32` operand in the 8-channel RGB upsample variant, which nothing launched and which is gone, and in
+    `resize_norm_fwd_kernel`, whose two rows are scalar fmas now; neither ever differed in the contention probe.)"""
     from concurrent.futures import ThreadPoolExecutor
 
-    known = {"rgb_up_blur_add_fwd_kernelILi8E": 4, "resize_norm_fwd_kernel": 1}
+    known = {}
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
     def compile_one(src):
