@@ -28,13 +28,13 @@ def run(steps=5, image_size=256, batch=32, lazy=False, trainers=2):
     import ops
 
     hb.load_library()
-    ops.set_precision("bf16")
+    ops.set_precision(os.environ.get("DET_PRECISION", "bf16"))
     prev_det = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True
     if os.environ.get("DET_TORCH_WARN") == "1":  # name every ATen op of the step that is flagged as not reproducible
         torch.use_deterministic_algorithms(True, warn_only=True)
     a = argparse.Namespace(batch=batch, image_size=image_size, gae=2, classifier="resnet", workdir="/tmp/sb_det",
-                           precision="bf16", device_rng=int(os.environ.get("DET_DEVICE_RNG", "0")))
+                           precision=os.environ.get("DET_PRECISION", "bf16"), device_rng=int(os.environ.get("DET_DEVICE_RNG", "0")))
     runs = []
     try:
         if os.environ.get("DET_WARM", "1") != "0":
