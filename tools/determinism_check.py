@@ -33,7 +33,11 @@ def run(steps=5, image_size=256, batch=32, lazy=False, trainers=2):
     torch.backends.cudnn.deterministic = True
     if os.environ.get("DET_TORCH_WARN") == "1":  # name every ATen op of the step that is flagged as not reproducible
         torch.use_deterministic_algorithms(True, warn_only=True)
-    a = argparse.Namespace(batch=batch, image_size=image_size, gae=2, classifier="resnet", workdir="/tmp/sb_det",
+    # DET_CLASSIFIER / DET_PL_EVERY / DET_START_STEP: BASELINE config 4's variant (MobileNetV2, path-length steps, which start
+    # after step 5000) through the same check
+    start = int(os.environ.get("DET_START_STEP", "0"))
+    a = argparse.Namespace(batch=batch, image_size=image_size, gae=2, classifier=os.environ.get("DET_CLASSIFIER", "resnet"),
+                           pl_every=int(os.environ.get("DET_PL_EVERY", "32")), workdir="/tmp/sb_det",
                            precision=os.environ.get("DET_PRECISION", "bf16"), device_rng=int(os.environ.get("DET_DEVICE_RNG", "0")))
     runs = []
     try:
@@ -47,6 +51,7 @@ def run(steps=5, image_size=256, batch=32, lazy=False, trainers=2):
             # output agrees until they do).  Not a race: the check is about run-to-run noise in steady state.
             bench.seed_all(42)
             tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
+            tr.steps = start
             tr.train()
             torch.cuda.synchronize()
             del tr
@@ -54,6 +59,7 @@ def run(steps=5, image_size=256, batch=32, lazy=False, trainers=2):
         for _ in range(trainers):
             bench.seed_all(42)
             tr = bench.build_trainer(a, torch.device("cuda:0"), 0, 1)
+            tr.steps = start
             rows = []
             for _i in range(steps):
                 tr.train()
