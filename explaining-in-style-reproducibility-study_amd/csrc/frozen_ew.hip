@@ -592,6 +592,64 @@ __global__ __launch_bounds__(256) void relu_gate_add_kernel(const uint4* __restr
     }
 }
 
+// ---- LPIPS-AlexNet's max-pools on the bf16 NHWC taps (round 6): 3 x 3 window, stride 2, no padding (torchvision alexnet
+// features[2] / [5]; reference stylex_train.py:404 through lpips 0.1.4).  ATen's channels_last bf16 kernel took 213 us per call
+// at B = 32 (16 MB in, 4 MB out: 75 GB/s) — 0.85 ms per train step for the four forward calls.  A lane owns 8 consecutive
+// channels of one output pixel (nine 16-byte loads); the window position of the maximum is kept (one byte per element, ATen's
+// rule: the FIRST maximum in (kh, kw) scan order, a NaN wins) so that the backward is a gather: an input pixel lies in at most
+// 2 x 2 windows and adds, in ascending window order, the gradients of those that chose it (fp32 sum, one rounding).
+__global__ __launch_bounds__(256) void maxpool3s2_nhwc_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y,
+                                                                  uint2* __restrict__ idx, int Hi, int Wi, int Ho, int Wo, int C8,
+                                                                  unsigned total) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cg = i % C8, ow = (i / C8) % Wo, oh = (i / (C8 * Wo)) % Ho, b = i / (C8 * Wo * Ho);
+        const uint4* xb = x + ((long)b * Hi * Wi) * C8 + cg;
+        float m[8];
+        unsigned pos[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -__builtin_inff(), pos[e] = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float v[8];
+                lp_unpack8(xb[((long)(2 * oh + kh) * Wi + (2 * ow + kw)) * C8], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > m[e] || v[e] != v[e]) m[e] = v[e], pos[e] = kh * 3 + kw;
+            }
+        y[i] = make_uint4(lp_pack2(m[0], m[1]), lp_pack2(m[2], m[3]), lp_pack2(m[4], m[5]), lp_pack2(m[6], m[7]));
+        idx[i] = make_uint2(pos[0] | pos[1] << 8 | pos[2] << 16 | pos[3] << 24, pos[4] | pos[5] << 8 | pos[6] << 16 | pos[7] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool3s2_nhwc_bwd_kernel(const uint4* __restrict__ gy, const uint2* __restrict__ idx,
+                                                                  uint4* __restrict__ gx, int Hi, int Wi, int Ho, int Wo, int C8,
+                                                                  unsigned total) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cg = i % C8, iw = (i / C8) % Wi, ih = (i / (C8 * Wi)) % Hi, b = i / (C8 * Wi * Hi);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const int oh0 = ih >= 2 ? (int)(ih - 1) / 2 : 0, oh1 = min((int)ih / 2, Ho - 1);  // windows with 2*oh <= ih <= 2*oh + 2
+        const int ow0 = iw >= 2 ? (int)(iw - 1) / 2 : 0, ow1 = min((int)iw / 2, Wo - 1);
+        for (int oh = oh0; oh <= oh1; ++oh)
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const long o = (((long)b * Ho + oh) * Wo + ow) * C8 + cg;
+                const unsigned me = (ih - 2 * oh) * 3 + (iw - 2 * ow);
+                const uint2 p = idx[o];
+                float g[8];
+                lp_unpack8(gy[o], g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned pe = ((e < 4 ? p.x : p.y) >> (8 * (e & 3))) & 0xffu;
+                    acc[e] += pe == me ? g[e] : 0.f;
+                }
+            }
+        gx[i] = make_uint4(lp_pack2(acc[0], acc[1]), lp_pack2(acc[2], acc[3]), lp_pack2(acc[4], acc[5]), lp_pack2(acc[6], acc[7]));
+    }
+}
+
 // ---- input gradient of a frozen network's FIRST convolution (round 6) -------------------------------------------------------
 // dx[b][c][ih][iw] = sum_n sum_{kh,kw} dy[b][n][(ih + pad - kh) / S][(iw + pad - kw) / S] * w[n][c][kh][kw]   (exact divisions only)
 // for the K x K / stride-S stems whose input is the 3-channel image: ResNet conv1 (7 x 7, stride 2, pad 3; torchvision
@@ -958,6 +1016,37 @@ int stylex_resize_norm_bwd(const float* gy, float* gx, const float* stdv, const 
     if (total > 0x7fffffffLL || sh[0] * sh[1] * sh[4] * sh[5] > 0x7fffffffLL) return STYLEX_EINVAL;
     hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3(grid_for((unsigned long)total)), dim3(256), 0, (hipStream_t)stream, gy, gx, stdv,
                        (int)sh[1], (int)sh[2], (int)sh[3], (int)sh[4], (int)sh[5], (unsigned)total);
+    return (int)hipGetLastError();
+}
+
+// sh = {B, Hi, Wi, C}: x / gx [B][Hi][Wi][C] bf16, y / gy [B][Ho][Wo][C] bf16, idx [B][Ho][Wo][C] bytes; Ho = (Hi - 3) / 2 + 1
+static int maxpool_dims(const int64_t* sh, int* Ho, int* Wo) {
+    if (!sh || sh[0] <= 0 || sh[1] < 3 || sh[2] < 3 || sh[3] < 8 || sh[3] % 8) return STYLEX_EINVAL;
+    *Ho = (int)((sh[1] - 3) / 2 + 1);
+    *Wo = (int)((sh[2] - 3) / 2 + 1);
+    if (sh[0] * sh[1] * sh[2] * (sh[3] / 8) > 0x7fffffffLL) return STYLEX_EINVAL;
+    return 0;
+}
+
+int stylex_maxpool3s2_nhwc_fwd(const void* x, void* y, void* idx, const int64_t* sh, void* stream) {
+    int Ho, Wo;
+    if (!x || !y || !idx || maxpool_dims(sh, &Ho, &Wo)) return STYLEX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15 || (reinterpret_cast<uintptr_t>(idx) & 7)) return STYLEX_EINVAL;
+    const int C8 = (int)(sh[3] / 8);
+    const unsigned total = (unsigned)(sh[0] * Ho * Wo * C8);
+    hipLaunchKernelGGL(maxpool3s2_nhwc_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y,
+                       (uint2*)idx, (int)sh[1], (int)sh[2], Ho, Wo, C8, total);
+    return (int)hipGetLastError();
+}
+
+int stylex_maxpool3s2_nhwc_bwd(const void* gy, const void* idx, void* gx, const int64_t* sh, void* stream) {
+    int Ho, Wo;
+    if (!gy || !gx || !idx || maxpool_dims(sh, &Ho, &Wo)) return STYLEX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15 || (reinterpret_cast<uintptr_t>(idx) & 7)) return STYLEX_EINVAL;
+    const int C8 = (int)(sh[3] / 8);
+    const unsigned total = (unsigned)(sh[0] * sh[1] * sh[2] * C8);
+    hipLaunchKernelGGL(maxpool3s2_nhwc_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)gy,
+                       (const uint2*)idx, (uint4*)gx, (int)sh[1], (int)sh[2], Ho, Wo, C8, total);
     return (int)hipGetLastError();
 }
 

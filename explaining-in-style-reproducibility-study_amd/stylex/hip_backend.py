@@ -122,6 +122,8 @@ SIGNATURES = {
     "stylex_resize_norm_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _i64p, _i64p, ctypes.c_void_p]),
     "stylex_resize_norm_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_relu_gate_add": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_void_p]),
+    "stylex_maxpool3s2_nhwc_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
+    "stylex_maxpool3s2_nhwc_bwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_conv_image_grad": (ctypes.c_int, [_c_f, _c_f, _c_f, _i64p, ctypes.c_void_p]),
     "stylex_lpips_tap_fwd": (ctypes.c_int, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p]),
@@ -1061,6 +1063,31 @@ def relu_gate_add(a, b, y):
     out = torch.empty_like(a)
     _check(lib.stylex_relu_gate_add(_ptr(a), _ptr(b), _ptr(y), _ptr(out), a.numel(), _stream()), "stylex_relu_gate_add")
     return out
+
+
+def maxpool3s2_cl_fwd(x):
+    """nn.MaxPool2d(3, 2) of a bf16 channels_last feature map (LPIPS-AlexNet's two pools): (y, idx) — idx one byte per element,
+    the window position of the first maximum, for maxpool3s2_cl_bwd (stylex_maxpool3s2_nhwc_fwd)."""
+    lib = _ensure_device(x)
+    assert x.dtype == torch.bfloat16 and is_cl(x) and x.shape[1] % 8 == 0 and x.shape[2] >= 3 and x.shape[3] >= 3, (x.dtype, x.shape)
+    b, c, h, w = x.shape
+    ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    y = _empty((b, c, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    idx = torch.empty((b, ho, wo, c), dtype=torch.uint8, device=x.device)
+    _check(lib.stylex_maxpool3s2_nhwc_fwd(_ptr(x), _ptr(y), _ptr(idx), _shape(b, h, w, c), _stream()), "stylex_maxpool3s2_nhwc_fwd")
+    return y, idx
+
+
+def maxpool3s2_cl_bwd(gy, idx, in_hw):
+    """Gradient of maxpool3s2_cl_fwd for an input of height / width `in_hw` (stylex_maxpool3s2_nhwc_bwd)."""
+    lib = _ensure_device(gy)
+    assert gy.dtype == torch.bfloat16 and is_cl(gy) and idx.dtype == torch.uint8
+    b, c, ho, wo = gy.shape
+    h, w = int(in_hw[0]), int(in_hw[1])
+    assert tuple(idx.shape) == (b, ho, wo, c) and ho == (h - 3) // 2 + 1 and wo == (w - 3) // 2 + 1
+    gx = _empty((b, c, h, w), dtype=torch.bfloat16, device=gy.device, memory_format=torch.channels_last)
+    _check(lib.stylex_maxpool3s2_nhwc_bwd(_ptr(gy), _ptr(idx), _ptr(gx), _shape(b, h, w, c), _stream()), "stylex_maxpool3s2_nhwc_bwd")
+    return gx
 
 
 def nchw_to_cl_bf16(x, relu=False):

@@ -24,6 +24,28 @@ _ALEX = [(3, 64, 11, 4, 2, False, 0), (64, 192, 5, 1, 2, True, 3), (192, 384, 3,
          (384, 256, 3, 1, 1, False, 8), (256, 256, 3, 1, 1, False, 10)]
 
 
+class _MaxPool3s2CL(torch.autograd.Function):
+    """MaxPool2d(3, 2) of a bf16 channels_last tap on csrc/frozen_ew.hip's kernels (round 6): ATen's channels_last bf16 kernel
+    took 213 us per call at B = 32 (0.85 ms per train step); same maxima, same choice among equal values as ATen."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import hip_backend as hb
+
+        y, idx = hb.maxpool3s2_cl_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        import hip_backend as hb
+
+        (idx,) = ctx.saved_tensors
+        return hb.maxpool3s2_cl_bwd(gy.contiguous(memory_format=torch.channels_last), idx, ctx.in_hw)
+
+
 class LPIPS(nn.Module):
     def __init__(self, net="alex", seed=4242, **_):
         super().__init__()
@@ -82,7 +104,7 @@ class LPIPS(nn.Module):
                 for i in range(1, len(_ALEX)):
                     _, _, _, s, p, mp, _ = _ALEX[i]
                     if mp:
-                        t = F.max_pool2d(t, 3, 2)
+                        t = _MaxPool3s2CL.apply(t) if os.environ.get("STYLEX_LPIPS_POOL", "1") != "0" else F.max_pool2d(t, 3, 2)
                     t = ops.conv2d(t, self.cw[i], self.cb[i], stride=s, padding=p, lrelu="relu")
                     out.append(t)
         finally:

@@ -305,6 +305,16 @@ int stylex_relu_gate_add(const void* a, const void* b, const void* y, void* out,
 int stylex_nchw_f32_to_nhwc_bf16(const float* x, void* y, int64_t B, int64_t C, int64_t HW, int relu, void* stream);
 int stylex_nhwc_bf16_to_nchw_f32(const void* g, const void* gate, float* gx, int64_t B, int64_t C, int64_t HW, void* stream);
 
+/* ---- LPIPS-AlexNet's max-pools on bf16 NHWC feature maps (round 6) --------------------------------
+ * nn.MaxPool2d(kernel_size=3, stride=2) of torchvision's AlexNet features[2] / [5] (LPIPS-AlexNet: reference
+ * stylex/stylex_train.py:404 through lpips 0.1.4) for this library's bf16 channels_last taps (lpips_alex._taps_bf16).
+ *   sh = {B, Hi, Wi, C}, C % 8 == 0, Hi, Wi >= 3;  Ho = (Hi - 3) / 2 + 1, Wo likewise.
+ *   fwd: y[b][oh][ow][c] = max over the window; idx[b][oh][ow][c] (one byte) = kh * 3 + kw of the FIRST maximum in scan order
+ *        (a NaN wins) — ATen's rule, so the gradient goes where max_pool2d_with_indices_backward sends it.
+ *   bwd: gx[b][ih][iw][c] = sum of gy over the (at most 2 x 2) windows that chose (ih, iw); fp32 sum, one rounding. */
+int stylex_maxpool3s2_nhwc_fwd(const void* x, void* y, void* idx, const int64_t* sh, void* stream);
+int stylex_maxpool3s2_nhwc_bwd(const void* gy, const void* idx, void* gx, const int64_t* sh, void* stream);
+
 /* ---- input gradient of a frozen network's first convolution (round 6) ---------------------------
  * The K x K / stride-S stem over the 3-channel image of the frozen classifier (torchvision ResNet conv1: 7 x 7 / 2 / pad 3,
  * reference stylex/resnet_classifier.py:19, 56-71) and of LPIPS-AlexNet (11 x 11 / 4 / pad 2, reference stylex_train.py:404):

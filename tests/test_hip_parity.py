@@ -1876,6 +1876,36 @@ def test_layout_bridge_kernels(shape):
     assert torch.equal(hb.relu_gate_add(gy, None, gate), (gy.float() * (gate.float() > 0)).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 63, 63), (3, 192, 31, 31), (1, 8, 3, 3), (2, 16, 8, 11), (1, 24, 4, 7)])
+def test_maxpool_3x3_stride_2_on_bf16_nhwc_vs_aten(shape):
+    """stylex_maxpool3s2_nhwc_fwd / _bwd (round 6: LPIPS-AlexNet's two pools on the bf16 channels_last taps) against
+    F.max_pool2d(x, 3, 2) and its autograd: the maxima exactly, the gradient exactly — including WHICH element of a window
+    with equal values receives it (post-ReLU taps are full of equal zeros: ATen takes the first maximum in scan order) —
+    on the two LPIPS shapes, the smallest window, odd / even sizes whose last rows and columns no window covers, and with
+    NaNs (a NaN is the maximum of its window)."""
+    import lpips_alex
+
+    B, C, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(64)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g).relu()  # many ties at zero
+    x = (x * 4).round() / 4  # and ties among the positive values
+    if H * W > 20:
+        x[0, 0, 1, 1] = float("nan")
+        x[-1, -1, H - 2, W - 2] = float("nan")
+    xb = cl(x.to(torch.bfloat16))
+    x1 = xb.clone().requires_grad_()
+    x2 = xb.clone().requires_grad_()
+    y1 = lpips_alex._MaxPool3s2CL.apply(x1)
+    y2 = F.max_pool2d(x2, 3, 2)
+    assert y1.shape == y2.shape and y1.dtype == torch.bfloat16 and hb.is_cl(y1)
+    assert torch.equal(torch.nan_to_num(y1.float(), nan=-7.0), torch.nan_to_num(y2.float(), nan=-7.0))
+    gy = cl(torch.randn(y2.shape, device=DEV, generator=g).to(torch.bfloat16))
+    y1.backward(gy)
+    y2.backward(gy)
+    assert x1.grad.dtype == torch.bfloat16 and hb.is_cl(x1.grad)
+    assert torch.equal(x1.grad, x2.grad), float((x1.grad.float() - x2.grad.float()).abs().max())
+
+
 def test_timing_pause_keeps_frozen_network_launches_out_of_the_classes():
     """hb.timing_pause(): conv launches of the calling thread inside the block are not recorded by the timing hook, and an
     autograd node built inside carries the pause into its backward (which runs on the engine's thread) — so that the frozen

@@ -20,7 +20,7 @@ from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 import bench  # noqa: E402
 
-a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir="/tmp/sb", precision="bf16")
+a = argparse.Namespace(batch=32, image_size=256, gae=2, classifier="resnet", workdir="/tmp/sb", precision="bf16", device_rng=1)  # bench.py's defaults
 sys.path[:0] = [os.path.join(ROOT, "explaining-in-style-reproducibility-study_amd", "stylex")]
 import hip_backend as hb  # noqa: E402
 import ops  # noqa: E402
