@@ -2643,6 +2643,29 @@ def test_two_ranks_on_one_gpu_exchange_gradients_over_gloo():
     assert rep["ranks"][0]["scalars_overlap"] != rep["ranks"][1]["scalars_overlap"]  # the ranks saw different data
 
 
+@pytest.mark.timeout(900)
+def test_bench_py_two_ranks_on_one_gpu():
+    """bench.py's N = 2 code path with the real kernels (tools/bench_two_ranks_one_gpu.py: both ranks on cuda:0, gloo): the
+    process group, the barriers, the MAX-reduced timing, the instrumented roofline steps with their collectives on every
+    rank, one JSON line from rank 0 with n_gpus 2 / dp2 and no CPU baseline (N = 1 only).  Its images/s is not a scaling
+    number (two ranks share the GPU and the buckets travel through the host)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_two_ranks_one_gpu.py"), "--steps", "3", "--warmup", "2",
+                        "--bench-a-steps", "0", "--fp32-steps", "0", "--roofline-steps", "1"], capture_output=True, text=True,
+                       timeout=800, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and rep["config"]["parallelism"] == "dp2" and rep["scaling"] == "weak"
+    assert rep["config"]["global_batch"] == 2 * rep["config"]["batch_per_gpu"]
+    assert rep["value"] > 0 and rep["cpu_baseline"] is None and rep["roofline"]["launches"] > 0
+
+
 def test_adam_pack_step_matches_torch_fused_adam_and_the_pack_kernels():
     """csrc/adam_pack.hip (round 4): ONE launch = the Adam update of torch._fused_adam_ on the optimiser's own state
     tensors + every cached operand copy of the stepped weights rewritten from the updated values.  Against two reference
